@@ -1,0 +1,581 @@
+/*
+ * v2p_phys_oracle.c -- CPU restatement (plain C, float64, dense linear algebra) of the
+ * articulated rigid-body step that replaces `gym.simulate` for the SMPL humanoid.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Linked/loaded by tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py as the checker; the product (vid2player3d_amd/) never
+ * touches it.
+ *
+ * PARITY UNPINNED.  The reference delegates this step to Isaac Gym Preview 4 / PhysX 5 GPU
+ * (closed binary, absent from /root/reference; call sites embodied_pose/env/tasks/
+ * base_task.py:450-454, humanoid_smpl_im.py:134,154,453-467; parameters
+ * embodied_pose/cfg/amass_im.yaml:32-52, embodied_pose/utils/config.py:190-222; actor
+ * setup humanoid_smpl_im.py:273-276,356-389).  No golden vectors exist for it and none can
+ * be produced here.  What this file pins instead is the *published algorithm class* PhysX
+ * implements -- reduced-coordinate articulation (floating base + spherical joints), implicit
+ * PD joint drives, convex-hull-vertex vs ground-plane contact with a <=4 point manifold per
+ * body, projected Gauss-Seidel contact/friction rows, semi-implicit Euler -- written the
+ * slow, obviously-correct way (body Jacobians, dense mass matrix, Cholesky) so that the HIP
+ * kernels, which use an O(n) articulated-body recursion, can be checked against an
+ * independent formulation.  Physical invariants (energy, momentum, rest contact) are checked
+ * on top in tests/test_phys_oracle.py.
+ *
+ * Model ("v2p physics v1"), one substep of length h:
+ *   generalized velocity  v = [xdot_0 (world), w_0 (world), wrel_b (b=1..B-1, body-b axes)]
+ *   Mt = M(q) + diag_joint(armature + h*kd + h^2*kp)
+ *   v* = v + h * Mt^-1 ( Q_ext - C(q,v) + kp*(q_tar - q) - (kd + h*kp)*wrel )
+ *        q = exponential-map coordinates of the joint quaternion (the reference's dof_pos
+ *        convention, embodied_pose/utils/motion_lib.py:460-488)
+ *   contacts: hull vertices with z < contact_offset; <=4 per body (deepest, farthest,
+ *        extreme left/right); rows n,t1,t2 per point; bias = d/h (d>=0) or
+ *        max(erp*d/h, -max_depenetration_velocity) (d<0); box friction |lt| <= mu*ln
+ *   PGS: n_iter sweeps, bodies ascending, points in slot order, rows n,t1,t2
+ *   v+ = v* + Mt^-1 J^T lambda;  angular damping 1/(1+h*c); |w| clamp; integrate.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define NB 24
+#define NJ (NB - 1)
+#define ND (6 + 3 * NJ)
+#define MAXC_BODY 4
+#define MAXROWS (NB * MAXC_BODY * 3)
+
+typedef struct {
+    int parents[NB];
+    double local_pos[NB][3];
+    double mass[NB];
+    double com[NB][3];
+    double inertia[NB][9]; /* about COM, body axes */
+    double kp[3 * NJ], kd[3 * NJ], armature[3 * NJ];
+    int hull_offsets[NB + 1];
+    const double *hull_verts; /* [V][3] body frame */
+} v2p_omodel;
+
+typedef struct {
+    double h;
+    double gravity_z;      /* -9.81 */
+    double mu;             /* 1.0 */
+    double contact_offset; /* 0.02 */
+    double max_depen_vel;  /* 10.0 */
+    double ang_damp;       /* 0.01 */
+    double max_ang_vel;    /* 100.0 */
+    double erp;            /* 0.2: fraction of a penetration corrected per substep */
+    int n_iter;            /* 4 */
+    int enable_contact;
+} v2p_oparams;
+
+typedef struct {
+    double root_pos[3];
+    double root_quat[4];  /* xyzw */
+    double jquat[NJ][4];  /* parent->child, xyzw */
+    double vel[ND];
+} v2p_ostate;
+
+/* ------------------------------------------------------------------ small helpers */
+static void cross(const double a[3], const double b[3], double o[3]) {
+    double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+static double dot3(const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static void qmul(const double a[4], const double b[4], double o[4]) {
+    double x = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    double y = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+    double z = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+    double w = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+    o[0] = x; o[1] = y; o[2] = z; o[3] = w;
+}
+static void qnormalize(double q[4]) {
+    double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int i = 0; i < 4; ++i) q[i] /= n;
+}
+static void q2mat(const double q[4], double R[9]) {
+    double x = q[0], y = q[1], z = q[2], w = q[3];
+    R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w);     R[2] = 2 * (x * z + y * w);
+    R[3] = 2 * (x * y + z * w);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+    R[6] = 2 * (x * z - y * w);     R[7] = 2 * (y * z + x * w);     R[8] = 1 - 2 * (x * x + y * y);
+}
+static void matvec(const double R[9], const double v[3], double o[3]) {
+    double x = R[0] * v[0] + R[1] * v[1] + R[2] * v[2];
+    double y = R[3] * v[0] + R[4] * v[1] + R[5] * v[2];
+    double z = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+/* rotation vector -> quaternion */
+static void rotvec2quat(const double v[3], double q[4]) {
+    double a = sqrt(dot3(v, v));
+    double k = a > 1e-12 ? sin(0.5 * a) / a : 0.5;
+    q[0] = v[0] * k; q[1] = v[1] * k; q[2] = v[2] * k; q[3] = cos(0.5 * a);
+}
+/* quaternion -> exponential map, the reference's convention
+ * (embodied_pose/utils/torch_utils.py:82-119): angle = wrap(2 acos w), axis = xyz/sqrt(1-w^2),
+ * default axis z and angle 0 when |sin| <= 1e-5. */
+static void quat2expmap(const double q[4], double e[3]) {
+    double w = q[3];
+    double s2 = 1.0 - w * w;
+    double s = s2 > 0 ? sqrt(s2) : 0.0;
+    if (!(fabs(s) > 1e-5)) { e[0] = e[1] = e[2] = 0.0; return; }
+    double wc = w > 1 ? 1 : (w < -1 ? -1 : w);
+    double ang = 2.0 * acos(wc);
+    ang = atan2(sin(ang), cos(ang));
+    e[0] = ang * q[0] / s; e[1] = ang * q[1] / s; e[2] = ang * q[2] / s;
+}
+/* exponential map -> quaternion (torch_utils.py:144-166) */
+static void expmap2quat(const double e[3], double q[4]) {
+    double ang = sqrt(dot3(e, e));
+    double ax[3] = {0, 0, 1};
+    double angn = atan2(sin(ang), cos(ang));
+    if (fabs(angn) > 1e-5) { ax[0] = e[0] / ang; ax[1] = e[1] / ang; ax[2] = e[2] / ang; } else { angn = 0.0; }
+    double sh = sin(0.5 * angn);
+    q[0] = ax[0] * sh; q[1] = ax[1] * sh; q[2] = ax[2] * sh; q[3] = cos(0.5 * angn);
+    qnormalize(q);
+}
+
+/* ------------------------------------------------------------------ kinematics */
+typedef struct {
+    double R[NB][9];   /* world <- body */
+    double x[NB][3];   /* body origin, world */
+    double w[NB][3];   /* angular velocity, world */
+    double xd[NB][3];  /* origin linear velocity, world */
+    double quat[NB][4];
+} kin_t;
+
+static void kinematics(const v2p_omodel *m, const v2p_ostate *s, kin_t *k) {
+    for (int b = 0; b < NB; ++b) {
+        int p = m->parents[b];
+        if (p < 0) {
+            memcpy(k->quat[b], s->root_quat, sizeof(double) * 4);
+            memcpy(k->x[b], s->root_pos, sizeof(double) * 3);
+            q2mat(k->quat[b], k->R[b]);
+            for (int i = 0; i < 3; ++i) { k->xd[b][i] = s->vel[i]; k->w[b][i] = s->vel[3 + i]; }
+        } else {
+            qmul(k->quat[p], s->jquat[b - 1], k->quat[b]);
+            qnormalize(k->quat[b]);
+            q2mat(k->quat[b], k->R[b]);
+            double r[3], wr[3], t[3];
+            matvec(k->R[p], m->local_pos[b], r);
+            for (int i = 0; i < 3; ++i) k->x[b][i] = k->x[p][i] + r[i];
+            matvec(k->R[b], &s->vel[6 + 3 * (b - 1)], wr);
+            for (int i = 0; i < 3; ++i) k->w[b][i] = k->w[p][i] + wr[i];
+            cross(k->w[p], r, t);
+            for (int i = 0; i < 3; ++i) k->xd[b][i] = k->xd[p][i] + t[i];
+        }
+    }
+}
+
+/* body Jacobian: [w_b; xdot_b] = J_b v, J_b is 6 x ND (row-major) */
+static void body_jacobian(const v2p_omodel *m, const kin_t *k, int b, double *J) {
+    memset(J, 0, sizeof(double) * 6 * ND);
+    /* root linear */
+    for (int i = 0; i < 3; ++i) J[(3 + i) * ND + i] = 1.0;
+    /* root angular */
+    double r0[3] = {k->x[b][0] - k->x[0][0], k->x[b][1] - k->x[0][1], k->x[b][2] - k->x[0][2]};
+    for (int i = 0; i < 3; ++i) {
+        double e[3] = {0, 0, 0}, c[3];
+        e[i] = 1.0;
+        J[i * ND + 3 + i] = 1.0;
+        cross(e, r0, c);
+        for (int r = 0; r < 3; ++r) J[(3 + r) * ND + 3 + i] = c[r];
+    }
+    for (int a = b; a > 0; a = m->parents[a]) {
+        double ra[3] = {k->x[b][0] - k->x[a][0], k->x[b][1] - k->x[a][1], k->x[b][2] - k->x[a][2]};
+        for (int i = 0; i < 3; ++i) {
+            double ax[3] = {k->R[a][0 * 3 + i], k->R[a][1 * 3 + i], k->R[a][2 * 3 + i]}, c[3];
+            int col = 6 + 3 * (a - 1) + i;
+            for (int r = 0; r < 3; ++r) J[r * ND + col] = ax[r];
+            cross(ax, ra, c);
+            for (int r = 0; r < 3; ++r) J[(3 + r) * ND + col] = c[r];
+        }
+    }
+}
+
+/* spatial inertia at the body origin, world axes: [A B; B^T m1] */
+static void spatial_inertia(const v2p_omodel *m, const kin_t *k, int b, double I6[36], double d[3], double Ic[9]) {
+    const double *R = k->R[b];
+    double tmp[9];
+    /* Ic = R I R^T */
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int l = 0; l < 3; ++l) s += R[i * 3 + l] * m->inertia[b][l * 3 + j];
+            tmp[i * 3 + j] = s;
+        }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int l = 0; l < 3; ++l) s += tmp[i * 3 + l] * R[j * 3 + l];
+            Ic[i * 3 + j] = s;
+        }
+    matvec(R, m->com[b], d);
+    double ms = m->mass[b];
+    double dx[9] = {0, -d[2], d[1], d[2], 0, -d[0], -d[1], d[0], 0}; /* [d]x */
+    memset(I6, 0, sizeof(double) * 36);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double dd = 0; /* [d]x [d]x */
+            for (int l = 0; l < 3; ++l) dd += dx[i * 3 + l] * dx[l * 3 + j];
+            I6[i * 6 + j] = Ic[i * 3 + j] - ms * dd;
+            I6[i * 6 + 3 + j] = ms * dx[i * 3 + j];
+            I6[(3 + i) * 6 + j] = -ms * dx[i * 3 + j];
+        }
+    for (int i = 0; i < 3; ++i) I6[(3 + i) * 6 + 3 + i] = ms;
+}
+
+/* dense Cholesky (lower) in place; returns 0 on success */
+static int cholesky(double *A, int n) {
+    for (int j = 0; j < n; ++j) {
+        double s = A[j * n + j];
+        for (int k = 0; k < j; ++k) s -= A[j * n + k] * A[j * n + k];
+        if (s <= 0) return -1;
+        double l = sqrt(s);
+        A[j * n + j] = l;
+        for (int i = j + 1; i < n; ++i) {
+            double t = A[i * n + j];
+            for (int k = 0; k < j; ++k) t -= A[i * n + k] * A[j * n + k];
+            A[i * n + j] = t / l;
+        }
+    }
+    return 0;
+}
+static void chol_solve(const double *L, int n, double *b) {
+    for (int i = 0; i < n; ++i) {
+        double s = b[i];
+        for (int k = 0; k < i; ++k) s -= L[i * n + k] * b[k];
+        b[i] = s / L[i * n + i];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        double s = b[i];
+        for (int k = i + 1; k < n; ++k) s -= L[k * n + i] * b[k];
+        b[i] = s / L[i * n + i];
+    }
+}
+
+/* ------------------------------------------------------------------ dynamics terms */
+/* M (ND x ND) and bias C (Coriolis/centrifugal + gravity) via body Jacobians. */
+static void mass_and_bias(const v2p_omodel *m, const v2p_oparams *p, const v2p_ostate *s, const kin_t *k, double *M, double *C) {
+    double J[6 * ND];
+    double avp[NB][3], xvp[NB][3]; /* velocity-product accelerations (vdot = 0) */
+    memset(M, 0, sizeof(double) * ND * ND);
+    memset(C, 0, sizeof(double) * ND);
+    for (int b = 0; b < NB; ++b) {
+        int par = m->parents[b];
+        if (par < 0) {
+            for (int i = 0; i < 3; ++i) avp[b][i] = xvp[b][i] = 0.0;
+        } else {
+            double wr[3], t[3], r[3], t2[3];
+            matvec(k->R[b], &s->vel[6 + 3 * (b - 1)], wr);
+            cross(k->w[par], wr, t);
+            for (int i = 0; i < 3; ++i) avp[b][i] = avp[par][i] + t[i];
+            matvec(k->R[par], m->local_pos[b], r);
+            cross(avp[par], r, t);
+            cross(k->w[par], r, t2);
+            cross(k->w[par], t2, t2);
+            for (int i = 0; i < 3; ++i) xvp[b][i] = xvp[par][i] + t[i] + t2[i];
+        }
+        double I6[36], d[3], Ic[9];
+        spatial_inertia(m, k, b, I6, d, Ic);
+        body_jacobian(m, k, b, J);
+        /* M += J^T I6 J */
+        double IJ[6 * ND];
+        for (int r = 0; r < 6; ++r)
+            for (int c = 0; c < ND; ++c) {
+                double sum = 0;
+                for (int l = 0; l < 6; ++l) sum += I6[r * 6 + l] * J[l * ND + c];
+                IJ[r * ND + c] = sum;
+            }
+        for (int r = 0; r < ND; ++r)
+            for (int c = 0; c < ND; ++c) {
+                double sum = 0;
+                for (int l = 0; l < 6; ++l) sum += J[l * ND + r] * IJ[l * ND + c];
+                M[r * ND + c] += sum;
+            }
+        /* force needed with vdot=0: f6 = I6 a_vp + velocity terms - gravity */
+        double a6[6] = {avp[b][0], avp[b][1], avp[b][2], xvp[b][0], xvp[b][1], xvp[b][2]};
+        double f6[6];
+        for (int r = 0; r < 6; ++r) {
+            double sum = 0;
+            for (int l = 0; l < 6; ++l) sum += I6[r * 6 + l] * a6[l];
+            f6[r] = sum;
+        }
+        double Iw[3], wIw[3], wd[3], wwd[3], t[3];
+        const double *w = k->w[b];
+        matvec(Ic, w, Iw);
+        cross(w, Iw, wIw);
+        cross(w, d, wd);
+        cross(w, wd, wwd);
+        double ms = m->mass[b];
+        double g[3] = {0, 0, p->gravity_z};
+        double fl[3] = {ms * (wwd[0] - g[0]), ms * (wwd[1] - g[1]), ms * (wwd[2] - g[2])};
+        cross(d, fl, t);
+        for (int i = 0; i < 3; ++i) { f6[i] += wIw[i] + t[i]; f6[3 + i] += fl[i]; }
+        for (int c = 0; c < ND; ++c) {
+            double sum = 0;
+            for (int l = 0; l < 6; ++l) sum += J[l * ND + c] * f6[l];
+            C[c] += sum;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ contact generation */
+typedef struct {
+    int n;
+    int body[NB * MAXC_BODY];
+    int vert[NB * MAXC_BODY];
+    double pos[NB * MAXC_BODY][3];
+} contacts_t;
+
+static void gen_contacts(const v2p_omodel *m, const v2p_oparams *p, const kin_t *k, contacts_t *cs) {
+    cs->n = 0;
+    for (int b = 0; b < NB; ++b) {
+        int v0 = m->hull_offsets[b], v1 = m->hull_offsets[b + 1];
+        int nv = v1 - v0;
+        double (*P)[3] = malloc(sizeof(double[3]) * (size_t)nv);
+        int count = 0, first[4] = {-1, -1, -1, -1};
+        int k0 = -1;
+        double zmin = 0;
+        for (int i = 0; i < nv; ++i) {
+            double t[3];
+            matvec(k->R[b], &m->hull_verts[3 * (v0 + i)], t);
+            for (int c = 0; c < 3; ++c) P[i][c] = k->x[b][c] + t[c];
+            if (P[i][2] < p->contact_offset) {
+                if (count < 4) first[count] = i;
+                if (k0 < 0 || P[i][2] < zmin) { k0 = i; zmin = P[i][2]; }
+                ++count;
+            }
+        }
+        int sel[4], ns = 0;
+        if (count > 0 && count <= 4) {
+            for (int i = 0; i < count; ++i) sel[ns++] = first[i];
+        } else if (count > 4) {
+            int k1 = -1, k2 = -1, k3 = -1;
+            double best = -1.0;
+            for (int i = 0; i < nv; ++i) {
+                if (!(P[i][2] < p->contact_offset) || i == k0) continue;
+                double dx = P[i][0] - P[k0][0], dy = P[i][1] - P[k0][1];
+                double d2 = dx * dx + dy * dy;
+                if (d2 > best) { best = d2; k1 = i; }
+            }
+            double ex = P[k1][0] - P[k0][0], ey = P[k1][1] - P[k0][1];
+            double amax = 0.0, amin = 0.0;
+            for (int i = 0; i < nv; ++i) {
+                if (!(P[i][2] < p->contact_offset) || i == k0 || i == k1) continue;
+                double area = ex * (P[i][1] - P[k0][1]) - ey * (P[i][0] - P[k0][0]);
+                if (area > amax) { amax = area; k2 = i; }
+                if (area < amin) { amin = area; k3 = i; }
+            }
+            sel[ns++] = k0;
+            sel[ns++] = k1;
+            if (k2 >= 0) sel[ns++] = k2;
+            if (k3 >= 0) sel[ns++] = k3;
+        }
+        for (int i = 0; i < ns; ++i) {
+            int c = cs->n++;
+            cs->body[c] = b;
+            cs->vert[c] = sel[i];
+            memcpy(cs->pos[c], P[sel[i]], sizeof(double) * 3);
+        }
+        free(P);
+    }
+}
+
+/* ------------------------------------------------------------------ one substep */
+int v2p_oracle_substep(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s, const double *pd_target /*[69]*/,
+                       const double *ext_force /*[3] world, at root COM*/, const double *ext_torque /*[3] world*/,
+                       double *contact_force /*[NB*3] out*/, double *dof_force /*[69] out*/, int *contact_ids /*[NB*4] out: body*64+vertex, -1 padded*/) {
+    double *M = malloc(sizeof(double) * ND * ND), C[ND], J[6 * ND];
+    double rhs[ND], q[3 * NJ];
+    kin_t k;
+    const double h = p->h;
+    kinematics(m, s, &k);
+    mass_and_bias(m, p, s, &k, M, C);
+
+    /* generalized forces */
+    for (int i = 0; i < ND; ++i) rhs[i] = -C[i];
+    if (ext_force || ext_torque) {
+        double d[3], t[3], w6[6] = {0, 0, 0, 0, 0, 0};
+        matvec(k.R[0], m->com[0], d);
+        if (ext_force) { cross(d, ext_force, t); for (int i = 0; i < 3; ++i) { w6[i] += t[i]; w6[3 + i] += ext_force[i]; } }
+        if (ext_torque) for (int i = 0; i < 3; ++i) w6[i] += ext_torque[i];
+        body_jacobian(m, &k, 0, J);
+        for (int c = 0; c < ND; ++c) for (int l = 0; l < 6; ++l) rhs[c] += J[l * ND + c] * w6[l];
+    }
+    for (int b = 1; b < NB; ++b) quat2expmap(s->jquat[b - 1], &q[3 * (b - 1)]);
+    for (int j = 0; j < 3 * NJ; ++j) {
+        double wj = s->vel[6 + j];
+        double tar = pd_target ? pd_target[j] : q[j];
+        rhs[6 + j] += m->kp[j] * (tar - q[j]) - (m->kd[j] + h * m->kp[j]) * wj;
+        M[(6 + j) * ND + 6 + j] += m->armature[j] + h * m->kd[j] + h * h * m->kp[j];
+    }
+    if (cholesky(M, ND)) { free(M); return -1; }
+    chol_solve(M, ND, rhs);
+    double v[ND];
+    for (int i = 0; i < ND; ++i) v[i] = s->vel[i] + h * rhs[i];
+
+    /* contacts */
+    if (contact_force) memset(contact_force, 0, sizeof(double) * NB * 3);
+    if (contact_ids) for (int i = 0; i < NB * 4; ++i) contact_ids[i] = -1;
+    if (p->enable_contact) {
+        contacts_t cs;
+        gen_contacts(m, p, &k, &cs);
+        int nrow = cs.n * 3;
+        double *Jr = calloc((size_t)(nrow > 0 ? nrow : 1) * ND, sizeof(double));
+        double *Tr = calloc((size_t)(nrow > 0 ? nrow : 1) * ND, sizeof(double));
+        double *wii = calloc((size_t)(nrow > 0 ? nrow : 1), sizeof(double));
+        double *lam = calloc((size_t)(nrow > 0 ? nrow : 1), sizeof(double));
+        double *bias = calloc((size_t)(nrow > 0 ? nrow : 1), sizeof(double));
+        const double dirs[3][3] = {{0, 0, 1}, {1, 0, 0}, {0, 1, 0}};
+        int slot_in_body[NB];
+        memset(slot_in_body, 0, sizeof(slot_in_body));
+        for (int c = 0; c < cs.n; ++c) {
+            int b = cs.body[c];
+            if (contact_ids) contact_ids[b * 4 + slot_in_body[b]] = b * 64 + cs.vert[c];
+            slot_in_body[b]++;
+            body_jacobian(m, &k, b, J);
+            double r[3] = {cs.pos[c][0] - k.x[b][0], cs.pos[c][1] - k.x[b][1], cs.pos[c][2] - k.x[b][2]};
+            for (int a = 0; a < 3; ++a) {
+                int row = 3 * c + a;
+                double rxn[3];
+                cross(r, dirs[a], rxn); /* point velocity . n = n.xdot + (r x n).w */
+                for (int col = 0; col < ND; ++col) {
+                    double sum = 0;
+                    for (int l = 0; l < 3; ++l) sum += J[l * ND + col] * rxn[l] + J[(3 + l) * ND + col] * dirs[a][l];
+                    Jr[row * ND + col] = sum;
+                    Tr[row * ND + col] = sum;
+                }
+                chol_solve(M, ND, &Tr[row * ND]);
+                double sum = 0;
+                for (int col = 0; col < ND; ++col) sum += Jr[row * ND + col] * Tr[row * ND + col];
+                wii[row] = sum;
+            }
+            double d = cs.pos[c][2];
+            bias[3 * c] = d >= 0 ? d / h : fmax(p->erp * d / h, -p->max_depen_vel);
+        }
+        for (int it = 0; it < p->n_iter; ++it)
+            for (int c = 0; c < cs.n; ++c)
+                for (int a = 0; a < 3; ++a) {
+                    int row = 3 * c + a;
+                    double rel = bias[row];
+                    for (int col = 0; col < ND; ++col) rel += Jr[row * ND + col] * v[col];
+                    double nl = lam[row] - rel / wii[row];
+                    if (a == 0) { if (nl < 0) nl = 0; }
+                    else { double lim = p->mu * lam[3 * c]; if (nl > lim) nl = lim; if (nl < -lim) nl = -lim; }
+                    double dl = nl - lam[row];
+                    lam[row] = nl;
+                    for (int col = 0; col < ND; ++col) v[col] += Tr[row * ND + col] * dl;
+                }
+        if (contact_force)
+            for (int c = 0; c < cs.n; ++c) {
+                int b = cs.body[c];
+                contact_force[3 * b + 2] += lam[3 * c] / h;
+                contact_force[3 * b + 0] += lam[3 * c + 1] / h;
+                contact_force[3 * b + 1] += lam[3 * c + 2] / h;
+            }
+        free(Jr); free(Tr); free(wii); free(lam); free(bias);
+    }
+
+    /* joint drive torque actually applied (implicit form) */
+    if (dof_force)
+        for (int j = 0; j < 3 * NJ; ++j) {
+            double tar = pd_target ? pd_target[j] : q[j];
+            dof_force[j] = m->kp[j] * (tar - q[j] - h * v[6 + j]) - m->kd[j] * v[6 + j];
+        }
+
+    /* angular damping + angular velocity clamp, then integrate */
+    double sc = 1.0 / (1.0 + h * p->ang_damp);
+    for (int i = 3; i < ND; ++i) v[i] *= sc;
+    for (int g = 0; g < NB; ++g) {
+        double *w = &v[3 + 3 * g];
+        double n = sqrt(dot3(w, w));
+        if (n > p->max_ang_vel) { double f = p->max_ang_vel / n; w[0] *= f; w[1] *= f; w[2] *= f; }
+    }
+    memcpy(s->vel, v, sizeof(v));
+    for (int i = 0; i < 3; ++i) s->root_pos[i] += h * v[i];
+    double dq[4], rv[3], nq[4];
+    for (int i = 0; i < 3; ++i) rv[i] = h * v[3 + i];
+    rotvec2quat(rv, dq);
+    qmul(dq, s->root_quat, nq); /* world-frame rate: left multiply */
+    qnormalize(nq);
+    memcpy(s->root_quat, nq, sizeof(nq));
+    for (int b = 1; b < NB; ++b) {
+        for (int i = 0; i < 3; ++i) rv[i] = h * v[6 + 3 * (b - 1) + i];
+        rotvec2quat(rv, dq);
+        qmul(s->jquat[b - 1], dq, nq); /* body-frame rate: right multiply */
+        qnormalize(nq);
+        memcpy(s->jquat[b - 1], nq, sizeof(nq));
+    }
+    free(M);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ state <-> Isaac-Gym-style tensors */
+/* root[13] = pos3 quat4 linvel3 angvel3 (humanoid_smpl.py:66-113), dof_pos = exp-map, dof_vel = joint-frame rate */
+void v2p_oracle_set_state(v2p_ostate *s, const double *root13, const double *dof_pos, const double *dof_vel) {
+    memcpy(s->root_pos, root13, sizeof(double) * 3);
+    memcpy(s->root_quat, root13 + 3, sizeof(double) * 4);
+    qnormalize(s->root_quat);
+    memcpy(s->vel, root13 + 7, sizeof(double) * 6);
+    for (int b = 1; b < NB; ++b) {
+        expmap2quat(&dof_pos[3 * (b - 1)], s->jquat[b - 1]);
+        for (int i = 0; i < 3; ++i) s->vel[6 + 3 * (b - 1) + i] = dof_vel[3 * (b - 1) + i];
+    }
+}
+
+void v2p_oracle_get_state(const v2p_omodel *m, const v2p_ostate *s, double *root13, double *dof_pos, double *dof_vel, double *rb_state /*[NB*13]*/) {
+    kin_t k;
+    kinematics(m, s, &k);
+    if (root13) {
+        memcpy(root13, s->root_pos, sizeof(double) * 3);
+        memcpy(root13 + 3, s->root_quat, sizeof(double) * 4);
+        memcpy(root13 + 7, s->vel, sizeof(double) * 6);
+    }
+    for (int b = 1; b < NB; ++b) {
+        if (dof_pos) quat2expmap(s->jquat[b - 1], &dof_pos[3 * (b - 1)]);
+        if (dof_vel) for (int i = 0; i < 3; ++i) dof_vel[3 * (b - 1) + i] = s->vel[6 + 3 * (b - 1) + i];
+    }
+    if (rb_state)
+        for (int b = 0; b < NB; ++b) {
+            double *o = rb_state + 13 * b;
+            memcpy(o, k.x[b], sizeof(double) * 3);
+            memcpy(o + 3, k.quat[b], sizeof(double) * 4);
+            memcpy(o + 7, k.xd[b], sizeof(double) * 3);
+            memcpy(o + 10, k.w[b], sizeof(double) * 3);
+        }
+}
+
+/* one control step = nsub substeps; the residual wrench is held for the first `hold` substeps
+ * (Isaac Gym consumes applied forces in the next simulate() only: SURVEY.md section 7 hard parts). */
+int v2p_oracle_step(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s, const double *pd_target, const double *ext_force,
+                    const double *ext_torque, int nsub, int hold, double *contact_force, double *dof_force, int *contact_ids) {
+    for (int i = 0; i < nsub; ++i) {
+        int on = i < hold;
+        int rc = v2p_oracle_substep(m, p, s, pd_target, on ? ext_force : 0, on ? ext_torque : 0, contact_force, dof_force, contact_ids);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ diagnostics for invariant tests */
+/* kinetic energy, potential energy, linear momentum[3], angular momentum about the world origin[3] */
+void v2p_oracle_diagnostics(const v2p_omodel *m, const v2p_oparams *p, const v2p_ostate *s, double *out8) {
+    kin_t k;
+    kinematics(m, s, &k);
+    double ke = 0, pe = 0, P[3] = {0, 0, 0}, L[3] = {0, 0, 0};
+    for (int b = 0; b < NB; ++b) {
+        double I6[36], d[3], Ic[9], wd[3], vc[3], c[3], Iw[3], t[3];
+        spatial_inertia(m, &k, b, I6, d, Ic);
+        cross(k.w[b], d, wd);
+        for (int i = 0; i < 3; ++i) { vc[i] = k.xd[b][i] + wd[i]; c[i] = k.x[b][i] + d[i]; }
+        matvec(Ic, k.w[b], Iw);
+        ke += 0.5 * m->mass[b] * dot3(vc, vc) + 0.5 * dot3(k.w[b], Iw);
+        pe += -m->mass[b] * p->gravity_z * c[2];
+        cross(c, vc, t);
+        for (int i = 0; i < 3; ++i) { P[i] += m->mass[b] * vc[i]; L[i] += m->mass[b] * t[i] + Iw[i]; }
+    }
+    out8[0] = ke; out8[1] = pe;
+    for (int i = 0; i < 3; ++i) { out8[2 + i] = P[i]; out8[5 + i] = L[i]; }
+}
+
+int v2p_oracle_sizeof_model(void) { return (int)sizeof(v2p_omodel); }
+int v2p_oracle_sizeof_state(void) { return (int)sizeof(v2p_ostate); }
+int v2p_oracle_sizeof_params(void) { return (int)sizeof(v2p_oparams); }

@@ -1,0 +1,135 @@
+"""Physical-invariant checks of the C physics oracle (oracle/phys).  Parity with PhysX is unpinned
+(closed binary); these tests establish that the restatement is a self-consistent rigid-body model."""
+import numpy as np
+import pytest
+
+from oracle.phys_oracle import PhysOracle, default_params
+from vid2player3d_amd.model import load_baked_model
+
+BASE = np.array([0.5, 0.5, 0.5, 0.5])
+
+
+@pytest.fixture(scope="module")
+def model():
+    return load_baked_model()
+
+
+def standing_state(rng, height=0.95, pose_sigma=0.3, vel_sigma=1.0):
+    root = np.zeros(13)
+    root[2] = height
+    root[3:7] = BASE
+    root[7:13] = rng.normal(0, vel_sigma, 6)
+    return root, rng.normal(0, pose_sigma, 69), rng.normal(0, vel_sigma, 69)
+
+
+def _free_flight_drift(model, h, t_end=0.2):
+    rng = np.random.default_rng(0)
+    zeros = np.zeros(69)
+    o = PhysOracle(model, default_params(h=h, enable_contact=False, gravity_z=0.0, ang_damp=0.0), kp=zeros, kd=zeros, armature=zeros)
+    root, dp, dv = standing_state(rng, height=3.0)
+    o.set_state(root, dp, dv)
+    d0 = o.diagnostics()
+    for _ in range(int(round(t_end / h))):
+        o.step(nsub=1, hold=0)
+    d1 = o.diagnostics()
+    return (np.abs(d1["P"] - d0["P"]).max() / np.abs(d0["P"]).max(), np.abs(d1["L"] - d0["L"]).max() / np.abs(d0["L"]).max(),
+            abs(d1["ke"] - d0["ke"]) / d0["ke"])
+
+
+def test_free_flight_conserves_momentum_and_energy(model):
+    """Torque-free, gravity-free flight: linear/angular momentum and kinetic energy are conserved by the
+    continuous model, so the discrete drift must be small AND first order in h (a wrong Coriolis/bias
+    term would leave an h-independent residual)."""
+    coarse = _free_flight_drift(model, 1e-3)
+    fine = _free_flight_drift(model, 2.5e-4)
+    for c, f in zip(coarse, fine):
+        assert c < 2e-2
+        assert f < 0.4 * c, (coarse, fine)
+
+
+def test_free_fall_momentum_rate_is_weight(model):
+    rng = np.random.default_rng(1)
+    zeros = np.zeros(69)
+    o = PhysOracle(model, default_params(h=1.0 / 120, enable_contact=False, ang_damp=0.0), kp=zeros, kd=zeros, armature=zeros)
+    root, dp, dv = standing_state(rng, height=5.0)
+    root[10:13] = 0.0
+    o.set_state(root, dp, 0.0 * dv)   # no internal motion: the discrete update is exact
+    d0 = o.diagnostics()
+    n = 30
+    for _ in range(n):
+        o.step(nsub=1, hold=0)
+    d1 = o.diagnostics()
+    expect = d0["P"] + np.array([0, 0, -9.81 * model.total_mass * n / 120.0])
+    assert np.allclose(d1["P"], expect, atol=1e-6 * model.total_mass)
+
+
+def test_energy_is_dissipated_by_drives(model):
+    """With PD drives holding the current pose (target = q) and no gravity, kinetic energy can only fall."""
+    rng = np.random.default_rng(2)
+    o = PhysOracle(model, default_params(enable_contact=False, gravity_z=0.0))
+    root, dp, dv = standing_state(rng, height=3.0, vel_sigma=2.0)
+    o.set_state(root, dp, dv)
+    ke = [o.diagnostics()["ke"]]
+    for _ in range(20):
+        o.step(pd_target=o.get_state()[1], nsub=1, hold=0)
+        ke.append(o.diagnostics()["ke"])
+    assert all(b <= a * (1 + 1e-9) for a, b in zip(ke, ke[1:]))
+    assert ke[-1] < ke[0]
+    assert np.abs(o.get_state()[2]).max() < 0.25 * np.abs(dv).max()   # joint rates are damped out; free-root motion remains
+
+
+def test_external_wrench_changes_momentum(model):
+    zeros = np.zeros(69)
+    o = PhysOracle(model, default_params(enable_contact=False, gravity_z=0.0, ang_damp=0.0), kp=zeros, kd=zeros, armature=zeros)
+    root = np.zeros(13)
+    root[2] = 2.0
+    root[3:7] = BASE
+    o.set_state(root, np.zeros(69), np.zeros(69))
+    f = np.array([10.0, -20.0, 30.0])
+    o.step(ext_force=f, ext_torque=np.zeros(3), nsub=4, hold=2)
+    assert np.allclose(o.diagnostics()["P"], f * 2 / 120.0, rtol=1e-3)
+
+
+def test_rest_contact_supports_weight(model):
+    """Standing on the plane with the drives holding the rest pose: the feet carry the body weight while
+    it is upright; it eventually tips over (no balance controller) and then rests on the ground, again
+    carried by the contacts, without tunnelling."""
+    o = PhysOracle(model)
+    root = np.zeros(13)
+    root[2] = 0.965
+    root[3:7] = BASE
+    pose = np.zeros(69)
+    o.set_state(root, pose, np.zeros(69))
+    weight = 9.81 * model.total_mass
+    fz = []
+    for _ in range(30):
+        cf, _, ids = o.step(pd_target=pose, nsub=4, hold=0)
+        fz.append(cf[:, 2].sum())
+    rb = o.get_state()[3]
+    assert rb[13, 2] > 1.5                                   # still upright after 1 s
+    assert abs(np.mean(fz[-15:]) - weight) < 0.1 * weight
+    assert set(np.nonzero((ids >= 0).any(axis=1))[0].tolist()) <= {3, 4, 7, 8}   # only feet touch
+    for _ in range(100):
+        cf, _, ids = o.step(pd_target=pose, nsub=4, hold=0)
+        fz.append(cf[:, 2].sum())
+    rb = o.get_state()[3]
+    assert rb[13, 2] < 0.4                                   # fell over
+    assert rb[:, 2].min() > -0.02                            # nothing tunnels the plane
+    assert abs(np.mean(fz[-20:]) - weight) < 0.1 * weight
+
+
+def test_contact_manifold_is_bounded_and_deterministic(model):
+    o = PhysOracle(model)
+    root = np.zeros(13)
+    root[2] = 0.12                                     # lying on its back/side: many bodies touch
+    root[3:7] = [0.0, 0.0, 0.0, 1.0]
+    o.set_state(root, np.zeros(69), np.zeros(69))
+    _, _, ids = o.step(pd_target=np.zeros(69), nsub=1, hold=0)
+    o.set_state(root, np.zeros(69), np.zeros(69))
+    _, _, ids2 = o.step(pd_target=np.zeros(69), nsub=1, hold=0)
+    assert np.array_equal(ids, ids2)
+    assert (ids >= 0).sum() > 12
+    for b in range(24):
+        sel = ids[b][ids[b] >= 0]
+        assert len(set(sel.tolist())) == len(sel)
+        assert all(v // 64 == b for v in sel)
