@@ -1,0 +1,212 @@
+/*
+ * v2p_rollout.h -- C ABI of the MI355X-native rollout engine for vid2player3d's
+ * embodied_pose SMPL-humanoid imitation task.
+ *
+ * This is the drop-in boundary.  The reference's task object
+ * (embodied_pose/env/tasks/humanoid_smpl_im.py) talks to Isaac Gym through ~25 gym.* calls;
+ * the entry points below are what a reference-side binding would call instead.  Each entry
+ * point names the reference interface it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - plain C, no torch types.  Every `float*`/`int64_t*` is a DEVICE pointer owned by the
+ *     caller (PyTorch-ROCm tensors on the Python side); the library never frees them.
+ *   - row-major, fp32 data, int64 flags/indices (reference buffer dtypes, base_task.py:62-74),
+ *     quaternions xyzw.
+ *   - every call returns 0 on success or a negative v2p_status; v2p_last_error() returns a
+ *     thread-local message.  The Python shim turns non-zero codes into RuntimeError (the
+ *     reference's error convention is Python exceptions).
+ *   - calls are asynchronous on the hipStream_t passed as `void* stream` (NULL = default
+ *     stream); a handle is single-threaded; handles on different GPUs are independent.
+ *   - B = 24 bodies, D = 69 dofs, A = 75 actions, OBS = 461.
+ */
+#ifndef V2P_ROLLOUT_H
+#define V2P_ROLLOUT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define V2P_NUM_BODIES 24
+#define V2P_NUM_DOF 69
+#define V2P_NUM_ACTIONS 75
+#define V2P_NUM_OBS 461
+#define V2P_MOTION_STATE_DIM 331  /* root_pos3 root_rot4 dof_pos69 root_vel3 root_ang_vel3 dof_vel69 key_pos12 rb_pos72 rb_rot96 */
+#define V2P_CONTEXT_DIM 378       /* body_pos72 body_rot96 dof_pos69 body_pos_gt72 dof_pos_gt69 (humanoid_smpl_im.py:202) */
+#define V2P_ABI_VERSION 1
+
+typedef enum {
+    V2P_OK = 0,
+    V2P_ERR_INVALID = -1,     /* bad argument */
+    V2P_ERR_UNSUPPORTED = -2, /* valid in the reference, not built yet (e.g. anisotropic joint gains) */
+    V2P_ERR_HIP = -3,         /* HIP runtime error */
+    V2P_ERR_NOMEM = -4
+} v2p_status;
+
+typedef struct v2p_model v2p_model; /* body model (host copy + device constants) */
+typedef struct v2p_mlib v2p_mlib;   /* reference-motion tables (device pointers, not owned) */
+typedef struct v2p_env v2p_env;     /* a batch of environments on one GPU */
+
+/* ---- body model -------------------------------------------------------------------------
+ * Replaces gym.load_asset / create_actor / get+set_actor_dof_properties /
+ * get_actor_rigid_body_properties (humanoid_smpl_im.py:273-287, 356-389): the caller hands
+ * over the compiled model (HOST pointers; copied). */
+typedef struct {
+    int32_t num_bodies;          /* must be 24 */
+    const int32_t* parents;      /* [B]   -1 for the root */
+    const float* local_pos;      /* [B,3] joint offset in the parent frame */
+    const float* mass;           /* [B] */
+    const float* com;            /* [B,3] body frame */
+    const float* inertia;        /* [B,9] about COM, body axes */
+    const float* kp;             /* [D] already scaled by body mass (humanoid_smpl_im.py:376-385) */
+    const float* kd;             /* [D] */
+    const float* armature;       /* [D] */
+    const int32_t* hull_offsets; /* [B+1] */
+    const float* hull_verts;     /* [V,3] body frame */
+} v2p_model_desc;
+
+int v2p_model_create(const v2p_model_desc* desc, int device, v2p_model** out);
+void v2p_model_destroy(v2p_model* m);
+
+/* ---- reference-motion tables ------------------------------------------------------------
+ * Replaces the tensor attributes of utils/motion_lib.py:MotionLib (motion_lib.py:78-99,
+ * 370-384).  DEVICE pointers, borrowed for the lifetime of the handle. */
+typedef struct {
+    int64_t num_motions;
+    int64_t num_frames_total;
+    const float* gts;               /* [F,24,3] global translations */
+    const float* grs;               /* [F,24,4] global rotations */
+    const float* lrs;               /* [F,24,4] local rotations */
+    const float* grvs;              /* [F,3]  root linear velocity */
+    const float* gravs;             /* [F,3]  root angular velocity */
+    const float* dvs;               /* [F,69] dof velocities */
+    const float* motion_lengths;    /* [C] seconds */
+    const int64_t* motion_num_frames; /* [C] */
+    const float* motion_dt;         /* [C] */
+    const float* motion_min_verts_h; /* [C] */
+    const int64_t* length_starts;   /* [C] first row of each clip */
+    const float* motion_bodies;     /* [C,11] gender + 10 betas */
+    int32_t key_body_ids[4];        /* amass_im.yaml:17 -> R_Ankle, L_Ankle, L_Hand, R_Hand */
+} v2p_motion_tables;
+
+int v2p_mlib_create(const v2p_motion_tables* tables, int device, v2p_mlib** out);
+void v2p_mlib_destroy(v2p_mlib* m);
+
+/* MotionLib.get_motion_state(..., return_rigid_body=True) (motion_lib.py:164-266).
+ * `out` points to 9 device arrays in the order root_pos[Q,3] root_rot[Q,4] dof_pos[Q,69]
+ * root_vel[Q,3] root_ang_vel[Q,3] dof_vel[Q,69] key_pos[Q,4,3] rb_pos[Q,24,3] rb_rot[Q,24,4];
+ * NULL entries are skipped. */
+int v2p_motion_state(const v2p_mlib* m, const int64_t* motion_ids, const float* motion_times, int64_t num_queries,
+                     int adjust_height, float ground_tolerance, float* const out[9], void* stream);
+
+/* ---- stand-alone task ops (op-level parity tests; also usable by an unmodified task) -----
+ * compute_humanoid_reward (humanoid_smpl_im.py:918-953); specs = k_dof,k_vel,k_pos,k_rot,
+ * w_dof,w_vel,w_pos,w_rot. */
+int v2p_reward(int64_t n, const float* body_pos, const float* body_rot, const float* tgt_pos, const float* tgt_rot,
+               const float* dof_pos, const float* dof_vel, const float* tgt_dof_pos, const float* tgt_dof_vel,
+               const float* body_pos_weights /*[24]*/, const float specs[8], float* reward /*[n]*/, float* sub_rewards /*[n,4]*/,
+               void* stream);
+/* compute_humanoid_reset (humanoid_smpl_im.py:956-987); contact bodies are excluded through
+ * `term_heights_masked` = termination heights with -inf at the contact bodies. */
+int v2p_reset_flags(int64_t n, const int64_t* progress, const float* rb_pos, const float* term_heights_masked /*[24]*/,
+                    const float* cur_time, const float* clip_len, float max_episode_length, int enable_early_termination,
+                    int64_t* reset_out, int64_t* terminated_out, void* stream);
+/* compute_humanoid_observations_imitation, the 734-d in-network observation
+ * (humanoid_smpl_im.py:773-850 == models/im_network_builder.py:262-338), local_root_obs =
+ * root_height_obs = True. */
+int v2p_obs_imitation(int64_t n, const float* body_pos, const float* body_rot, const float* tgt_pos, const float* tgt_rot,
+                      const float* dof_pos, const float* dof_vel, const float* tgt_dof_pos, const float* body_vel,
+                      const float* body_ang_vel, const float* motion_bodies /*[n,11]*/, float* obs /*[n,734]*/, void* stream);
+
+/* ---- environments -----------------------------------------------------------------------
+ * Simulation + task parameters (cfg/amass_im.yaml:3-52, utils/config.py:190-222). */
+typedef struct {
+    float sim_dt;               /* 1/60 (config.py:20) */
+    int32_t substeps;           /* 2   (amass_im.yaml:38) */
+    int32_t control_freq_inv;   /* 2   (amass_im.yaml:11)  -> control dt = 1/30, 4 physics substeps of 1/120 */
+    int32_t num_solver_iterations; /* 4 (num_position_iterations) */
+    int32_t enable_contact;     /* 0 = BASELINE config 2 (PD only) */
+    int32_t residual_hold_sims; /* simulate() calls during which the residual wrench acts: 1 (first_sim) .. control_freq_inv (all) */
+    float gravity_z;            /* -9.81 */
+    float friction;             /* 1.0 */
+    float contact_offset;       /* 0.02 */
+    float max_depenetration_velocity; /* 10 */
+    float erp;                  /* 0.2 */
+    float angular_damping;      /* 0.01 (humanoid_smpl_im.py:274) */
+    float max_angular_velocity; /* 100  (humanoid_smpl_im.py:275) */
+    float pd_tar_lim;           /* 0.5*pi (humanoid_smpl_im.py:73) */
+    float residual_force_scale; /* 31.85 */
+    float residual_torque_scale;
+    float ground_tolerance;     /* 0 */
+    float max_episode_length;   /* 300 */
+    int32_t enable_early_termination;
+    int32_t context_length;     /* 32 */
+    int32_t context_padding;    /* 8 */
+    float term_heights[24];     /* per body; contact bodies get -inf (humanoid_smpl_im.py:217-224, 956-987) */
+    float body_pos_weights[24]; /* humanoid_smpl_im.py:109-115 */
+    float reward_specs[8];      /* k_dof,k_vel,k_pos,k_rot,w_dof,w_vel,w_pos,w_rot (humanoid_smpl_im.py:682) */
+} v2p_sim_cfg;
+
+/* Caller-owned DEVICE buffers the engine reads/writes; these are the tensors the reference
+ * task exposes (humanoid_smpl.py:66-113, base_task.py:62-74, humanoid_smpl_im.py:594-636). */
+typedef struct {
+    float* root_states;    /* [N,13] pos3 quat4 linvel3 angvel3 */
+    float* dof_state;      /* [N,69,2] (pos, vel) interleaved like gym's dof state tensor */
+    float* rb_state;       /* [N,24,13] */
+    float* contact_force;  /* [N,24,3] net contact force per body */
+    float* dof_force;      /* [N,69] */
+    float* pd_target;      /* [N,69] clamped PD targets of the last step */
+    float* obs;            /* [N,461] */
+    float* rew;            /* [N] */
+    float* sub_rewards;    /* [N,4] */
+    int64_t* reset;        /* [N] */
+    int64_t* terminate;    /* [N] */
+    int64_t* progress;     /* [N] */
+    float* cur_time;       /* [N] _cur_ref_motion_times */
+    float* reset_time;     /* [N] _reset_ref_motion_times */
+    float* target[2];      /* 2 x [N,331]: current / previous target motion state, flipped every step */
+    float* context_feat;   /* [N,48,378] (nullable) */
+    uint8_t* context_mask; /* [N,48]     (nullable) */
+} v2p_env_buffers;
+
+/* Replaces create_sim/add_ground/create_env/create_actor/prepare_sim/acquire_*_tensor
+ * (humanoid_smpl.py:66-134, humanoid_smpl_im.py:231-389).  env_motion_id [N] is a DEVICE
+ * array (each env is bound to one clip, humanoid_smpl_im.py:247-254). */
+int v2p_env_create(const v2p_model* model, const v2p_mlib* mlib, const v2p_sim_cfg* cfg, const int64_t* env_motion_id,
+                   int64_t num_envs, const v2p_env_buffers* buffers, int device, v2p_env** out);
+void v2p_env_destroy(v2p_env* e);
+
+/* HumanoidSMPL.reset(env_ids) with reference-state init (humanoid_smpl.py:136-173,
+ * humanoid_smpl_im.py:442-563).  env_ids NULL = all envs.  motion_times [n] (device) are the
+ * RSI phases; the caller draws them (MotionLib.sample_time, motion_lib.py:138-159) so that
+ * the RNG stays on the Python side.  Fills state, target, obs, context. */
+int v2p_env_reset(v2p_env* e, const int64_t* env_ids, int64_t n, const float* motion_times, void* stream);
+
+/* BaseTask.step(actions) (base_task.py:147-165) = pre_physics_step + _physics_step +
+ * post_physics_step.  actions [N,75] is masked IN PLACE for envs whose reset flag is set
+ * (humanoid_smpl_im.py:126). */
+int v2p_env_step(v2p_env* e, float* actions, void* stream);
+/* The three stages separately (trace replay / profiling). */
+int v2p_env_pre_physics(v2p_env* e, float* actions, void* stream);   /* humanoid_smpl_im.py:125-157 */
+int v2p_env_physics(v2p_env* e, void* stream);                        /* base_task.py:450-454 + refresh_* */
+int v2p_env_post_physics(v2p_env* e, void* stream);                   /* humanoid_smpl_im.py:398-418 */
+
+/* set_actor_root_state_tensor_indexed + set_dof_state_tensor_indexed (+ rigid-body state for
+ * teacher-forced replay): pushes the caller-edited root_states/dof_state (and rb_state when
+ * `with_rb_state`) buffers into the engine's internal structure-of-arrays state. */
+int v2p_env_push_state(v2p_env* e, const int64_t* env_ids, int64_t n, int with_rb_state, void* stream);
+
+/* index (0/1) of the CURRENT target inside v2p_env_buffers.target; the other one is the previous target */
+int v2p_env_target_index(const v2p_env* e);
+
+/* diagnostics for tests: contact vertex ids chosen in the last substep, [N,24,4] int32, body*64+vertex or -1 */
+int v2p_env_debug_contacts(v2p_env* e, int32_t* out, void* stream);
+
+const char* v2p_last_error(void);
+int v2p_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* V2P_ROLLOUT_H */

@@ -1,0 +1,54 @@
+"""Helpers shared by the `-m gpu` parity tests."""
+import numpy as np
+import torch
+
+from vid2player3d_amd import synth
+from vid2player3d_amd.model import load_baked_model
+from vid2player3d_amd.motion_lib import MotionLib
+from vid2player3d_amd.tasks import HumanoidSMPLIM, default_cfg
+
+DEV = "cuda:0"
+
+
+def T(x, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(x)).to(device=DEV, dtype=dtype).contiguous()
+
+
+def N(x):
+    return x.detach().cpu().numpy()
+
+
+def golden_motion_lib(golden_tables):
+    return MotionLib(golden_tables, DEV)
+
+
+def synth_tables(seed=7, num_clips=16, min_frames=60, max_frames=200):
+    from vid2player3d_amd import motion_tables
+
+    m = load_baked_model()
+    clips = synth.make_clips(seed, num_clips, min_frames, max_frames)
+    return motion_tables.build_tables(clips, m.parents, m.local_pos)
+
+
+def make_task(num_envs, motion_lib, motion_ids=None, **env_overrides):
+    cfg = default_cfg(num_envs, motion_lib=motion_lib, **env_overrides)
+    if motion_ids is None:
+        cfg["env"]["sample_first_motions"] = True
+    task = HumanoidSMPLIM(cfg, device_type="cuda", device_id=0)
+    if motion_ids is not None:
+        # bind envs to given clips (the ids tensor is borrowed by the engine, so edit it in place)
+        task._reset_ref_motion_ids.copy_(T(motion_ids, torch.long))
+        task._reset_ref_motion_bodies = motion_lib._motion_bodies[task._reset_ref_motion_ids]
+    return task
+
+
+def close(a, b, tol, what=""):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    if a.size == 0:
+        return
+    err = np.abs(a - b).max()
+    lim = tol * max(1.0, np.abs(b).max())
+    assert np.isfinite(a).all(), what + ": non-finite values"
+    assert err <= lim, "%s: max abs err %.3e > %.1e" % (what, err, lim)

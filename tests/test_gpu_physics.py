@@ -1,0 +1,153 @@
+"""Parity of the HIP physics step (one env per lane, float32, O(n) recursions) with the C oracle
+(dense float64 restatement of the same model, oracle/phys) through the C ABI, plus size-independent
+properties at the BASELINE sizes.  PhysX itself is closed: parity with Isaac Gym is unpinned."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import task_oracle as O
+from oracle.phys_oracle import PhysOracle, default_params
+from tests.gpu_util import DEV, N, T, close, make_task, synth_tables
+
+pytestmark = pytest.mark.gpu
+
+# float32 recursion vs float64 dense solve after 4 substeps (velocities are O(1..10), positions O(1))
+TOL_POS, TOL_VEL, TOL_FORCE = 2e-5, 5e-4, 5e-3
+
+
+@pytest.fixture(scope="module")
+def mlib():
+    from vid2player3d_amd.motion_lib import MotionLib
+
+    return MotionLib(synth_tables(seed=5, num_clips=8, min_frames=60, max_frames=120), DEV)
+
+
+def _run_pair(mlib, n, contact, seed, lift=0.0, vel_sigma=0.5, steps=1):
+    rng = np.random.default_rng(seed)
+    task = make_task(n, mlib, enable_contact=contact)
+    times = T(rng.uniform(0.1, 1.0, size=n))
+    task.reset_with_times(None, times)
+    # perturb the reference state so that the drives, Coriolis terms and contacts all have work to do
+    root = N(task._humanoid_root_states).copy()
+    root[:, 2] += lift
+    root[:, 7:13] += rng.normal(0, vel_sigma, size=(n, 6)).astype(np.float32)
+    dpos = N(task._dof_pos).copy() + rng.normal(0, 0.05, size=(n, 69)).astype(np.float32)
+    dvel = N(task._dof_vel).copy() + rng.normal(0, vel_sigma, size=(n, 69)).astype(np.float32)
+    task._humanoid_root_states[:] = T(root)
+    task._dof_pos[:] = T(dpos)
+    task._dof_vel[:] = T(dvel)
+    task._reset_env_tensors(None)
+    bm = task.body_model
+    oracles = []
+    for e in range(n):
+        o = PhysOracle(bm, default_params(enable_contact=contact), kp=bm.kp.astype(np.float32), kd=bm.kd.astype(np.float32))
+        o.set_state(root[e], dpos[e], dvel[e])
+        oracles.append(o)
+    out = []
+    for s in range(steps):
+        act = np.concatenate([N(task._target_dof_pos) + rng.normal(0, 0.17, size=(n, 69)), rng.normal(0, 0.17, size=(n, 6))], axis=1).astype(np.float32)
+        rb0 = N(task._rigid_body_state).reshape(n, 24, 13).copy()
+        dpos_before = N(task._dof_pos).copy()
+        a = T(act)
+        task.pre_physics_step(a)
+        task._physics_step()
+        torch.cuda.synchronize()
+        pd_tar = N(task._pd_target)
+        # wrench from the numpy oracle of pre_physics on the same inputs
+        _, pd_ref, _, force, torque = O.pre_physics(act, N(task.reset_buf), dpos_before, rb0[:, 0, 3:7], bm.kp.astype(np.float32))
+        close(pd_tar, pd_ref, 1e-6, "pd target")
+        res = {"root": [], "dpos": [], "dvel": [], "rb": [], "cf": [], "df": [], "ids": []}
+        for e in range(n):
+            cf, df, ids = oracles[e].step(pd_target=pd_tar[e], ext_force=force[e], ext_torque=torque[e], nsub=4, hold=2)
+            r, p, v, rb = oracles[e].get_state()
+            for k, x in zip(("root", "dpos", "dvel", "rb", "cf", "df", "ids"), (r, p, v, rb, cf, df, ids)):
+                res[k].append(x)
+        res = {k: np.stack(v) for k, v in res.items()}
+        got = {"root": N(task._humanoid_root_states), "dpos": N(task._dof_pos), "dvel": N(task._dof_vel),
+               "rb": N(task._rigid_body_state).reshape(n, 24, 13), "cf": N(task._contact_forces), "df": N(task.dof_force_tensor),
+               "ids": N(task.debug_contacts())}
+        out.append((got, res))
+        task.post_physics_step()
+    task.close()
+    return out
+
+
+def _compare(got, ref, what):
+    close(got["root"][:, :7], ref["root"][:, :7], TOL_POS, what + " root pose")
+    close(got["root"][:, 7:], ref["root"][:, 7:], TOL_VEL, what + " root vel")
+    close(got["dpos"], ref["dpos"], 5e-5, what + " dof_pos")
+    close(got["dvel"], ref["dvel"], TOL_VEL, what + " dof_vel")
+    close(got["rb"][..., :3], ref["rb"][..., :3], TOL_POS, what + " rb pos")
+    # quaternion sign is arbitrary
+    qs = np.sign(np.sum(got["rb"][..., 3:7] * ref["rb"][..., 3:7], axis=-1, keepdims=True))
+    close(got["rb"][..., 3:7] * qs, ref["rb"][..., 3:7], TOL_POS, what + " rb rot")
+    close(got["rb"][..., 7:], ref["rb"][..., 7:], TOL_VEL, what + " rb vel")
+    close(got["df"], ref["df"], TOL_FORCE, what + " dof force")
+
+
+def test_pd_only_step_matches_oracle(mlib):
+    """BASELINE config 2: flat ground absent, PD control + gravity + residual wrench only."""
+    (got, ref), = _run_pair(mlib, 32, contact=False, seed=1, lift=0.5)
+    _compare(got, ref, "no-contact")
+    assert np.abs(got["cf"]).max() == 0.0
+
+
+def test_contact_step_matches_oracle(mlib):
+    """BASELINE config 3: hull-vs-plane contacts with the PGS solve."""
+    (got, ref), = _run_pair(mlib, 32, contact=True, seed=2, lift=0.0)
+    same = np.all(got["ids"] == ref["ids"], axis=(1, 2))
+    assert same.mean() > 0.9, "contact sets differ in %d of %d envs" % ((~same).sum(), len(same))
+    assert (ref["ids"] >= 0).any(axis=(1, 2)).mean() > 0.8, "fixture must put most humanoids in contact"
+    sel = {k: v[same] for k, v in got.items()}, {k: v[same] for k, v in ref.items()}
+    _compare(sel[0], sel[1], "contact")
+    close(sel[0]["cf"], sel[1]["cf"], TOL_FORCE, "contact force")
+
+
+def test_fallen_humanoid_many_contacts_matches_oracle(mlib):
+    """Low root height: most bodies touch the plane (worst case for the block Gauss-Seidel sweep)."""
+    (got, ref), = _run_pair(mlib, 16, contact=True, seed=3, lift=-0.75, vel_sigma=0.2)
+    assert ((ref["ids"] >= 0).any(axis=2).sum(axis=1) >= 6).mean() > 0.5
+    same = np.all(got["ids"] == ref["ids"], axis=(1, 2))
+    assert same.mean() > 0.8
+    sel = {k: v[same] for k, v in got.items()}, {k: v[same] for k, v in ref.items()}
+    _compare(sel[0], sel[1], "fallen")
+    close(sel[0]["cf"], sel[1]["cf"], 2e-2, "contact force")
+
+
+def test_multi_step_drift_is_bounded(mlib):
+    """8 control steps (32 substeps): float32 vs float64 trajectories stay close while contact sets agree."""
+    pairs = _run_pair(mlib, 16, contact=True, seed=4, steps=8)
+    got, ref = pairs[-1]
+    same = np.all([np.all(g["ids"] == r["ids"], axis=(1, 2)) for g, r in pairs], axis=0)
+    assert same.mean() > 0.5
+    close(got["rb"][same][..., :3], ref["rb"][same][..., :3], 2e-3, "rb pos after 8 steps")
+
+
+@pytest.mark.parametrize("n", [1024, 8192])
+def test_full_size_properties(mlib, n):
+    """Size-independent invariants at the BASELINE env counts: finite state, unit quaternions, nothing
+    tunnels the plane, contact forces push up, FK consistency of the exposed tensors, determinism."""
+    def run():
+        task = make_task(n, mlib)
+        g = torch.Generator(device=DEV)
+        g.manual_seed(3)
+        task.reset_with_times(None, torch.rand(n, device=DEV, generator=g) * 0.8)
+        for _ in range(6):
+            a = torch.cat([task._target_dof_pos + 0.17 * torch.randn((n, 69), device=DEV, generator=g), 0.17 * torch.randn((n, 6), device=DEV, generator=g)], dim=1).contiguous()
+            task.step(a)
+        torch.cuda.synchronize()
+        out = {k: getattr(task, k).clone() for k in ("obs_buf", "rew_buf", "reset_buf", "_rigid_body_state", "_contact_forces", "_dof_state")}
+        task.close()
+        return out
+    a, b = run(), run()
+    for k in a:
+        assert torch.equal(a[k], b[k]), "%s is not deterministic" % k
+    rb = a["_rigid_body_state"].view(n, 24, 13)
+    assert torch.isfinite(rb).all() and torch.isfinite(a["obs_buf"]).all() and torch.isfinite(a["rew_buf"]).all()
+    assert (rb[..., 3:7].norm(dim=-1) - 1).abs().max() < 1e-4
+    assert rb[..., 2].min() > -0.25
+    assert a["_contact_forces"][..., 2].min() >= 0.0
+    assert (a["rew_buf"] >= 0).all() and (a["rew_buf"] <= 1.0 + 1e-6).all()
+    # root state == rigid body 0 ; obs is the concat of the exposed tensors
+    assert torch.equal(a["obs_buf"][:, :72], rb[..., 0:3].reshape(n, 72))
+    assert torch.equal(a["obs_buf"][:, 168:237], a["_dof_state"].view(n, 69, 2)[..., 0])

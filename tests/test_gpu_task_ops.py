@@ -1,0 +1,161 @@
+"""Parity of the HIP sampler / reward / reset / obs kernels and of the task state machine, through the C ABI.
+
+Checked against (a) golden vectors recorded from the reference's own Python (tests/golden) and (b) the numpy
+oracle on larger seeded inputs.  Tolerances are float32 op-order noise: 5e-6 relative for gathers / blends,
+2e-4 for the rotation-angle reward term (acos near 1 is ill-conditioned in float32 in the reference itself)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import task_oracle as O
+from tests.gpu_util import DEV, N, T, close, golden_motion_lib, make_task, synth_tables
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mlib(golden_tables):
+    return golden_motion_lib(golden_tables)
+
+
+@pytest.mark.parametrize("adjust", [True, False])
+def test_motion_state_matches_reference_golden(mlib, golden_motion_state, adjust):
+    g = golden_motion_state
+    res = mlib.get_motion_state(T(g["ids"], torch.long), T(g["times"]), return_rigid_body=True, adjust_height=adjust, ground_tolerance=0.0)
+    sfx = "" if adjust else "_noadj"
+    for name, r in zip(O.MOTION_STATE_NAMES, res):
+        close(N(r), g[name + sfx], 5e-6, name + sfx)
+
+
+def test_motion_state_large_vs_oracle():
+    from vid2player3d_amd.motion_lib import MotionLib
+
+    tabs = synth_tables(seed=11, num_clips=24)
+    lib = MotionLib(tabs, DEV)
+    rng = np.random.default_rng(0)
+    q = 20000
+    ids = rng.integers(0, 24, size=q)
+    times = (rng.uniform(-0.05, 1.1, size=q) * tabs["motion_lengths"][ids]).astype(np.float32)
+    res = lib.get_motion_state(T(ids, torch.long), T(times), return_rigid_body=True, adjust_height=True, ground_tolerance=0.01)
+    ref = O.get_motion_state(tabs, ids, times, True, 0.01)
+    for name, r, o in zip(O.MOTION_STATE_NAMES, res, ref):
+        close(N(r), o, 5e-6, name)
+    # without rigid bodies the first seven outputs are unchanged
+    res7 = lib.get_motion_state(T(ids, torch.long), T(times), return_rigid_body=False, adjust_height=True, ground_tolerance=0.01)
+    assert len(res7) == 7
+    for a, b in zip(res7, res):
+        assert torch.equal(a, b)
+
+
+def test_motion_state_empty_query(mlib):
+    res = mlib.get_motion_state(torch.zeros(0, dtype=torch.long, device=DEV), torch.zeros(0, device=DEV), return_rigid_body=True)
+    assert [tuple(r.shape) for r in res][:3] == [(0, 3), (0, 4), (0, 69)]
+
+
+def _reward(lib, g, n):
+    from vid2player3d_amd import _lib
+
+    rew = torch.empty(n, device=DEV)
+    sub = torch.empty((n, 4), device=DEV)
+    w = (C.c_float * 24)(*g["body_pos_weights"].tolist())
+    s = (C.c_float * 8)(60, 0.2, 100, 40, 0.6, 0.1, 0.2, 0.1)
+    args = [T(g[k][:n]) for k in ("body_pos", "body_rot", "tgt_pos", "tgt_rot", "dof_pos", "dof_vel", "tgt_dof_pos", "tgt_dof_vel")]
+    _lib.check(lib.v2p_reward(n, *[_lib.ptr(a) for a in args], w, s, _lib.ptr(rew), _lib.ptr(sub), None), "v2p_reward")
+    torch.cuda.synchronize()
+    return N(rew), N(sub)
+
+
+def test_reward_matches_reference_golden(golden_task_ops):
+    from vid2player3d_amd import _lib
+
+    g = golden_task_ops
+    rew, sub = _reward(_lib.load(), g, g["reward"].shape[0])
+    close(sub[:, :3], g["sub_rewards"][:, :3], 5e-6, "sub[dof,vel,pos]")
+    close(sub[:, 3], g["sub_rewards"][:, 3], 2e-4, "sub[rot]")
+    close(rew, g["reward"], 5e-5, "reward")
+
+
+def test_reset_flags_match_reference_golden(golden_task_ops):
+    from vid2player3d_amd import _lib
+
+    g = golden_task_ops
+    lib = _lib.load()
+    n = g["reset_out"].shape[0]
+    h = g["reset_heights"].astype(np.float32).copy()
+    h[[7, 3]] = -np.inf
+    rst = torch.empty(n, dtype=torch.long, device=DEV)
+    term = torch.empty(n, dtype=torch.long, device=DEV)
+    _lib.check(lib.v2p_reset_flags(n, _lib.ptr(T(g["reset_progress"], torch.long)), _lib.ptr(T(g["reset_rb_pos"])), (C.c_float * 24)(*h.tolist()),
+                                   _lib.ptr(T(g["reset_cur_time"])), _lib.ptr(T(g["reset_clip_len"])), 300.0, 1, _lib.ptr(rst), _lib.ptr(term), None),
+               "v2p_reset_flags")
+    assert np.array_equal(N(rst), g["reset_out"])
+    assert np.array_equal(N(term), g["terminate_out"])
+
+
+def test_obs_imitation_734_matches_reference_golden(golden_task_ops):
+    from vid2player3d_amd import _lib
+
+    g = golden_task_ops
+    lib = _lib.load()
+    n = g["obs734"].shape[0]
+    obs = torch.empty((n, 734), device=DEV)
+    args = [T(g[k]) for k in ("body_pos", "body_rot", "tgt_pos", "tgt_rot", "dof_pos", "dof_vel", "tgt_dof_pos", "body_vel", "body_ang_vel",
+                              "obs734_motion_bodies")]
+    _lib.check(lib.v2p_obs_imitation(n, *[_lib.ptr(a) for a in args], _lib.ptr(obs), None), "v2p_obs_imitation")
+    close(N(obs), g["obs734"], 5e-6, "obs734")
+
+
+def test_env_trace_replay_matches_reference(mlib, golden_env_trace):
+    """reset / pre_physics_step / post_physics_step against the trace recorded from the reference's own
+    HumanoidSMPLIM methods, with the recorded 'simulated' states teacher-forced in place of physics."""
+    g = golden_env_trace
+    task = make_task(6, mlib, motion_ids=g["motion_ids"], record_pd_torque=True)
+    for tag, nsteps in (("e0_", int(g["num_steps"])), ("e1_", int(g["num_steps_e1"]))):
+        task.reset_with_times(None, T(g[tag + "reset_motion_times"]))
+        close(N(task._humanoid_root_states), g[tag + "reset_root_states"], 5e-6, tag + "root_states")
+        close(N(task._dof_pos), g[tag + "reset_dof_pos"], 5e-6, tag + "dof_pos")
+        close(N(task._dof_vel), g[tag + "reset_dof_vel"], 5e-6, tag + "dof_vel")
+        close(N(task._rigid_body_state).reshape(6, 24, 13), g[tag + "reset_rb_state"], 5e-6, tag + "rb_state")
+        close(N(task.context_feat), g[tag + "context_feat"], 5e-6, tag + "context_feat")
+        assert np.array_equal(N(task.context_mask), g[tag + "context_mask"])
+        close(N(task.obs_buf), g[tag + "reset_obs"], 5e-6, tag + "reset_obs")
+        assert not N(task.reset_buf).any() and not N(task._terminate_buf).any() and not N(task.progress_buf).any()
+        for i in range(nsteps):
+            p = "%ss%02d_" % (tag, i)
+            a = T(g[p + "actions"])
+            task.pre_physics_step(a)
+            close(N(a), g[p + "actions_after"], 0.0, p + "actions masked in place")
+            close(N(task.pd_torque), g[p + "pd_torque"], 2e-6, p + "pd_torque")
+            # teacher-forced physics: the recorded state goes in through the state-tensor views
+            task._dof_pos[:] = T(g[p + "sim_dof_pos"])
+            task._dof_vel[:] = T(g[p + "sim_dof_vel"])
+            task._rigid_body_state.view(6, 24, 13)[:] = T(g[p + "sim_rb_state"])
+            task._humanoid_root_states[:] = T(g[p + "sim_rb_state"][:, 0, :])
+            task._reset_env_tensors(None, with_rb_state=True)
+            task.post_physics_step()
+            close(N(task.obs_buf), g[p + "obs"], 5e-6, p + "obs")
+            close(N(task.rew_buf), g[p + "rew"], 1e-4, p + "rew")
+            close(N(task.extras["sub_rewards"]), g[p + "sub_rewards"], 5e-4, p + "sub_rewards")
+            assert np.array_equal(N(task.reset_buf), g[p + "reset"]), p
+            assert np.array_equal(N(task.extras["terminate"]), g[p + "terminate"]), p
+            assert np.array_equal(N(task.progress_buf), g[p + "progress"]), p
+            close(N(task._cur_ref_motion_times), g[p + "cur_time"], 1e-6, p + "cur_time")
+            for name in O.MOTION_STATE_NAMES:
+                close(N(getattr(task, "_target_" + name)), g[p + "target_" + name], 5e-6, p + "target_" + name)
+    task.close()
+
+
+def test_partial_reset_only_touches_selected_envs(mlib):
+    task = make_task(8, mlib)
+    task.reset_with_times(None, torch.full((8,), 0.2, device=DEV))
+    before = task.obs_buf.clone()
+    ids = torch.tensor([1, 6], device=DEV)
+    task.reset_with_times(ids, torch.tensor([0.5, 0.7], device=DEV))
+    after = task.obs_buf
+    keep = [0, 2, 3, 4, 5, 7]
+    assert torch.equal(after[keep], before[keep])
+    assert not torch.equal(after[1], before[1]) and not torch.equal(after[6], before[6])
+    assert torch.allclose(task._cur_ref_motion_times[ids], torch.tensor([0.5, 0.7], device=DEV))
+    task.close()

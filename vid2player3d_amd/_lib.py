@@ -1,0 +1,116 @@
+"""ctypes binding of libv2p_rollout.so (the C ABI in include/v2p_rollout.h).
+
+There is NO fallback: if the HIP library is missing or a call fails, a RuntimeError is raised
+(the reference's error convention is Python exceptions).
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libv2p_rollout.so")
+
+NUM_BODIES, NUM_DOF, NUM_ACTIONS, NUM_OBS = 24, 69, 75, 461
+MOTION_STATE_DIM, CONTEXT_DIM = 331, 378
+ABI_VERSION = 1
+
+c_f = C.POINTER(C.c_float)
+c_i32 = C.POINTER(C.c_int32)
+c_i64 = C.POINTER(C.c_int64)
+c_u8 = C.POINTER(C.c_uint8)
+vp = C.c_void_p
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("num_bodies", C.c_int32), ("parents", c_i32), ("local_pos", c_f), ("mass", c_f), ("com", c_f), ("inertia", c_f),
+                ("kp", c_f), ("kd", c_f), ("armature", c_f), ("hull_offsets", c_i32), ("hull_verts", c_f)]
+
+
+class MotionTables(C.Structure):
+    _fields_ = [("num_motions", C.c_int64), ("num_frames_total", C.c_int64), ("gts", vp), ("grs", vp), ("lrs", vp), ("grvs", vp),
+                ("gravs", vp), ("dvs", vp), ("motion_lengths", vp), ("motion_num_frames", vp), ("motion_dt", vp),
+                ("motion_min_verts_h", vp), ("length_starts", vp), ("motion_bodies", vp), ("key_body_ids", C.c_int32 * 4)]
+
+
+class SimCfg(C.Structure):
+    _fields_ = [("sim_dt", C.c_float), ("substeps", C.c_int32), ("control_freq_inv", C.c_int32), ("num_solver_iterations", C.c_int32),
+                ("enable_contact", C.c_int32), ("residual_hold_sims", C.c_int32), ("gravity_z", C.c_float), ("friction", C.c_float),
+                ("contact_offset", C.c_float), ("max_depenetration_velocity", C.c_float), ("erp", C.c_float),
+                ("angular_damping", C.c_float), ("max_angular_velocity", C.c_float), ("pd_tar_lim", C.c_float),
+                ("residual_force_scale", C.c_float), ("residual_torque_scale", C.c_float), ("ground_tolerance", C.c_float),
+                ("max_episode_length", C.c_float), ("enable_early_termination", C.c_int32), ("context_length", C.c_int32),
+                ("context_padding", C.c_int32), ("term_heights", C.c_float * 24), ("body_pos_weights", C.c_float * 24),
+                ("reward_specs", C.c_float * 8)]
+
+
+class EnvBuffers(C.Structure):
+    _fields_ = [("root_states", vp), ("dof_state", vp), ("rb_state", vp), ("contact_force", vp), ("dof_force", vp), ("pd_target", vp),
+                ("obs", vp), ("rew", vp), ("sub_rewards", vp), ("reset", vp), ("terminate", vp), ("progress", vp), ("cur_time", vp),
+                ("reset_time", vp), ("target", vp * 2), ("context_feat", vp), ("context_mask", vp)]
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libv2p_rollout.so is missing (%s): build it with `python -m vid2player3d_amd.build`; "
+                           "there is no CPU fallback for the rollout engine" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.v2p_last_error.restype = C.c_char_p
+    lib.v2p_abi_version.restype = C.c_int
+    if lib.v2p_abi_version() != ABI_VERSION:
+        raise RuntimeError("libv2p_rollout.so ABI %d != binding ABI %d: rebuild" % (lib.v2p_abi_version(), ABI_VERSION))
+    sig = {
+        "v2p_model_create": [C.POINTER(ModelDesc), C.c_int, C.POINTER(vp)],
+        "v2p_mlib_create": [C.POINTER(MotionTables), C.c_int, C.POINTER(vp)],
+        "v2p_motion_state": [vp, vp, vp, C.c_int64, C.c_int, C.c_float, C.POINTER(vp * 9), vp],
+        "v2p_reward": [C.c_int64] + [vp] * 8 + [c_f, c_f, vp, vp, vp],
+        "v2p_reset_flags": [C.c_int64, vp, vp, c_f, vp, vp, C.c_float, C.c_int, vp, vp, vp],
+        "v2p_obs_imitation": [C.c_int64] + [vp] * 11 + [vp],
+        "v2p_env_create": [vp, vp, C.POINTER(SimCfg), vp, C.c_int64, C.POINTER(EnvBuffers), C.c_int, C.POINTER(vp)],
+        "v2p_env_reset": [vp, vp, C.c_int64, vp, vp],
+        "v2p_env_step": [vp, vp, vp],
+        "v2p_env_pre_physics": [vp, vp, vp],
+        "v2p_env_physics": [vp, vp],
+        "v2p_env_post_physics": [vp, vp],
+        "v2p_env_push_state": [vp, vp, C.c_int64, C.c_int, vp],
+        "v2p_env_target_index": [vp],
+        "v2p_env_debug_contacts": [vp, vp, vp],
+    }
+    for name, args in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    for name in ("v2p_model_destroy", "v2p_mlib_destroy", "v2p_env_destroy"):
+        fn = getattr(lib, name)
+        fn.argtypes = [vp]
+        fn.restype = None
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = (
+    "v2p_model_create", "v2p_model_destroy", "v2p_mlib_create", "v2p_mlib_destroy", "v2p_motion_state", "v2p_reward", "v2p_reset_flags",
+    "v2p_obs_imitation", "v2p_env_create", "v2p_env_destroy", "v2p_env_reset", "v2p_env_step", "v2p_env_pre_physics", "v2p_env_physics",
+    "v2p_env_post_physics", "v2p_env_push_state", "v2p_env_target_index", "v2p_env_debug_contacts", "v2p_last_error", "v2p_abi_version",
+)
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, load().v2p_last_error().decode()))
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor / None."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def current_stream(device):
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

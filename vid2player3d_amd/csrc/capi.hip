@@ -1,0 +1,276 @@
+// C-ABI entry points of libv2p_rollout.so (declared in include/v2p_rollout.h).
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+
+#include "v2p_internal.hpp"
+
+namespace v2p {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_hip(hipError_t e, const char* what) {
+    if (e == hipSuccess) return V2P_OK;
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return V2P_ERR_HIP;
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+}  // namespace v2p
+
+using namespace v2p;
+
+extern "C" {
+
+const char* v2p_last_error(void) { return g_err; }
+int v2p_abi_version(void) { return V2P_ABI_VERSION; }
+
+int v2p_model_create(const v2p_model_desc* d, int device, v2p_model** out) {
+    if (!d || !out) { set_error("v2p_model_create: null argument"); return V2P_ERR_INVALID; }
+    if (d->num_bodies != NB) { set_error("v2p_model_create: num_bodies must be %d, got %d", NB, d->num_bodies); return V2P_ERR_UNSUPPORTED; }
+    if (d->hull_offsets[NB] > MAX_HULL_VERTS) { set_error("v2p_model_create: %d hull vertices exceed the limit %d", d->hull_offsets[NB], MAX_HULL_VERTS); return V2P_ERR_UNSUPPORTED; }
+    v2p_model* m = new (std::nothrow) v2p_model();
+    if (!m) { set_error("v2p_model_create: out of host memory"); return V2P_ERR_NOMEM; }
+    memset(&m->host, 0, sizeof(m->host));
+    DevModel& h = m->host;
+    for (int b = 0; b < NB; ++b) {
+        int p = d->parents[b];
+        if ((b == 0 && p != -1) || (b > 0 && (p < 0 || p >= b))) {
+            set_error("v2p_model_create: parents must be topologically ordered with a single root (body %d has parent %d)", b, p);
+            delete m;
+            return V2P_ERR_INVALID;
+        }
+        h.parents[b] = p;
+        h.depth[b] = b == 0 ? 0 : h.depth[p] + 1;
+        if (h.depth[b] >= MAX_DEPTH) { set_error("v2p_model_create: tree depth exceeds %d", MAX_DEPTH); delete m; return V2P_ERR_UNSUPPORTED; }
+        for (int k = 0; k < 3; ++k) { h.local_pos[b][k] = d->local_pos[3 * b + k]; h.com[b][k] = d->com[3 * b + k]; }
+        h.mass[b] = d->mass[b];
+        const float* I = d->inertia + 9 * b;
+        h.inertia[b][0] = I[0]; h.inertia[b][1] = 0.5f * (I[1] + I[3]); h.inertia[b][2] = 0.5f * (I[2] + I[6]);
+        h.inertia[b][3] = I[4]; h.inertia[b][4] = 0.5f * (I[5] + I[7]); h.inertia[b][5] = I[8];
+        if (b > 0) {
+            const float *kp = d->kp + 3 * (b - 1), *kd = d->kd + 3 * (b - 1), *ar = d->armature + 3 * (b - 1);
+            if (kp[0] != kp[1] || kp[0] != kp[2] || kd[0] != kd[1] || kd[0] != kd[2] || ar[0] != ar[1] || ar[0] != ar[2]) {
+                set_error("v2p_model_create: joint of body %d has per-axis gains; only isotropic spherical-joint gains are built", b);
+                delete m;
+                return V2P_ERR_UNSUPPORTED;
+            }
+            h.kp[b] = kp[0]; h.kd[b] = kd[0]; h.arm[b] = ar[0];
+        }
+        h.hull_offsets[b] = d->hull_offsets[b];
+    }
+    h.hull_offsets[NB] = d->hull_offsets[NB];
+    for (int b = 0; b < NB; ++b) {
+        float r2 = 0.f;
+        for (int v = h.hull_offsets[b]; v < h.hull_offsets[b + 1]; ++v) {
+            for (int k = 0; k < 3; ++k) h.hull_verts[v][k] = d->hull_verts[3 * v + k];
+            float n2 = h.hull_verts[v][0] * h.hull_verts[v][0] + h.hull_verts[v][1] * h.hull_verts[v][1] + h.hull_verts[v][2] * h.hull_verts[v][2];
+            if (n2 > r2) r2 = n2;
+        }
+        h.bound_radius[b] = sqrtf(r2);
+    }
+    m->device = device;
+    m->dev = nullptr;
+    DeviceGuard g(device);
+    if (!g.ok) { set_error("v2p_model_create: cannot select device %d", device); delete m; return V2P_ERR_HIP; }
+    int rc = check_hip(hipMalloc((void**)&m->dev, sizeof(DevModel)), "hipMalloc(model)");
+    if (rc == V2P_OK) rc = check_hip(hipMemcpy(m->dev, &m->host, sizeof(DevModel), hipMemcpyHostToDevice), "hipMemcpy(model)");
+    if (rc != V2P_OK) { if (m->dev) (void)hipFree(m->dev); delete m; return rc; }
+    *out = m;
+    return V2P_OK;
+}
+
+void v2p_model_destroy(v2p_model* m) {
+    if (!m) return;
+    DeviceGuard g(m->device);
+    if (m->dev) (void)hipFree(m->dev);
+    delete m;
+}
+
+int v2p_mlib_create(const v2p_motion_tables* t, int device, v2p_mlib** out) {
+    if (!t || !out) { set_error("v2p_mlib_create: null argument"); return V2P_ERR_INVALID; }
+    if (t->num_motions <= 0 || t->num_frames_total <= 0) { set_error("v2p_mlib_create: empty motion library"); return V2P_ERR_INVALID; }
+    const void* ptrs[] = {t->gts, t->grs, t->lrs, t->grvs, t->gravs, t->dvs, t->motion_lengths, t->motion_num_frames, t->motion_dt,
+                          t->motion_min_verts_h, t->length_starts, t->motion_bodies};
+    for (const void* p : ptrs)
+        if (!p) { set_error("v2p_mlib_create: null table pointer"); return V2P_ERR_INVALID; }
+    if (((uintptr_t)t->grs | (uintptr_t)t->lrs) & 15) { set_error("v2p_mlib_create: grs/lrs must be 16-byte aligned"); return V2P_ERR_INVALID; }
+    for (int k = 0; k < 4; ++k)
+        if (t->key_body_ids[k] < 0 || t->key_body_ids[k] >= NB) { set_error("v2p_mlib_create: key body id out of range"); return V2P_ERR_INVALID; }
+    v2p_mlib* m = new (std::nothrow) v2p_mlib();
+    if (!m) { set_error("v2p_mlib_create: out of host memory"); return V2P_ERR_NOMEM; }
+    m->t = *t;
+    m->device = device;
+    *out = m;
+    return V2P_OK;
+}
+
+void v2p_mlib_destroy(v2p_mlib* m) { delete m; }
+
+int v2p_motion_state(const v2p_mlib* m, const int64_t* ids, const float* times, int64_t q, int adjust_height, float ground_tol,
+                     float* const out[9], void* stream) {
+    if (!m || !out || q < 0 || (q > 0 && (!ids || !times))) { set_error("v2p_motion_state: bad argument"); return V2P_ERR_INVALID; }
+    DeviceGuard g(m->device);
+    return launch_motion_state(m->t, ids, times, q, adjust_height, ground_tol, out, (hipStream_t)stream);
+}
+
+int v2p_reward(int64_t n, const float* body_pos, const float* body_rot, const float* tgt_pos, const float* tgt_rot, const float* dof_pos,
+               const float* dof_vel, const float* tgt_dof_pos, const float* tgt_dof_vel, const float* w, const float specs[8], float* reward,
+               float* sub, void* stream) {
+    if (n < 0 || !w || !specs) { set_error("v2p_reward: bad argument"); return V2P_ERR_INVALID; }
+    return launch_reward(n, body_pos, body_rot, tgt_pos, tgt_rot, dof_pos, dof_vel, tgt_dof_pos, tgt_dof_vel, w, specs, reward, sub,
+                         (hipStream_t)stream);
+}
+
+int v2p_reset_flags(int64_t n, const int64_t* progress, const float* rb_pos, const float* heights, const float* cur_time,
+                    const float* clip_len, float max_len, int early, int64_t* reset_out, int64_t* term_out, void* stream) {
+    if (n < 0 || !heights) { set_error("v2p_reset_flags: bad argument"); return V2P_ERR_INVALID; }
+    return launch_reset_flags(n, progress, rb_pos, heights, cur_time, clip_len, max_len, early, reset_out, term_out, (hipStream_t)stream);
+}
+
+int v2p_obs_imitation(int64_t n, const float* body_pos, const float* body_rot, const float* tgt_pos, const float* tgt_rot,
+                      const float* dof_pos, const float* dof_vel, const float* tgt_dof_pos, const float* body_vel,
+                      const float* body_ang_vel, const float* motion_bodies, float* obs, void* stream) {
+    if (n < 0) { set_error("v2p_obs_imitation: bad argument"); return V2P_ERR_INVALID; }
+    return launch_obs_imitation(n, body_pos, body_rot, tgt_pos, tgt_rot, dof_pos, dof_vel, tgt_dof_pos, body_vel, body_ang_vel,
+                                motion_bodies, obs, (hipStream_t)stream);
+}
+
+int v2p_env_create(const v2p_model* model, const v2p_mlib* mlib, const v2p_sim_cfg* c, const int64_t* env_motion_id, int64_t n,
+                   const v2p_env_buffers* b, int device, v2p_env** out) {
+    if (!model || !mlib || !c || !env_motion_id || !b || !out || n <= 0) { set_error("v2p_env_create: bad argument"); return V2P_ERR_INVALID; }
+    if (model->device != device || mlib->device != device) { set_error("v2p_env_create: model/motion-lib live on another device"); return V2P_ERR_INVALID; }
+    const void* req[] = {b->root_states, b->dof_state, b->rb_state, b->contact_force, b->dof_force, b->pd_target, b->obs, b->rew,
+                         b->sub_rewards, b->reset, b->terminate, b->progress, b->cur_time, b->reset_time, b->target[0], b->target[1]};
+    for (const void* p : req)
+        if (!p) { set_error("v2p_env_create: a required buffer is null"); return V2P_ERR_INVALID; }
+    if (c->substeps < 1 || c->control_freq_inv < 1 || c->sim_dt <= 0.f || c->num_solver_iterations < 0 ||
+        c->residual_hold_sims < 0 || c->residual_hold_sims > c->control_freq_inv) {
+        set_error("v2p_env_create: bad sim parameters");
+        return V2P_ERR_INVALID;
+    }
+    v2p_env* e = new (std::nothrow) v2p_env();
+    if (!e) { set_error("v2p_env_create: out of host memory"); return V2P_ERR_NOMEM; }
+    memset(e, 0, sizeof(*e));
+    e->model = model;
+    e->mlib = mlib;
+    e->buf = *b;
+    e->n = n;
+    e->device = device;
+    e->motion_id = env_motion_id;
+    EnvParams& p = e->p;
+    p.h = c->sim_dt / (float)c->substeps;
+    p.nsub = c->substeps * c->control_freq_inv;
+    p.hold_sub = c->residual_hold_sims * c->substeps;
+    p.n_iter = c->num_solver_iterations;
+    p.enable_contact = c->enable_contact;
+    p.gravity_z = c->gravity_z; p.mu = c->friction; p.contact_offset = c->contact_offset; p.max_depen = c->max_depenetration_velocity;
+    p.erp = c->erp; p.ang_damp = c->angular_damping; p.max_ang_vel = c->max_angular_velocity;
+    p.pd_tar_lim = c->pd_tar_lim; p.res_force_scale = c->residual_force_scale; p.res_torque_scale = c->residual_torque_scale;
+    p.ground_tolerance = c->ground_tolerance; p.max_episode_length = c->max_episode_length;
+    p.enable_early_termination = c->enable_early_termination;
+    p.context_length = c->context_length; p.context_padding = c->context_padding;
+    p.dt = (float)c->control_freq_inv * c->sim_dt;
+    memcpy(p.term_heights, c->term_heights, sizeof(p.term_heights));
+    memcpy(p.body_pos_weights, c->body_pos_weights, sizeof(p.body_pos_weights));
+    memcpy(p.reward_specs, c->reward_specs, sizeof(p.reward_specs));
+    DeviceGuard g(device);
+    if (!g.ok) { set_error("v2p_env_create: cannot select device %d", device); delete e; return V2P_ERR_HIP; }
+    size_t N = (size_t)n;
+    int rc = check_hip(hipMalloc((void**)&e->state, sizeof(float) * STATE_SLOTS * N), "hipMalloc(state)");
+    if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->ctrl, sizeof(float) * CTRL_SLOTS * N), "hipMalloc(ctrl)");
+    if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->out, sizeof(float) * OUT_SLOTS * N), "hipMalloc(out)");
+    if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->ws, sizeof(float) * (size_t)physics_ws_slots() * N), "hipMalloc(ws)");
+    if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->contact_ids, sizeof(int32_t) * NB * 4 * N), "hipMalloc(contact_ids)");
+    if (rc == V2P_OK) rc = check_hip(hipMemset(e->state, 0, sizeof(float) * STATE_SLOTS * N), "hipMemset(state)");
+    if (rc == V2P_OK) rc = check_hip(hipMemset(e->ctrl, 0, sizeof(float) * CTRL_SLOTS * N), "hipMemset(ctrl)");
+    if (rc == V2P_OK) rc = check_hip(hipMemset(e->out, 0, sizeof(float) * OUT_SLOTS * N), "hipMemset(out)");
+    if (rc == V2P_OK) rc = check_hip(hipMemset(e->ws, 0, sizeof(float) * (size_t)physics_ws_slots() * N), "hipMemset(ws)");
+    if (rc == V2P_OK) rc = check_hip(hipMemset(e->contact_ids, 0xff, sizeof(int32_t) * NB * 4 * N), "hipMemset(contact_ids)");
+    if (rc != V2P_OK) { v2p_env_destroy(e); return rc; }
+    *out = e;
+    return V2P_OK;
+}
+
+void v2p_env_destroy(v2p_env* e) {
+    if (!e) return;
+    DeviceGuard g(e->device);
+    if (e->state) (void)hipFree(e->state);
+    if (e->ctrl) (void)hipFree(e->ctrl);
+    if (e->out) (void)hipFree(e->out);
+    if (e->ws) (void)hipFree(e->ws);
+    if (e->contact_ids) (void)hipFree(e->contact_ids);
+    delete e;
+}
+
+int v2p_env_reset(v2p_env* e, const int64_t* env_ids, int64_t n, const float* motion_times, void* stream) {
+    if (!e || !motion_times || n < 0 || n > e->n) { set_error("v2p_env_reset: bad argument"); return V2P_ERR_INVALID; }
+    DeviceGuard g(e->device);
+    return launch_env_reset(e, env_ids, env_ids ? n : e->n, motion_times, (hipStream_t)stream);
+}
+
+int v2p_env_pre_physics(v2p_env* e, float* actions, void* stream) {
+    if (!e || !actions) { set_error("v2p_env_pre_physics: bad argument"); return V2P_ERR_INVALID; }
+    DeviceGuard g(e->device);
+    return launch_env_pre(e, actions, (hipStream_t)stream);
+}
+
+int v2p_env_physics(v2p_env* e, void* stream) {
+    if (!e) { set_error("v2p_env_physics: bad argument"); return V2P_ERR_INVALID; }
+    DeviceGuard g(e->device);
+    int rc = launch_env_physics(e, (hipStream_t)stream);
+    if (rc == V2P_OK) rc = launch_env_export(e, (hipStream_t)stream);
+    return rc;
+}
+
+int v2p_env_post_physics(v2p_env* e, void* stream) {
+    if (!e) { set_error("v2p_env_post_physics: bad argument"); return V2P_ERR_INVALID; }
+    DeviceGuard g(e->device);
+    return launch_env_post(e, (hipStream_t)stream);
+}
+
+int v2p_env_step(v2p_env* e, float* actions, void* stream) {
+    int rc = v2p_env_pre_physics(e, actions, stream);
+    if (rc == V2P_OK) rc = v2p_env_physics(e, stream);
+    if (rc == V2P_OK) rc = v2p_env_post_physics(e, stream);
+    return rc;
+}
+
+int v2p_env_push_state(v2p_env* e, const int64_t* env_ids, int64_t n, int with_rb_state, void* stream) {
+    if (!e || n < 0 || n > e->n) { set_error("v2p_env_push_state: bad argument"); return V2P_ERR_INVALID; }
+    DeviceGuard g(e->device);
+    return launch_env_push_state(e, env_ids, env_ids ? n : e->n, with_rb_state, (hipStream_t)stream);
+}
+
+int v2p_env_target_index(const v2p_env* e) { return e ? e->cur_target : V2P_ERR_INVALID; }
+
+int v2p_env_debug_contacts(v2p_env* e, int32_t* out, void* stream) {
+    if (!e || !out) { set_error("v2p_env_debug_contacts: bad argument"); return V2P_ERR_INVALID; }
+    DeviceGuard g(e->device);
+    return check_hip(hipMemcpyAsync(out, e->contact_ids, sizeof(int32_t) * NB * 4 * (size_t)e->n, hipMemcpyDeviceToDevice, (hipStream_t)stream),
+                     "hipMemcpyAsync(contact_ids)");
+}
+
+}  // extern "C"

@@ -1,0 +1,509 @@
+// Task-side kernels of the imitation env: everything HumanoidSMPLIM does around the physics
+// step (embodied_pose/env/tasks/humanoid_smpl_im.py).  All of them are HBM/L2-bound
+// elementwise + gather work; the mapping is one thread per (env, body) so that the
+// reference's row-major [N,24,*] tensors are read/written by adjacent lanes, with an LDS
+// reduction over the 24 bodies of an env where the reference takes means.
+#include <math.h>
+
+#include "motion_sample.hpp"
+
+namespace v2p {
+
+constexpr int EB_BLOCK = 192;          // 8 envs x 24 bodies = 3 wave64
+constexpr int ENVS_PER_BLOCK = EB_BLOCK / NB;
+
+// ------------------------------------------------------------------------------------------
+// reward  (compute_humanoid_reward, humanoid_smpl_im.py:918-953; dof_to_obs, humanoid_smpl.py:604-635)
+// ------------------------------------------------------------------------------------------
+struct RewardPartial {
+    float dof, vel, pos, rot;
+};
+
+// contribution of body j: its joint (j>=1) to the dof / vel terms, itself to the pos / rot terms
+__device__ __forceinline__ RewardPartial reward_partial(int j, V3 body_pos, Q4 body_rot, V3 tgt_pos, Q4 tgt_rot, V3 dof_pos, V3 dof_vel,
+                                                        V3 tgt_dof_pos, V3 tgt_dof_vel, float w) {
+    RewardPartial r{0.f, 0.f, 0.f, 0.f};
+    if (j > 0) {
+        V3 t0, n0, t1, n1;
+        ref_quat_to_tan_norm(ref_exp_map_to_quat(dof_pos), t0, n0);
+        ref_quat_to_tan_norm(ref_exp_map_to_quat(tgt_dof_pos), t1, n1);
+        V3 dt = t0 - t1, dn = n0 - n1;
+        r.dof = dot(dt, dt) + dot(dn, dn);
+        V3 dv = tgt_dof_vel - dof_vel;
+        r.vel = dot(dv, dv);
+    }
+    V3 dp = (tgt_pos - body_pos) * w;
+    r.pos = dot(dp, dp) * (1.f / 3.f);
+    V3 ax;
+    float ang = ref_quat_to_angle_axis(qmul(tgt_rot, qconj(body_rot)), ax);
+    r.rot = ang * ang;
+    return r;
+}
+
+__device__ __forceinline__ void reward_finish(const float* specs, float sdof, float svel, float spos, float srot, float& rew, float sub[4]) {
+    sub[0] = expf(-specs[0] * (sdof * (1.f / 138.f)));
+    sub[1] = expf(-specs[1] * (svel * (1.f / 69.f)));
+    sub[2] = expf(-specs[2] * (spos * (1.f / 24.f)));
+    sub[3] = expf(-specs[3] * (srot * (1.f / 24.f)));
+    rew = specs[4] * sub[0] + specs[5] * sub[1] + specs[6] * sub[2] + specs[7] * sub[3];
+}
+
+__device__ __forceinline__ V3 ld3(const float* p) { return V3{p[0], p[1], p[2]}; }
+__device__ __forceinline__ Q4 ld4(const float* p) { return Q4{p[0], p[1], p[2], p[3]}; }
+
+struct RewardSpecs {
+    float v[8];
+};
+struct Heights {
+    float v[NB];
+};
+
+__global__ __launch_bounds__(EB_BLOCK) void reward_kernel(int64_t n, const float* __restrict__ body_pos, const float* __restrict__ body_rot,
+                                                          const float* __restrict__ tgt_pos, const float* __restrict__ tgt_rot,
+                                                          const float* __restrict__ dof_pos, const float* __restrict__ dof_vel,
+                                                          const float* __restrict__ tgt_dof_pos, const float* __restrict__ tgt_dof_vel,
+                                                          Heights w, RewardSpecs specs, float* __restrict__ rew, float* __restrict__ sub) {
+    __shared__ float red[ENVS_PER_BLOCK][NB][4];
+    int le = threadIdx.x / NB, j = threadIdx.x % NB;
+    int64_t e = (int64_t)blockIdx.x * ENVS_PER_BLOCK + le;
+    RewardPartial r{0.f, 0.f, 0.f, 0.f};
+    if (e < n) {
+        int64_t bj = e * NB + j;
+        V3 z{0.f, 0.f, 0.f};
+        int64_t dj = e * NDOF + 3 * (j - 1);
+        r = reward_partial(j, ld3(body_pos + bj * 3), ld4(body_rot + bj * 4), ld3(tgt_pos + bj * 3), ld4(tgt_rot + bj * 4),
+                           j ? ld3(dof_pos + dj) : z, j ? ld3(dof_vel + dj) : z, j ? ld3(tgt_dof_pos + dj) : z, j ? ld3(tgt_dof_vel + dj) : z,
+                           w.v[j]);
+    }
+    red[le][j][0] = r.dof; red[le][j][1] = r.vel; red[le][j][2] = r.pos; red[le][j][3] = r.rot;
+    __syncthreads();
+    if (j == 0 && e < n) {
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < NB; ++b)
+            for (int k = 0; k < 4; ++k) s[k] += red[le][b][k];
+        float rw, sb[4];
+        reward_finish(specs.v, s[0], s[1], s[2], s[3], rw, sb);
+        rew[e] = rw;
+        for (int k = 0; k < 4; ++k) sub[e * 4 + k] = sb[k];
+    }
+}
+
+int launch_reward(int64_t n, const float* body_pos, const float* body_rot, const float* tgt_pos, const float* tgt_rot, const float* dof_pos,
+                  const float* dof_vel, const float* tgt_dof_pos, const float* tgt_dof_vel, const float* w, const float* specs, float* rew,
+                  float* sub, hipStream_t s) {
+    if (n <= 0) return V2P_OK;
+    Heights hw;
+    RewardSpecs sp;
+    for (int i = 0; i < NB; ++i) hw.v[i] = w[i];
+    for (int i = 0; i < 8; ++i) sp.v[i] = specs[i];
+    unsigned blocks = (unsigned)((n + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK);
+    hipLaunchKernelGGL(reward_kernel, dim3(blocks), dim3(EB_BLOCK), 0, s, n, body_pos, body_rot, tgt_pos, tgt_rot, dof_pos, dof_vel,
+                       tgt_dof_pos, tgt_dof_vel, hw, sp, rew, sub);
+    return check_hip(hipGetLastError(), "reward_kernel");
+}
+
+// ------------------------------------------------------------------------------------------
+// reset flags  (compute_humanoid_reset, humanoid_smpl_im.py:956-987)
+// ------------------------------------------------------------------------------------------
+__global__ void reset_flags_kernel(int64_t n, const int64_t* __restrict__ progress, const float* __restrict__ rb_pos, Heights h,
+                                   const float* __restrict__ cur_time, const float* __restrict__ clip_len, float max_len, int early,
+                                   int64_t* __restrict__ reset_out, int64_t* __restrict__ term_out) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    int64_t prog = progress[e];
+    int64_t term = 0;
+    if (early) {
+        bool fall = false;
+        for (int b = 0; b < NB; ++b) fall |= rb_pos[(e * NB + b) * 3 + 2] < h.v[b];
+        if (fall && prog > 1) term = 1;
+    }
+    bool cond = ((float)prog >= max_len - 1.f) || (cur_time[e] >= clip_len[e]);
+    reset_out[e] = cond ? 1 : term;
+    term_out[e] = term;
+}
+
+int launch_reset_flags(int64_t n, const int64_t* progress, const float* rb_pos, const float* heights, const float* cur_time,
+                       const float* clip_len, float max_len, int early, int64_t* reset_out, int64_t* term_out, hipStream_t s) {
+    if (n <= 0) return V2P_OK;
+    Heights h;
+    for (int i = 0; i < NB; ++i) h.v[i] = heights[i];
+    unsigned blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(reset_flags_kernel, dim3(blocks), dim3(256), 0, s, n, progress, rb_pos, h, cur_time, clip_len, max_len, early,
+                       reset_out, term_out);
+    return check_hip(hipGetLastError(), "reset_flags_kernel");
+}
+
+// ------------------------------------------------------------------------------------------
+// 734-d in-network imitation observation  (humanoid_smpl_im.py:773-850, next row f-1)
+// layout: root_h 1 | local_body_pos 69 | local_body_rot 144 | local_vel 72 | local_ang_vel 72 | dof_vel 69 |
+//         rel_root_h 1 | rel_root_rot 6 | rel_2d_pos 2 | rel_heading 2 | rel_dof 69 | rel_body_pos 72 | rel_body_rot 144 | motion_bodies 11
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(EB_BLOCK) void obs_imitation_kernel(int64_t n, const float* __restrict__ body_pos, const float* __restrict__ body_rot,
+                                                                 const float* __restrict__ tgt_pos, const float* __restrict__ tgt_rot,
+                                                                 const float* __restrict__ dof_pos, const float* __restrict__ dof_vel,
+                                                                 const float* __restrict__ tgt_dof_pos, const float* __restrict__ body_vel,
+                                                                 const float* __restrict__ body_ang_vel, const float* __restrict__ motion_bodies,
+                                                                 float* __restrict__ obs) {
+    int le = threadIdx.x / NB, j = threadIdx.x % NB;
+    int64_t e = (int64_t)blockIdx.x * ENVS_PER_BLOCK + le;
+    if (e >= n) return;
+    float* o = obs + e * 734;
+    V3 root_pos = ld3(body_pos + e * NB * 3);
+    Q4 root_rot = ref_remove_base_rot(ld4(body_rot + e * NB * 4));
+    float heading = ref_calc_heading(root_rot);
+    Q4 hinv = ref_heading_quat(-heading);
+    int64_t bj = e * NB + j;
+    V3 p = ld3(body_pos + bj * 3);
+    Q4 q = ld4(body_rot + bj * 4);
+    V3 lp = ref_quat_rotate(hinv, p - root_pos);
+    if (j > 0) st3(o + 1 + 3 * (j - 1), lp);
+    V3 tn, nm;
+    if (j == 0) ref_quat_to_tan_norm(root_rot, tn, nm);  // reference overwrites the root entry with the un-headed root (:807-808)
+    else ref_quat_to_tan_norm(qmul(hinv, q), tn, nm);
+    st3(o + 70 + 6 * j, tn);
+    st3(o + 70 + 6 * j + 3, nm);
+    st3(o + 214 + 3 * j, ref_quat_rotate(hinv, ld3(body_vel + bj * 3)));
+    st3(o + 286 + 3 * j, ref_quat_rotate(hinv, ld3(body_ang_vel + bj * 3)));
+    V3 tp = ld3(tgt_pos + bj * 3);
+    Q4 tq = ld4(tgt_rot + bj * 4);
+    st3(o + 507 + 3 * j, ref_quat_rotate(hinv, tp - p));
+    ref_quat_to_tan_norm(qmul(qconj(q), tq), tn, nm);
+    st3(o + 579 + 6 * j, tn);
+    st3(o + 579 + 6 * j + 3, nm);
+    if (j > 0) {
+        int64_t dj = e * NDOF + 3 * (j - 1);
+        st3(o + 358 + 3 * (j - 1), ld3(dof_vel + dj));
+        st3(o + 438 + 3 * (j - 1), ld3(tgt_dof_pos + dj) - ld3(dof_pos + dj));
+    } else {
+        o[0] = root_pos.z;
+        V3 t_root_pos = tp;
+        Q4 t_root_rot = ref_remove_base_rot(tq);
+        o[427] = root_pos.z - t_root_pos.z;
+        ref_quat_to_tan_norm(qmul(t_root_rot, qconj(root_rot)), tn, nm);
+        st3(o + 428, tn);
+        st3(o + 431, nm);
+        V3 rel = ref_quat_rotate(hinv, t_root_pos - root_pos);
+        o[434] = rel.x; o[435] = rel.y;
+        float dh = ref_calc_heading(t_root_rot) - heading;
+        o[436] = cosf(dh); o[437] = sinf(dh);
+    }
+    if (j < 11) o[723 + j] = motion_bodies[e * 11 + j];
+}
+
+int launch_obs_imitation(int64_t n, const float* body_pos, const float* body_rot, const float* tgt_pos, const float* tgt_rot,
+                         const float* dof_pos, const float* dof_vel, const float* tgt_dof_pos, const float* body_vel,
+                         const float* body_ang_vel, const float* motion_bodies, float* obs, hipStream_t s) {
+    if (n <= 0) return V2P_OK;
+    unsigned blocks = (unsigned)((n + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK);
+    hipLaunchKernelGGL(obs_imitation_kernel, dim3(blocks), dim3(EB_BLOCK), 0, s, n, body_pos, body_rot, tgt_pos, tgt_rot, dof_pos, dof_vel,
+                       tgt_dof_pos, body_vel, body_ang_vel, motion_bodies, obs);
+    return check_hip(hipGetLastError(), "obs_imitation_kernel");
+}
+
+// ------------------------------------------------------------------------------------------
+// env kernels
+// ------------------------------------------------------------------------------------------
+struct EnvView {
+    v2p_env_buffers b;
+    v2p_motion_tables t;
+    EnvParams p;
+    const int64_t* motion_id;
+    float* state;
+    float* ctrl;
+    float* out;
+    int64_t n;
+    int cur;  // current target buffer
+};
+
+static EnvView make_view(const v2p_env* e) {
+    EnvView v;
+    v.b = e->buf;
+    v.t = e->mlib->t;
+    v.p = e->p;
+    v.motion_id = e->motion_id;
+    v.state = e->state;
+    v.ctrl = e->ctrl;
+    v.out = e->out;
+    v.n = e->n;
+    v.cur = e->cur_target;
+    return v;
+}
+
+// raw-state observation row (_compute_humanoid_obs, humanoid_smpl_im.py:653-668; order :198)
+__device__ __forceinline__ void write_obs(const EnvView& v, int64_t e, int j, V3 pos, Q4 rot, V3 vel, V3 ang, V3 dpos, V3 dvel) {
+    float* o = v.b.obs + e * NOBS;
+    st3(o + 3 * j, pos);
+    st4(o + 72 + 4 * j, rot);
+    if (j > 0) {
+        st3(o + 168 + 3 * (j - 1), dpos);
+        st3(o + 237 + 3 * (j - 1), dvel);
+    }
+    st3(o + 306 + 3 * j, vel);
+    st3(o + 378 + 3 * j, ang);
+    if (j < 11) o[450 + j] = v.t.motion_bodies[v.motion_id[e] * 11 + j];
+}
+
+// ---- reset: reference-state init (humanoid_smpl_im.py:489-528, 741-755; humanoid_smpl.py:153-173)
+__global__ __launch_bounds__(EB_BLOCK) void env_reset_kernel(EnvView v, const int64_t* __restrict__ env_ids, int64_t n,
+                                                             const float* __restrict__ motion_times) {
+    int le = threadIdx.x / NB, j = threadIdx.x % NB;
+    int64_t i = (int64_t)blockIdx.x * ENVS_PER_BLOCK + le;
+    if (i >= n) return;
+    int64_t e = env_ids ? env_ids[i] : i;
+    int64_t mid = v.motion_id[e];
+    float t0 = motion_times[i];
+    FrameRef fr = frame_lookup(v.t, mid, t0, 1, v.p.ground_tolerance);
+    BodySample s = sample_body_values(v.t, fr, j);
+    const int64_t N = v.n;
+    // exposed tensors
+    float* rb = v.b.rb_state + (e * NB + j) * 13;
+    st3(rb, s.pos);
+    st4(rb + 3, s.rot);
+    V3 zero{0.f, 0.f, 0.f};
+    st3(rb + 7, zero);   // body velocities are zeroed on reset (_set_env_state :748-749)
+    st3(rb + 10, zero);
+    if (j == 0) {
+        float* r = v.b.root_states + e * 13;
+        st3(r, s.pos); st4(r + 3, s.rot); st3(r + 7, s.root_vel); st3(r + 10, s.root_ang_vel);
+        v.state[(ST_ROOT_POS + 0) * N + e] = s.pos.x; v.state[(ST_ROOT_POS + 1) * N + e] = s.pos.y; v.state[(ST_ROOT_POS + 2) * N + e] = s.pos.z;
+        Q4 rq = qnormalize(s.rot);
+        v.state[(ST_ROOT_QUAT + 0) * N + e] = rq.x; v.state[(ST_ROOT_QUAT + 1) * N + e] = rq.y;
+        v.state[(ST_ROOT_QUAT + 2) * N + e] = rq.z; v.state[(ST_ROOT_QUAT + 3) * N + e] = rq.w;
+        v.state[(ST_VEL + 0) * N + e] = s.root_vel.x; v.state[(ST_VEL + 1) * N + e] = s.root_vel.y; v.state[(ST_VEL + 2) * N + e] = s.root_vel.z;
+        v.state[(ST_VEL + 3) * N + e] = s.root_ang_vel.x; v.state[(ST_VEL + 4) * N + e] = s.root_ang_vel.y; v.state[(ST_VEL + 5) * N + e] = s.root_ang_vel.z;
+        v.b.cur_time[e] = t0;
+        v.b.reset_time[e] = t0;
+        v.b.progress[e] = 0;
+        v.b.reset[e] = 0;
+        v.b.terminate[e] = 0;
+    } else {
+        float* d = v.b.dof_state + (e * NDOF + 3 * (j - 1)) * 2;
+        d[0] = s.dof_pos.x; d[1] = s.dof_vel.x; d[2] = s.dof_pos.y; d[3] = s.dof_vel.y; d[4] = s.dof_pos.z; d[5] = s.dof_vel.z;
+        // gym.set_dof_state_tensor_indexed: the engine's joint quaternion is rebuilt from the exp-map dof_pos
+        Q4 jq = ref_exp_map_to_quat(s.dof_pos);
+        int base = ST_JQUAT + 4 * (j - 1);
+        v.state[(base + 0) * N + e] = jq.x; v.state[(base + 1) * N + e] = jq.y; v.state[(base + 2) * N + e] = jq.z; v.state[(base + 3) * N + e] = jq.w;
+        int vb = ST_VEL + 6 + 3 * (j - 1);
+        v.state[(vb + 0) * N + e] = s.dof_vel.x; v.state[(vb + 1) * N + e] = s.dof_vel.y; v.state[(vb + 2) * N + e] = s.dof_vel.z;
+    }
+    write_obs(v, e, j, s.pos, s.rot, zero, zero, s.dof_pos, s.dof_vel);
+    // target = state one control step ahead (_set_target_motion_state :594-624)
+    FrameRef fr1 = frame_lookup(v.t, mid, t0 + v.p.dt, 1, v.p.ground_tolerance);
+    sample_body(v.t, fr1, j, e, packed_out(v.b.target[v.cur]));
+}
+
+// ---- context window (_init_context, humanoid_smpl_im.py:530-563)
+__global__ __launch_bounds__(EB_BLOCK) void env_context_kernel(EnvView v, const int64_t* __restrict__ env_ids, int64_t n,
+                                                               const float* __restrict__ motion_times) {
+    const int W = v.p.context_length + 2 * v.p.context_padding;
+    int lq = threadIdx.x / NB, j = threadIdx.x % NB;
+    int64_t q = (int64_t)blockIdx.x * ENVS_PER_BLOCK + lq;
+    if (q >= n * W) return;
+    int64_t i = q / W;
+    int w = (int)(q - i * W);
+    int64_t e = env_ids ? env_ids[i] : i;
+    int64_t mid = v.motion_id[e];
+    float t = (motion_times[i] + v.p.dt) + v.p.dt * (float)(w - v.p.context_padding);
+    FrameRef fr = frame_lookup(v.t, mid, t, 1, v.p.ground_tolerance);
+    BodySample s = sample_body_values(v.t, fr, j);
+    float* o = v.b.context_feat + (e * W + w) * V2P_CONTEXT_DIM;
+    st3(o + 3 * j, s.pos);
+    st4(o + 72 + 4 * j, s.rot);
+    st3(o + 237 + 3 * j, s.pos);
+    if (j > 0) {
+        st3(o + 168 + 3 * (j - 1), s.dof_pos);
+        st3(o + 309 + 3 * (j - 1), s.dof_pos);
+    } else if (v.b.context_mask) {
+        v.b.context_mask[e * W + w] = t <= v.t.motion_lengths[mid] + 2.f * v.p.dt ? 1 : 0;
+    }
+}
+
+int launch_env_reset(v2p_env* env, const int64_t* env_ids, int64_t n, const float* motion_times, hipStream_t s) {
+    if (n <= 0) return V2P_OK;
+    EnvView v = make_view(env);
+    unsigned blocks = (unsigned)((n + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK);
+    hipLaunchKernelGGL(env_reset_kernel, dim3(blocks), dim3(EB_BLOCK), 0, s, v, env_ids, n, motion_times);
+    int rc = check_hip(hipGetLastError(), "env_reset_kernel");
+    if (rc) return rc;
+    if (env->buf.context_feat) {
+        int64_t q = n * (env->p.context_length + 2 * env->p.context_padding);
+        unsigned cb = (unsigned)((q + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK);
+        hipLaunchKernelGGL(env_context_kernel, dim3(cb), dim3(EB_BLOCK), 0, s, v, env_ids, n, motion_times);
+        rc = check_hip(hipGetLastError(), "env_context_kernel");
+    }
+    return rc;
+}
+
+// ---- pre-physics (humanoid_smpl_im.py:125-157, 391-396): one thread per action component
+__global__ void env_pre_kernel(EnvView v, float* __restrict__ actions) {
+    int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t e = tid / NACT;
+    int a = (int)(tid - e * NACT);
+    if (e >= v.n) return;
+    const int64_t N = v.n;
+    bool dead = v.b.reset[e] == 1;
+    float act = actions[tid];
+    if (dead) { act = 0.f; actions[tid] = 0.f; }  // in place on the caller's tensor, like the reference
+    if (a < NDOF) {
+        float q = v.b.dof_state[(e * NDOF + a) * 2];
+        float tar = fmaxf(fminf(act, q + v.p.pd_tar_lim), q - v.p.pd_tar_lim);
+        v.b.pd_target[e * NDOF + a] = tar;
+        v.ctrl[(CT_PD + a) * N + e] = tar;
+    } else if (a == NDOF || a == NDOF + 3) {
+        // residual root wrench, rotated into the heading frame of the root body
+        float a1 = dead ? 0.f : actions[tid + 1], a2 = dead ? 0.f : actions[tid + 2];
+        float sc = a == NDOF ? v.p.res_force_scale : v.p.res_torque_scale;
+        Q4 rq = ref_remove_base_rot(ld4(v.b.rb_state + e * NB * 13 + 3));
+        Q4 hq = ref_heading_quat(ref_calc_heading(rq));
+        V3 w = ref_quat_rotate(hq, V3{act * sc, a1 * sc, a2 * sc});
+        int base = a == NDOF ? CT_FORCE : CT_TORQUE;
+        v.ctrl[(base + 0) * N + e] = w.x; v.ctrl[(base + 1) * N + e] = w.y; v.ctrl[(base + 2) * N + e] = w.z;
+    }
+}
+
+int launch_env_pre(v2p_env* env, float* actions, hipStream_t s) {
+    EnvView v = make_view(env);
+    int64_t threads = env->n * NACT;
+    unsigned blocks = (unsigned)((threads + 255) / 256);
+    hipLaunchKernelGGL(env_pre_kernel, dim3(blocks), dim3(256), 0, s, v, actions);
+    return check_hip(hipGetLastError(), "env_pre_kernel");
+}
+
+// ---- export: physics outputs (structure-of-arrays) -> the row-major tensors the reference exposes
+//      (the six gym.refresh_*_tensor calls, humanoid_smpl_im.py:452-468)
+__global__ __launch_bounds__(EB_BLOCK) void env_export_kernel(EnvView v) {
+    int le = threadIdx.x / NB, j = threadIdx.x % NB;
+    int64_t e = (int64_t)blockIdx.x * ENVS_PER_BLOCK + le;
+    if (e >= v.n) return;
+    const int64_t N = v.n;
+    float* rb = v.b.rb_state + (e * NB + j) * 13;
+#pragma unroll
+    for (int k = 0; k < 13; ++k) rb[k] = v.out[(OUT_RB + j * 13 + k) * N + e];
+    float* cf = v.b.contact_force + (e * NB + j) * 3;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) cf[k] = v.out[(OUT_CONTACT + j * 3 + k) * N + e];
+    if (j == 0) {
+        float* r = v.b.root_states + e * 13;
+#pragma unroll
+        for (int k = 0; k < 13; ++k) r[k] = v.out[(OUT_RB + k) * N + e];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            int d = 3 * (j - 1) + k;
+            v.b.dof_state[(e * NDOF + d) * 2] = v.out[(OUT_DOF_POS + d) * N + e];
+            v.b.dof_state[(e * NDOF + d) * 2 + 1] = v.state[(ST_VEL + 6 + d) * N + e];
+            v.b.dof_force[e * NDOF + d] = v.out[(OUT_DOF_FORCE + d) * N + e];
+        }
+    }
+}
+
+int launch_env_export(v2p_env* env, hipStream_t s) {
+    EnvView v = make_view(env);
+    unsigned blocks = (unsigned)((env->n + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK);
+    hipLaunchKernelGGL(env_export_kernel, dim3(blocks), dim3(EB_BLOCK), 0, s, v);
+    return check_hip(hipGetLastError(), "env_export_kernel");
+}
+
+// ---- push caller-edited root/dof state into the engine (set_*_state_tensor_indexed, humanoid_smpl.py:161-173)
+__global__ __launch_bounds__(EB_BLOCK) void env_push_state_kernel(EnvView v, const int64_t* __restrict__ env_ids, int64_t n) {
+    int le = threadIdx.x / NB, j = threadIdx.x % NB;
+    int64_t i = (int64_t)blockIdx.x * ENVS_PER_BLOCK + le;
+    if (i >= n) return;
+    int64_t e = env_ids ? env_ids[i] : i;
+    const int64_t N = v.n;
+    if (j == 0) {
+        const float* r = v.b.root_states + e * 13;
+        for (int k = 0; k < 3; ++k) v.state[(ST_ROOT_POS + k) * N + e] = r[k];
+        Q4 q = qnormalize(ld4(r + 3));
+        v.state[(ST_ROOT_QUAT + 0) * N + e] = q.x; v.state[(ST_ROOT_QUAT + 1) * N + e] = q.y;
+        v.state[(ST_ROOT_QUAT + 2) * N + e] = q.z; v.state[(ST_ROOT_QUAT + 3) * N + e] = q.w;
+        for (int k = 0; k < 6; ++k) v.state[(ST_VEL + k) * N + e] = r[7 + k];
+    } else {
+        const float* d = v.b.dof_state + (e * NDOF + 3 * (j - 1)) * 2;
+        Q4 jq = ref_exp_map_to_quat(V3{d[0], d[2], d[4]});
+        int base = ST_JQUAT + 4 * (j - 1);
+        v.state[(base + 0) * N + e] = jq.x; v.state[(base + 1) * N + e] = jq.y; v.state[(base + 2) * N + e] = jq.z; v.state[(base + 3) * N + e] = jq.w;
+        int vb = ST_VEL + 6 + 3 * (j - 1);
+        v.state[(vb + 0) * N + e] = d[1]; v.state[(vb + 1) * N + e] = d[3]; v.state[(vb + 2) * N + e] = d[5];
+    }
+}
+
+int launch_env_push_state(v2p_env* env, const int64_t* env_ids, int64_t n, int /*with_rb*/, hipStream_t s) {
+    if (n <= 0) return V2P_OK;
+    EnvView v = make_view(env);
+    unsigned blocks = (unsigned)((n + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK);
+    hipLaunchKernelGGL(env_push_state_kernel, dim3(blocks), dim3(EB_BLOCK), 0, s, v, env_ids, n);
+    return check_hip(hipGetLastError(), "env_push_state_kernel");
+}
+
+// ---- post-physics (humanoid_smpl_im.py:398-418): progress/time, new target, obs, reward, reset
+__global__ __launch_bounds__(EB_BLOCK) void env_post_kernel(EnvView v) {
+    __shared__ float red[ENVS_PER_BLOCK][NB][4];
+    __shared__ int fell[ENVS_PER_BLOCK];
+    int le = threadIdx.x / NB, j = threadIdx.x % NB;
+    int64_t e = (int64_t)blockIdx.x * ENVS_PER_BLOCK + le;
+    bool live = e < v.n;
+    if (j == 0) fell[le] = 0;
+    __syncthreads();
+    RewardPartial r{0.f, 0.f, 0.f, 0.f};
+    float t_new = 0.f;
+    int64_t mid = 0;
+    if (live) {
+        mid = v.motion_id[e];
+        t_new = v.b.cur_time[e] + v.p.dt;  // _cur_ref_motion_times += dt
+        // sim state as exposed
+        const float* rb = v.b.rb_state + (e * NB + j) * 13;
+        V3 pos = ld3(rb), vel = ld3(rb + 7), ang = ld3(rb + 10);
+        Q4 rot = ld4(rb + 3);
+        V3 dpos{0.f, 0.f, 0.f}, dvel{0.f, 0.f, 0.f};
+        if (j > 0) {
+            const float* d = v.b.dof_state + (e * NDOF + 3 * (j - 1)) * 2;
+            dpos = V3{d[0], d[2], d[4]};
+            dvel = V3{d[1], d[3], d[5]};
+        }
+        write_obs(v, e, j, pos, rot, vel, ang, dpos, dvel);
+        // reward against the PREVIOUS target = the target that was current during this step (:677-680)
+        const float* tg = v.b.target[v.cur] + e * MSD;
+        V3 z{0.f, 0.f, 0.f};
+        r = reward_partial(j, pos, rot, ld3(tg + MS_RB_POS + 3 * j), ld4(tg + MS_RB_ROT + 4 * j), dpos, dvel,
+                           j ? ld3(tg + MS_DOF_POS + 3 * (j - 1)) : z, j ? ld3(tg + MS_DOF_VEL + 3 * (j - 1)) : z, v.p.body_pos_weights[j]);
+        if (pos.z < v.p.term_heights[j]) atomicOr(&fell[le], 1);
+        // new target at cur_time + dt (one step ahead), written to the other buffer
+        FrameRef fr = frame_lookup(v.t, mid, t_new + v.p.dt, 1, v.p.ground_tolerance);
+        sample_body(v.t, fr, j, e, packed_out(v.b.target[1 - v.cur]));
+    }
+    red[le][j][0] = r.dof; red[le][j][1] = r.vel; red[le][j][2] = r.pos; red[le][j][3] = r.rot;
+    __syncthreads();
+    if (live && j == 0) {
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < NB; ++b)
+            for (int k = 0; k < 4; ++k) s[k] += red[le][b][k];
+        float rw, sb[4];
+        reward_finish(v.p.reward_specs, s[0], s[1], s[2], s[3], rw, sb);
+        int64_t old_reset = v.b.reset[e];
+        int64_t old_term = v.b.terminate[e];
+        if (old_reset == 1) { rw = 0.f; sb[0] = sb[1] = sb[2] = sb[3] = 0.f; }  // :688-691
+        v.b.rew[e] = rw;
+        for (int k = 0; k < 4; ++k) v.b.sub_rewards[e * 4 + k] = sb[k];
+        int64_t prog = v.b.progress[e] + 1;
+        v.b.progress[e] = prog;
+        v.b.cur_time[e] = t_new;
+        int64_t term = (v.p.enable_early_termination && fell[le] && prog > 1) ? 1 : 0;
+        bool cond = ((float)prog >= v.p.max_episode_length - 1.f) || (t_new >= v.t.motion_lengths[mid]);
+        int64_t rst = cond ? 1 : term;
+        if (old_reset == 1) { rst = 1; term = old_term; }  // sticky until the next epoch reset (:735-738)
+        v.b.reset[e] = rst;
+        v.b.terminate[e] = term;
+    }
+}
+
+int launch_env_post(v2p_env* env, hipStream_t s) {
+    EnvView v = make_view(env);
+    unsigned blocks = (unsigned)((env->n + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK);
+    hipLaunchKernelGGL(env_post_kernel, dim3(blocks), dim3(EB_BLOCK), 0, s, v);
+    int rc = check_hip(hipGetLastError(), "env_post_kernel");
+    if (rc == V2P_OK) env->cur_target = 1 - env->cur_target;
+    return rc;
+}
+
+}  // namespace v2p

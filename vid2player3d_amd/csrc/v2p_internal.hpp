@@ -1,0 +1,124 @@
+// Internal (non-ABI) declarations shared by the translation units of libv2p_rollout.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/v2p_rollout.h"
+
+namespace v2p {
+
+constexpr int NB = V2P_NUM_BODIES;
+constexpr int NJ = NB - 1;
+constexpr int NDOF = V2P_NUM_DOF;
+constexpr int NACT = V2P_NUM_ACTIONS;
+constexpr int NOBS = V2P_NUM_OBS;
+constexpr int MSD = V2P_MOTION_STATE_DIM;
+constexpr int MAX_HULL_VERTS = 1536;
+constexpr int MAX_DEPTH = 12;
+
+// offsets inside one packed motion-state row [331]
+constexpr int MS_ROOT_POS = 0, MS_ROOT_ROT = 3, MS_DOF_POS = 7, MS_ROOT_VEL = 76, MS_ROOT_ANG_VEL = 79, MS_DOF_VEL = 82, MS_KEY_POS = 151,
+              MS_RB_POS = 163, MS_RB_ROT = 235;
+
+// Body model as the kernels see it: uniform across lanes, read through scalar loads.
+struct DevModel {
+    int32_t parents[NB];
+    int32_t depth[NB];
+    float local_pos[NB][3];
+    float mass[NB];
+    float com[NB][3];
+    float inertia[NB][6];  // xx xy xz yy yz zz about COM, body axes
+    float kp[NB];          // per joint (isotropic over its 3 axes), index = body id, [0] unused
+    float kd[NB];
+    float arm[NB];
+    float bound_radius[NB];  // max |hull vertex| (contact culling)
+    int32_t hull_offsets[NB + 1];
+    float hull_verts[MAX_HULL_VERTS][3];
+};
+
+struct DevTables {
+    v2p_motion_tables t;
+};
+
+}  // namespace v2p
+
+struct v2p_model {
+    v2p::DevModel host;
+    v2p::DevModel* dev;
+    int device;
+};
+
+struct v2p_mlib {
+    v2p_motion_tables t;
+    int device;
+};
+
+namespace v2p {
+
+// physics workspace layout: see physics.hip
+struct EnvParams {
+    float h;               // substep length
+    int nsub;              // substeps per control step
+    int hold_sub;          // substeps during which the residual wrench acts
+    int n_iter;
+    int enable_contact;
+    float gravity_z, mu, contact_offset, max_depen, erp, ang_damp, max_ang_vel;
+    float pd_tar_lim, res_force_scale, res_torque_scale, ground_tolerance, max_episode_length;
+    int enable_early_termination;
+    int context_length, context_padding;
+    float dt;              // control step
+    float term_heights[NB];
+    float body_pos_weights[NB];
+    float reward_specs[8];
+};
+
+}  // namespace v2p
+
+struct v2p_env {
+    const v2p_model* model;
+    const v2p_mlib* mlib;
+    v2p::EnvParams p;
+    v2p_env_buffers buf;
+    int64_t n;
+    int device;
+    int cur_target;           // index of the current target buffer
+    const int64_t* motion_id; // [N] device (borrowed)
+    float* state;             // SoA [STATE_SLOTS][N]
+    float* ctrl;              // SoA [CTRL_SLOTS][N]: pd target 69, wrench 6
+    float* out;               // SoA [OUT_SLOTS][N]: physics outputs before export
+    float* ws;                // SoA [WS_SLOTS][N] physics workspace
+    int32_t* contact_ids;     // [N,24,4] debug
+};
+
+namespace v2p {
+
+// state SoA slots
+constexpr int ST_ROOT_POS = 0, ST_ROOT_QUAT = 3, ST_JQUAT = 7, ST_VEL = 7 + 4 * NJ, STATE_SLOTS = 7 + 4 * NJ + 6 + 3 * NJ;  // 174
+constexpr int CT_PD = 0, CT_FORCE = NDOF, CT_TORQUE = NDOF + 3, CTRL_SLOTS = NDOF + 6;
+// physics outputs (SoA): rigid-body state 24x13, dof_pos 69, contact force 72, dof force 69
+constexpr int OUT_RB = 0, OUT_DOF_POS = NB * 13, OUT_CONTACT = OUT_DOF_POS + NDOF, OUT_DOF_FORCE = OUT_CONTACT + NB * 3,
+              OUT_SLOTS = OUT_DOF_FORCE + NDOF;
+
+void set_error(const char* fmt, ...);
+int check_hip(hipError_t e, const char* what);
+
+// launchers (each in its own translation unit)
+int launch_motion_state(const v2p_motion_tables& t, const int64_t* ids, const float* times, int64_t q, int adjust_height, float ground_tol,
+                        float* const out[9], hipStream_t s);
+int launch_reward(int64_t n, const float* body_pos, const float* body_rot, const float* tgt_pos, const float* tgt_rot, const float* dof_pos,
+                  const float* dof_vel, const float* tgt_dof_pos, const float* tgt_dof_vel, const float* w, const float* specs, float* rew,
+                  float* sub, hipStream_t s);
+int launch_reset_flags(int64_t n, const int64_t* progress, const float* rb_pos, const float* heights, const float* cur_time,
+                       const float* clip_len, float max_len, int early, int64_t* reset_out, int64_t* term_out, hipStream_t s);
+int launch_obs_imitation(int64_t n, const float* body_pos, const float* body_rot, const float* tgt_pos, const float* tgt_rot,
+                         const float* dof_pos, const float* dof_vel, const float* tgt_dof_pos, const float* body_vel,
+                         const float* body_ang_vel, const float* motion_bodies, float* obs, hipStream_t s);
+int launch_env_reset(v2p_env* e, const int64_t* env_ids, int64_t n, const float* motion_times, hipStream_t s);
+int launch_env_pre(v2p_env* e, float* actions, hipStream_t s);
+int launch_env_physics(v2p_env* e, hipStream_t s);
+int launch_env_export(v2p_env* e, hipStream_t s);
+int launch_env_post(v2p_env* e, hipStream_t s);
+int launch_env_push_state(v2p_env* e, const int64_t* env_ids, int64_t n, int with_rb, hipStream_t s);
+int physics_ws_slots();
+
+}  // namespace v2p

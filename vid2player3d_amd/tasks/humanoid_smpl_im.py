@@ -1,0 +1,500 @@
+"""HumanoidSMPLIM: the imitation task of embodied_pose, running on the MI355X rollout engine.
+
+Drop-in for `embodied_pose/env/tasks/humanoid_smpl_im.py:HumanoidSMPLIM` behind the VecTask
+surface: same constructor signature `(cfg, sim_params, physics_engine,
+device_type, device_id, headless)`, same buffers (`obs_buf rew_buf reset_buf progress_buf
+states_buf extras`), same methods (`step reset register_model pre_epoch get_aux_losses
+render_vis`), same back-channel attributes the agent reads (`context_feat context_mask
+smpl_rest_joints smpl_parents smpl_children body_names _motion_lib _reset_ref_motion_ids
+_cur_ref_motion_times context_length`), and the tensor views the reference task keeps over
+the Isaac Gym state tensors (`_rigid_body_pos`, `_dof_pos`, `_humanoid_root_states`, ...).
+
+Every per-step / per-reset computation is a HIP kernel reached through the C ABI
+(include/v2p_rollout.h); this class only owns the torch tensors and the Python-side RNG.
+"""
+import ctypes as C
+import math
+import os
+from dataclasses import dataclass, field
+from enum import Enum
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..model import BodyModel, load_baked_model
+from ..motion_lib import MotionLib
+
+
+@dataclass
+class PhysxParams:
+    """sim.physx block of cfg/amass_im.yaml:39-48"""
+    num_threads: int = 4
+    solver_type: int = 1
+    num_position_iterations: int = 4
+    num_velocity_iterations: int = 0
+    contact_offset: float = 0.02
+    rest_offset: float = 0.0
+    bounce_threshold_velocity: float = 0.2
+    max_depenetration_velocity: float = 10.0
+    default_buffer_size_multiplier: float = 10.0
+
+
+@dataclass
+class SimParams:
+    """What embodied_pose/utils/config.py:190-222 (`parse_sim_params`) hands to the task."""
+    dt: float = 1.0 / 60.0
+    substeps: int = 2
+    gravity: tuple = (0.0, 0.0, -9.81)
+    physx: PhysxParams = field(default_factory=PhysxParams)
+
+    @classmethod
+    def from_cfg(cls, sim_cfg):
+        sp = cls()
+        sim_cfg = sim_cfg or {}
+        sp.dt = float(sim_cfg.get("dt", sp.dt))
+        sp.substeps = int(sim_cfg.get("substeps", sp.substeps))
+        for k, v in (sim_cfg.get("physx") or {}).items():
+            if hasattr(sp.physx, k):
+                setattr(sp.physx, k, type(getattr(sp.physx, k))(v))
+        return sp
+
+
+def default_cfg(num_envs=8192, **env_overrides):
+    """The env/sim blocks of embodied_pose/cfg/amass_im.yaml as a dict."""
+    env = {
+        "numEnvs": num_envs, "envSpacing": 5, "episodeLength": 300, "enableDebugVis": False, "pdControl": True, "powerScale": 1.0,
+        "controlFrequencyInv": 2, "stateInit": "Hybrid", "hybridInitProb": 1.0, "numAMPObsSteps": 10, "enableHistObs": False,
+        "localRootObs": True, "keyBodies": ["R_Ankle", "L_Ankle", "L_Hand", "R_Hand"], "contactBodies": ["R_Ankle", "L_Ankle"],
+        "terminationBodyHeight": -0.5, "terminationHeadHeight": 1.0, "enableEarlyTermination": True, "residual_force_scale": 31.85,
+        "context_length": 32, "context_padding": 8,
+        "plane": {"staticFriction": 1.0, "dynamicFriction": 1.0, "restitution": 0.0},
+    }
+    env.update(env_overrides)
+    sim = {"substeps": 2, "physx": {"num_position_iterations": 4, "num_velocity_iterations": 0, "contact_offset": 0.02,
+                                    "rest_offset": 0.0, "bounce_threshold_velocity": 0.2, "max_depenetration_velocity": 10.0}}
+    return {"env": env, "sim": sim, "args": None}
+
+
+class HumanoidSMPLIM:
+    class StateInit(Enum):
+        Default = 0
+        Start = 1
+        Random = 2
+        Hybrid = 3
+
+    def __init__(self, cfg, sim_params=None, physics_engine=None, device_type="cuda", device_id=0, headless=True):
+        self.cfg = cfg
+        env = cfg["env"]
+        self.args = cfg.get("args")
+        if device_type not in ("cuda", "GPU"):
+            raise RuntimeError("HumanoidSMPLIM runs on the HIP rollout engine only (device_type=%r); there is no CPU simulation path" % device_type)
+        self.device = "cuda:%d" % device_id
+        self.device_id = device_id
+        self.headless = headless
+        self.model = None
+        self.viewer = None
+        sim_params = sim_params or SimParams.from_cfg(cfg.get("sim"))
+        self.sim_params = sim_params
+
+        # ---- config (humanoid_smpl_im.py:54-117, humanoid_smpl.py:24-64)
+        self.has_shape_obs = env.get("has_shape_obs", False)
+        self.has_self_collision = env.get("has_self_collision", False)
+        if self.has_self_collision:
+            raise NotImplementedError("has_self_collision=True (hull-hull contacts) is not built; the reference default is False")
+        self.residual_force_scale = env.get("residual_force_scale", 0.0)
+        self.residual_torque_scale = env.get("residual_torque_scale", self.residual_force_scale)
+        self.kp_scale = env.get("kp_scale", 1.0)
+        self.kd_scale = env.get("kd_scale", self.kp_scale)
+        self.context_length = env.get("context_length", 32)
+        self.context_padding = env.get("context_padding", 8)
+        self.truncate_time = env.get("truncate_time", True)
+        self.pd_tar_lim = env.get("pd_tar_lim", 0.5) * np.pi
+        self.control_freq_inv = env.get("controlFrequencyInv", 1)
+        self._motion_sync_dt = self.control_freq_inv * sim_params.dt
+        self.dt = self.control_freq_inv * sim_params.dt
+        self._pd_control = env.get("pdControl", True)
+        if not self._pd_control:
+            raise NotImplementedError("pdControl=False (direct torque actuation) is not built; amass_im/djokovic_im use PD targets")
+        self._state_init = HumanoidSMPLIM.StateInit[env.get("stateInit", "Hybrid")]
+        self._hybrid_init_prob = env.get("hybridInitProb", 1.0)
+        if self._state_init == HumanoidSMPLIM.StateInit.Default or (self._state_init == HumanoidSMPLIM.StateInit.Hybrid and self._hybrid_init_prob < 1.0):
+            raise NotImplementedError("default-pose state init is not built; amass_im/djokovic_im use reference-state init (hybridInitProb 1.0)")
+        self.ground_tolerance = env.get("ground_tolerance", 0.0)
+        self.max_episode_length = env.get("episodeLength", 300)
+        self._local_root_obs = env.get("localRootObs", True)
+        self._root_height_obs = env.get("rootHeightObs", True)
+        self._enable_early_termination = env.get("enableEarlyTermination", True)
+        self.num_envs = int(env["numEnvs"])
+        self.record_pd_torque = bool(env.get("record_pd_torque", False))
+
+        # ---- body model (replaces Robot.load_from_skeleton + gym.load_asset, :231-298)
+        bm = env.get("body_model")
+        self.body_model = bm if isinstance(bm, BodyModel) else load_baked_model(
+            default_humanoid_mass=env.get("default_humanoid_mass", 90.0), kp_scale=self.kp_scale, kd_scale=self.kd_scale)
+        self.body_names = list(self.body_model.body_names)
+        self.num_bodies = self.body_model.num_bodies
+        self.num_dof = self._num_dof = self.body_model.num_dof
+        self._dof_body_ids = self.body_model.dof_body_ids
+        self._dof_offsets = self.body_model.dof_offsets
+        self._dof_obs_size = len(self._dof_body_ids) * 6
+        self._num_actions = self._num_dof + (6 if self.residual_force_scale > 0 else 0)
+        if self._num_actions != _lib.NUM_ACTIONS:
+            raise NotImplementedError("residual_force_scale must be > 0 (75-d actions); got %d actions" % self._num_actions)
+        self.humanoid_masses = np.full(self.num_envs, self.body_model.total_mass)
+
+        # ---- motion library (:420-440)
+        self._motion_lib = self._load_motion(env)
+        mb_dim = self._motion_lib._motion_bodies.shape[-1]
+        self.obs_names = ["body_pos", "body_rot", "dof_pos", "dof_vel", "body_vel", "body_ang_vel", "motion_bodies"]
+        nb = self.num_bodies
+        shape_dict = {"body_pos": (nb, 3), "body_pos_gt": (nb, 3), "body_rot": (nb, 4), "dof_pos": (self._num_dof,), "dof_pos_gt": (self._num_dof,),
+                      "dof_vel": (self._num_dof,), "body_vel": (nb, 3), "body_ang_vel": (nb, 3), "motion_bodies": (mb_dim,), "joint_conf": (nb,)}
+        self.obs_shapes = [shape_dict[x] for x in self.obs_names]
+        self.obs_dims = [int(np.prod(x)) for x in self.obs_shapes]
+        self.context_names = ["body_pos", "body_rot", "dof_pos", "body_pos_gt", "dof_pos_gt"]
+        if "transform_specs" in env:
+            raise NotImplementedError("transform_specs (joint masking / noise on the context) is not built")
+        self.context_shapes = [shape_dict[x] for x in self.context_names]
+        self.context_dims = [int(np.prod(x)) for x in self.context_shapes]
+        self.is_env_dim_setup = False
+        self._num_obs = sum(self.obs_dims)
+        if self._num_obs != _lib.NUM_OBS:
+            raise RuntimeError("observation size %d != %d" % (self._num_obs, _lib.NUM_OBS))
+        self.num_obs = self._num_obs
+        self.num_states = 0
+        self.num_actions = self._num_actions
+        env["numObservations"] = self.num_obs
+        env["numActions"] = self.num_actions
+
+        # each env is bound to one clip for its lifetime (:247-254)
+        mdev = self._motion_lib._device
+        if env.get("sample_first_motions", False):
+            ids = torch.arange(self.num_envs, device=mdev) % self._motion_lib.num_motions()
+        else:
+            ids = self._motion_lib.sample_motions(self.num_envs, weights_from_lenth=env.get("motion_weights_from_length", False))
+        if "motion_id" in env:
+            ids[:] = env["motion_id"]
+        self._reset_ref_motion_ids = ids.to(self.device).contiguous()
+        self._reset_ref_motion_bodies = self._motion_lib._motion_bodies[self._reset_ref_motion_ids].to(self.device)
+
+        self._allocate_buffers()
+        self._build_termination_heights()
+        key_bodies, contact_bodies = env.get("keyBodies", []), env.get("contactBodies", [])
+        self._key_body_ids = torch.tensor([self.body_names.index(b) for b in key_bodies], device=self.device, dtype=torch.long)
+        self._contact_body_ids = torch.tensor([self.body_names.index(b) for b in contact_bodies], device=self.device, dtype=torch.long)
+        self.body_pos_weights = torch.ones(self.num_bodies, device=self.device)
+        for val, bodies in env.get("body_pos_weights", dict()).items():
+            for body in bodies:
+                self.body_pos_weights[self.body_names.index(body)] = val
+        self.stiffness = torch.tensor(self.body_model.kp, dtype=torch.float32, device=self.device)
+        self.damping = torch.tensor(self.body_model.kd, dtype=torch.float32, device=self.device)
+
+        # agent back-channels (:325-327); joints in MJCF body order (the SMPL-order table needs the licensed SMPL model)
+        rest = np.zeros((self.num_bodies, 3))
+        for b in range(self.num_bodies):
+            p = self.body_model.parents[b]
+            rest[b] = self.body_model.local_pos[b] + (rest[p] if p >= 0 else 0.0)
+        self.smpl_rest_joints = torch.tensor(rest, dtype=torch.float32, device=self.device).unsqueeze(0).repeat(self.num_envs, 1, 1)
+        self.smpl_parents = torch.tensor(self.body_model.parents, dtype=torch.long, device=self.device)
+        ch = self.body_model.children_lists()
+        self.smpl_children = torch.tensor([(c[0] if c else -1) for c in ch], dtype=torch.long, device=self.device)
+
+        self._create_engine()
+        self._sub_rewards_names = "dof_reward,vel_reward,body_pos_reward,body_rot_reward"
+        self.extras = {}
+        self.actions = None
+
+    # ------------------------------------------------------------------ construction helpers
+    def _load_motion(self, env):
+        lib = env.get("motion_lib")
+        if isinstance(lib, MotionLib):
+            return lib
+        if "synthetic_motions" in env:
+            from .. import synth
+
+            spec = dict(env["synthetic_motions"])
+            clips = synth.make_clips(spec.get("seed", 7), spec.get("num_clips", 64), spec.get("min_frames", 90), spec.get("max_frames", 300),
+                                     spec.get("speed", 1.0))
+            return MotionLib.from_clips(clips, self.body_model, self.device)
+        path = env.get("motion_file")
+        if path and os.path.isfile(path) and path.endswith(".npz"):
+            with np.load(path) as z:
+                return MotionLib({k: z[k] for k in z.files}, self.device)
+        raise RuntimeError("no motion library: pass cfg['env']['motion_lib'] (MotionLib), 'synthetic_motions' or a flat .npz 'motion_file' "
+                           "(pickled reference MotionLib .pth files need the reference's classes to unpickle)")
+
+    def _allocate_buffers(self):
+        n, dev = self.num_envs, self.device
+        f = dict(dtype=torch.float32, device=dev)
+        i = dict(dtype=torch.long, device=dev)
+        self.obs_buf = torch.zeros((n, self.num_obs), **f)
+        self.states_buf = torch.zeros((n, self.num_states), **f)
+        self.rew_buf = torch.zeros(n, **f)
+        self.reset_buf = torch.ones(n, **i)
+        self.progress_buf = torch.zeros(n, **i)
+        self.randomize_buf = torch.zeros(n, **i)
+        self._terminate_buf = torch.ones(n, **i)
+        self._sub_rewards = torch.zeros((n, 4), **f)
+        # the tensors gym.acquire_*_tensor would have returned (humanoid_smpl.py:66-113)
+        self._root_states = torch.zeros((n, 13), **f)
+        self._humanoid_root_states = self._root_states
+        self._initial_humanoid_root_states = self._root_states.clone()
+        self._dof_state = torch.zeros((n * self._num_dof, 2), **f)
+        ds = self._dof_state.view(n, self._num_dof, 2)
+        self._dof_pos, self._dof_vel = ds[..., 0], ds[..., 1]
+        self._rigid_body_state = torch.zeros((n * self.num_bodies, 13), **f)
+        rb = self._rigid_body_state.view(n, self.num_bodies, 13)
+        self._rigid_body_pos, self._rigid_body_rot = rb[..., 0:3], rb[..., 3:7]
+        self._rigid_body_vel, self._rigid_body_ang_vel = rb[..., 7:10], rb[..., 10:13]
+        self._contact_forces = torch.zeros((n, self.num_bodies, 3), **f)
+        self.dof_force_tensor = torch.zeros((n, self._num_dof), **f)
+        self._pd_target = torch.zeros((n, self._num_dof), **f)
+        self._cur_ref_motion_times = torch.zeros(n, **f)
+        self._reset_ref_motion_times = torch.zeros(n, **f)
+        self._target_bufs = [torch.zeros((n, _lib.MOTION_STATE_DIM), **f) for _ in range(2)]
+        w = self.context_length + 2 * self.context_padding
+        self.context_feat = torch.zeros((n, w, _lib.CONTEXT_DIM), **f)
+        self._context_mask_u8 = torch.zeros((n, w), dtype=torch.uint8, device=dev)
+        self._humanoid_actor_ids = torch.arange(n, device=dev, dtype=torch.int32)
+        self._prev_dof_pos = None
+
+    def _build_termination_heights(self):
+        """humanoid_smpl_im.py:217-224"""
+        env = self.cfg["env"]
+        th = np.array([env.get("terminationBodyHeight", -0.5)] * self.num_bodies, dtype=np.float64)
+        head = self.body_names.index("Head")
+        self._humanoid_head_id = head
+        th[head] = max(env.get("terminationHeadHeight", 1.0), th[head])
+        self._termination_heights = torch.tensor(th, dtype=torch.float32, device=self.device)
+
+    def _create_engine(self):
+        lib = _lib.load()
+        env, sp, bm = self.cfg["env"], self.sim_params, self.body_model
+        keep = []
+
+        def farr(x):
+            a = np.ascontiguousarray(x, dtype=np.float32)
+            keep.append(a)
+            return a.ctypes.data_as(_lib.c_f)
+
+        def iarr(x):
+            a = np.ascontiguousarray(x, dtype=np.int32)
+            keep.append(a)
+            return a.ctypes.data_as(_lib.c_i32)
+
+        d = _lib.ModelDesc(num_bodies=bm.num_bodies, parents=iarr(bm.parents), local_pos=farr(bm.local_pos), mass=farr(bm.mass),
+                           com=farr(bm.com), inertia=farr(bm.inertia), kp=farr(bm.kp), kd=farr(bm.kd), armature=farr(bm.armature),
+                           hull_offsets=iarr(bm.hull_offsets), hull_verts=farr(bm.hull_verts))
+        self._h_model = C.c_void_p()
+        _lib.check(lib.v2p_model_create(C.byref(d), self.device_id, C.byref(self._h_model)), "v2p_model_create")
+        c = _lib.SimCfg()
+        c.sim_dt = sp.dt
+        c.substeps = sp.substeps
+        c.control_freq_inv = self.control_freq_inv
+        c.num_solver_iterations = sp.physx.num_position_iterations
+        c.enable_contact = int(env.get("enable_contact", True))
+        hold = env.get("residual_force_hold", "first_sim")
+        c.residual_hold_sims = 1 if hold == "first_sim" else self.control_freq_inv
+        c.gravity_z = sp.gravity[2]
+        c.friction = 0.5 * (env["plane"]["staticFriction"] + env["plane"]["dynamicFriction"]) if "plane" in env else 1.0
+        c.contact_offset = sp.physx.contact_offset
+        c.max_depenetration_velocity = sp.physx.max_depenetration_velocity
+        c.erp = env.get("contact_erp", 0.2)
+        c.angular_damping = 0.01
+        c.max_angular_velocity = 100.0
+        c.pd_tar_lim = self.pd_tar_lim
+        c.residual_force_scale = self.residual_force_scale
+        c.residual_torque_scale = self.residual_torque_scale
+        c.ground_tolerance = self.ground_tolerance
+        c.max_episode_length = self.max_episode_length
+        c.enable_early_termination = int(self._enable_early_termination)
+        c.context_length = self.context_length
+        c.context_padding = self.context_padding
+        th = self._termination_heights.cpu().numpy().copy()
+        th[self._contact_body_ids.cpu().numpy()] = -np.inf  # fall_height[:, contact_body_ids] = False (:970)
+        c.term_heights[:] = th.tolist()
+        c.body_pos_weights[:] = self.body_pos_weights.cpu().numpy().tolist()
+        specs = {"k_dof": 60, "k_vel": 0.2, "k_pos": 100, "k_rot": 40, "w_dof": 0.6, "w_vel": 0.1, "w_pos": 0.2, "w_rot": 0.1}
+        specs.update(env.get("reward_specs", dict()))
+        c.reward_specs[:] = [specs[k] for k in ("k_dof", "k_vel", "k_pos", "k_rot", "w_dof", "w_vel", "w_pos", "w_rot")]
+        self.reward_specs = specs
+        b = _lib.EnvBuffers()
+        b.root_states = self._root_states.data_ptr()
+        b.dof_state = self._dof_state.data_ptr()
+        b.rb_state = self._rigid_body_state.data_ptr()
+        b.contact_force = self._contact_forces.data_ptr()
+        b.dof_force = self.dof_force_tensor.data_ptr()
+        b.pd_target = self._pd_target.data_ptr()
+        b.obs = self.obs_buf.data_ptr()
+        b.rew = self.rew_buf.data_ptr()
+        b.sub_rewards = self._sub_rewards.data_ptr()
+        b.reset = self.reset_buf.data_ptr()
+        b.terminate = self._terminate_buf.data_ptr()
+        b.progress = self.progress_buf.data_ptr()
+        b.cur_time = self._cur_ref_motion_times.data_ptr()
+        b.reset_time = self._reset_ref_motion_times.data_ptr()
+        b.target[0] = self._target_bufs[0].data_ptr()
+        b.target[1] = self._target_bufs[1].data_ptr()
+        b.context_feat = self.context_feat.data_ptr()
+        b.context_mask = self._context_mask_u8.data_ptr()
+        self._h_env = C.c_void_p()
+        _lib.check(lib.v2p_env_create(self._h_model, self._motion_lib.handle(), C.byref(c), _lib.ptr(self._reset_ref_motion_ids),
+                                      self.num_envs, C.byref(b), self.device_id, C.byref(self._h_env)), "v2p_env_create")
+        self._lib = lib
+        self._cur = 0
+
+    def close(self):
+        if getattr(self, "_h_env", None):
+            self._lib.v2p_env_destroy(self._h_env)
+            self._h_env = None
+        if getattr(self, "_h_model", None):
+            self._lib.v2p_model_destroy(self._h_model)
+            self._h_model = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ reference surface
+    def get_obs_size(self):
+        return self._num_obs
+
+    def get_action_size(self):
+        return self._num_actions
+
+    def get_states(self):
+        return self.states_buf
+
+    def register_model(self, model):
+        self.model = model
+
+    def pre_epoch(self, epoch):
+        return
+
+    def render_vis(self, init=False):
+        return
+
+    def render(self, sync_frame_time=False):
+        return
+
+    def get_aux_losses(self, model_res_dict):
+        """humanoid_smpl_im.py:694-722 with empty aux_loss_specs (amass_im / djokovic_im)."""
+        if self.cfg["env"].get("aux_loss_specs"):
+            raise NotImplementedError("aux_loss_specs are not built")
+        return {}, {}
+
+    @property
+    def context_mask(self):
+        return self._context_mask_u8.bool()
+
+    def _stream(self):
+        return _lib.current_stream(self.device)
+
+    def reset(self, env_ids=None):
+        """HumanoidSMPL.reset (humanoid_smpl.py:136-159) with reference-state init."""
+        if env_ids is None:
+            n = self.num_envs
+            ids_t, motion_ids = None, self._reset_ref_motion_ids
+        else:
+            ids_t = env_ids.to(device=self.device, dtype=torch.long).contiguous()
+            n = ids_t.shape[0]
+            if n == 0:
+                return
+            motion_ids = self._reset_ref_motion_ids[ids_t]
+        if self._state_init == HumanoidSMPLIM.StateInit.Start:
+            times = torch.zeros(n, device=self.device)
+        else:
+            trunc = self.context_length * self.dt if self.truncate_time else None
+            times = self._motion_lib.sample_time(motion_ids, truncate_time=trunc).to(self.device)
+        self.reset_with_times(ids_t, times)
+
+    def reset_with_times(self, env_ids, motion_times):
+        """Reference-state init at explicit clip times (parity tests; _reset_ref_state_init :489-528)."""
+        times = motion_times.to(device=self.device, dtype=torch.float32).contiguous()
+        n = self.num_envs if env_ids is None else env_ids.shape[0]
+        _lib.check(self._lib.v2p_env_reset(self._h_env, _lib.ptr(env_ids), n, _lib.ptr(times), self._stream()), "v2p_env_reset")
+        self._reset_ref_env_ids = env_ids
+        if self.model is not None:
+            if not self.is_env_dim_setup:
+                self.model.a2c_network.setup_env_named_dims(self.obs_names, self.obs_shapes, self.obs_dims, self.context_names,
+                                                            self.context_shapes, self.context_dims)
+                self.is_env_dim_setup = True
+            with torch.no_grad():
+                self.model.a2c_network.forward_context(self.context_feat, self.context_mask)
+
+    def step(self, actions):
+        """BaseTask.step (base_task.py:147-165).  `actions` [N,75] fp32 on this device; rows of envs whose
+        reset flag is set are zeroed in place like the reference does (humanoid_smpl_im.py:126)."""
+        self.pre_physics_step(actions)
+        self._physics_step()
+        self.post_physics_step()
+
+    def _check_actions(self, actions):
+        if actions.dtype != torch.float32 or not actions.is_contiguous() or str(actions.device) != self.device or tuple(actions.shape) != (self.num_envs, self.num_actions):
+            raise RuntimeError("actions must be a contiguous float32 [%d,%d] tensor on %s" % (self.num_envs, self.num_actions, self.device))
+
+    def pre_physics_step(self, actions):
+        self._check_actions(actions)
+        if self.record_pd_torque:
+            self._prev_dof_pos = self._dof_pos.clone()
+        _lib.check(self._lib.v2p_env_pre_physics(self._h_env, _lib.ptr(actions), self._stream()), "v2p_env_pre_physics")
+        self.actions = actions
+
+    def _physics_step(self):
+        _lib.check(self._lib.v2p_env_physics(self._h_env, self._stream()), "v2p_env_physics")
+
+    def post_physics_step(self):
+        _lib.check(self._lib.v2p_env_post_physics(self._h_env, self._stream()), "v2p_env_post_physics")
+        self._cur = 1 - self._cur
+        self.extras["terminate"] = self._terminate_buf
+        self.extras["sub_rewards"] = self._sub_rewards
+        self.extras["sub_rewards_names"] = self._sub_rewards_names
+
+    def step_fused(self, actions):
+        """One C call for the whole step (what bench.py times)."""
+        self._check_actions(actions)
+        _lib.check(self._lib.v2p_env_step(self._h_env, _lib.ptr(actions), self._stream()), "v2p_env_step")
+        self._cur = 1 - self._cur
+        self.actions = actions
+        self.extras["terminate"] = self._terminate_buf
+        self.extras["sub_rewards"] = self._sub_rewards
+        self.extras["sub_rewards_names"] = self._sub_rewards_names
+
+    def _reset_env_tensors(self, env_ids=None, with_rb_state=False):
+        """set_actor_root_state_tensor_indexed + set_dof_state_tensor_indexed (humanoid_smpl.py:161-173):
+        push edits made through `_humanoid_root_states/_dof_pos/_dof_vel` into the engine."""
+        n = self.num_envs if env_ids is None else env_ids.shape[0]
+        _lib.check(self._lib.v2p_env_push_state(self._h_env, _lib.ptr(env_ids), n, int(with_rb_state), self._stream()), "v2p_env_push_state")
+
+    def debug_contacts(self):
+        out = torch.empty((self.num_envs, self.num_bodies, 4), dtype=torch.int32, device=self.device)
+        _lib.check(self._lib.v2p_env_debug_contacts(self._h_env, _lib.ptr(out), self._stream()), "v2p_env_debug_contacts")
+        return out
+
+    # ------------------------------------------------------------------ target views
+    _SLICES = {"root_pos": (0, 3, None), "root_rot": (3, 7, None), "dof_pos": (7, 76, None), "root_vel": (76, 79, None),
+               "root_ang_vel": (79, 82, None), "dof_vel": (82, 151, None), "key_pos": (151, 163, (4, 3)), "rb_pos": (163, 235, (24, 3)),
+               "rb_rot": (235, 331, (24, 4))}
+
+    def _tview(self, which, name):
+        a, b, shp = self._SLICES[name]
+        t = self._target_bufs[which][:, a:b]
+        return t.view(self.num_envs, *shp) if shp else t
+
+    @property
+    def pd_torque(self):
+        if self._prev_dof_pos is None:
+            raise RuntimeError("set cfg['env']['record_pd_torque']=True to keep the pre-step dof positions")
+        return (self._pd_target - self._prev_dof_pos) * self.stiffness
+
+
+def _add_target_properties():
+    for name in HumanoidSMPLIM._SLICES:
+        setattr(HumanoidSMPLIM, "_target_" + name, property(lambda self, n=name: self._tview(self._cur, n)))
+        setattr(HumanoidSMPLIM, "_prev_target_" + name, property(lambda self, n=name: self._tview(1 - self._cur, n)))
+
+
+_add_target_properties()
