@@ -187,9 +187,10 @@ int v2p_env_reset(v2p_env* e, const int64_t* env_ids, int64_t n, const float* mo
  * post_physics_step.  actions [N,75] is masked IN PLACE for envs whose reset flag is set
  * (humanoid_smpl_im.py:126). */
 int v2p_env_step(v2p_env* e, float* actions, void* stream);
-/* The three stages separately (trace replay / profiling). */
+/* The stages separately (trace replay / profiling). */
 int v2p_env_pre_physics(v2p_env* e, float* actions, void* stream);   /* humanoid_smpl_im.py:125-157 */
-int v2p_env_physics(v2p_env* e, void* stream);                        /* base_task.py:450-454 + refresh_* */
+int v2p_env_physics(v2p_env* e, void* stream);                        /* base_task.py:450-454: the 2 x gym.simulate */
+int v2p_env_export(v2p_env* e, void* stream);                         /* the 6 gym.refresh_*_tensor calls, humanoid_smpl_im.py:452-468 */
 int v2p_env_post_physics(v2p_env* e, void* stream);                   /* humanoid_smpl_im.py:398-418 */
 
 /* set_actor_root_state_tensor_indexed + set_dof_state_tensor_indexed (+ rigid-body state for

@@ -87,9 +87,9 @@ def test_reset_flags_match_reference_golden(golden_task_ops):
     h[[7, 3]] = -np.inf
     rst = torch.empty(n, dtype=torch.long, device=DEV)
     term = torch.empty(n, dtype=torch.long, device=DEV)
-    _lib.check(lib.v2p_reset_flags(n, _lib.ptr(T(g["reset_progress"], torch.long)), _lib.ptr(T(g["reset_rb_pos"])), (C.c_float * 24)(*h.tolist()),
-                                   _lib.ptr(T(g["reset_cur_time"])), _lib.ptr(T(g["reset_clip_len"])), 300.0, 1, _lib.ptr(rst), _lib.ptr(term), None),
-               "v2p_reset_flags")
+    prog, rb, ct, cl = T(g["reset_progress"], torch.long), T(g["reset_rb_pos"]), T(g["reset_cur_time"]), T(g["reset_clip_len"])  # keep alive
+    _lib.check(lib.v2p_reset_flags(n, _lib.ptr(prog), _lib.ptr(rb), (C.c_float * 24)(*h.tolist()), _lib.ptr(ct), _lib.ptr(cl), 300.0, 1,
+                                   _lib.ptr(rst), _lib.ptr(term), None), "v2p_reset_flags")
     assert np.array_equal(N(rst), g["reset_out"])
     assert np.array_equal(N(term), g["terminate_out"])
 

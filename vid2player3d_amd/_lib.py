@@ -59,6 +59,11 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("libv2p_rollout.so is missing (%s): build it with `python -m vid2player3d_amd.build`; "
                            "there is no CPU fallback for the rollout engine" % LIB_PATH)
+    # PyTorch-ROCm owns the device memory and the streams we launch on, and it ships its own HIP
+    # runtime: import it first so that this library binds to the SAME libamdhip64 instance (two HIP
+    # runtimes in one process do not see each other's devices or streams).
+    import torch  # noqa: F401
+
     lib = C.CDLL(LIB_PATH)
     lib.v2p_last_error.restype = C.c_char_p
     lib.v2p_abi_version.restype = C.c_int
@@ -76,6 +81,7 @@ def load():
         "v2p_env_step": [vp, vp, vp],
         "v2p_env_pre_physics": [vp, vp, vp],
         "v2p_env_physics": [vp, vp],
+        "v2p_env_export": [vp, vp],
         "v2p_env_post_physics": [vp, vp],
         "v2p_env_push_state": [vp, vp, C.c_int64, C.c_int, vp],
         "v2p_env_target_index": [vp],
@@ -95,7 +101,7 @@ def load():
 
 EXPORTED_SYMBOLS = (
     "v2p_model_create", "v2p_model_destroy", "v2p_mlib_create", "v2p_mlib_destroy", "v2p_motion_state", "v2p_reward", "v2p_reset_flags",
-    "v2p_obs_imitation", "v2p_env_create", "v2p_env_destroy", "v2p_env_reset", "v2p_env_step", "v2p_env_pre_physics", "v2p_env_physics",
+    "v2p_obs_imitation", "v2p_env_create", "v2p_env_destroy", "v2p_env_reset", "v2p_env_step", "v2p_env_pre_physics", "v2p_env_physics", "v2p_env_export",
     "v2p_env_post_physics", "v2p_env_push_state", "v2p_env_target_index", "v2p_env_debug_contacts", "v2p_last_error", "v2p_abi_version",
 )
 

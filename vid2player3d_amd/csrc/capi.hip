@@ -240,9 +240,13 @@ int v2p_env_pre_physics(v2p_env* e, float* actions, void* stream) {
 int v2p_env_physics(v2p_env* e, void* stream) {
     if (!e) { set_error("v2p_env_physics: bad argument"); return V2P_ERR_INVALID; }
     DeviceGuard g(e->device);
-    int rc = launch_env_physics(e, (hipStream_t)stream);
-    if (rc == V2P_OK) rc = launch_env_export(e, (hipStream_t)stream);
-    return rc;
+    return launch_env_physics(e, (hipStream_t)stream);
+}
+
+int v2p_env_export(v2p_env* e, void* stream) {
+    if (!e) { set_error("v2p_env_export: bad argument"); return V2P_ERR_INVALID; }
+    DeviceGuard g(e->device);
+    return launch_env_export(e, (hipStream_t)stream);
 }
 
 int v2p_env_post_physics(v2p_env* e, void* stream) {
@@ -254,6 +258,7 @@ int v2p_env_post_physics(v2p_env* e, void* stream) {
 int v2p_env_step(v2p_env* e, float* actions, void* stream) {
     int rc = v2p_env_pre_physics(e, actions, stream);
     if (rc == V2P_OK) rc = v2p_env_physics(e, stream);
+    if (rc == V2P_OK) rc = v2p_env_export(e, stream);
     if (rc == V2P_OK) rc = v2p_env_post_physics(e, stream);
     return rc;
 }

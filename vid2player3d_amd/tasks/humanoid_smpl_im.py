@@ -445,6 +445,7 @@ class HumanoidSMPLIM:
 
     def _physics_step(self):
         _lib.check(self._lib.v2p_env_physics(self._h_env, self._stream()), "v2p_env_physics")
+        _lib.check(self._lib.v2p_env_export(self._h_env, self._stream()), "v2p_env_export")
 
     def post_physics_step(self):
         _lib.check(self._lib.v2p_env_post_physics(self._h_env, self._stream()), "v2p_env_post_physics")
