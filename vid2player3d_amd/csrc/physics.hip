@@ -22,6 +22,7 @@
 // over links / vertices / rows are wave-uniform (scalar control flow, no divergence except
 // value selects).
 #include <math.h>
+#include <stdlib.h>
 
 #include "v2p_internal.hpp"
 #include "v2p_math.hpp"
@@ -62,6 +63,7 @@ struct PhysArgs {
     float* __restrict__ ws;
     int32_t* __restrict__ contact_ids;
     int64_t n;
+    int lanes;  // environments per wave64 (active lanes); the rest of the wave shadows the last one
     EnvParams p;
 };
 
@@ -195,7 +197,10 @@ __device__ __forceinline__ void wsBlocksS(float* ws, int64_t N, int64_t e, int b
 template <bool CONTACT>
 __global__ __launch_bounds__(64) void physics_kernel(PhysArgs a) {
     const int64_t N = a.n;
-    int64_t e = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    // `lanes` environments per wave: the step is bound by dependent memory round trips, not by VALU
+    // work, so spreading the envs over more (partly filled) waves buys latency hiding.
+    int lane = threadIdx.x < a.lanes ? threadIdx.x : a.lanes - 1;
+    int64_t e = (int64_t)blockIdx.x * a.lanes + lane;
     if (e >= N) e = N - 1;  // tail lanes shadow the last env (identical values, identical addresses)
     const DevModel& M = *a.model;
     float* __restrict__ ws = a.ws;
@@ -752,7 +757,14 @@ int launch_env_physics(v2p_env* env, hipStream_t s) {
     a.contact_ids = env->contact_ids;
     a.n = env->n;
     a.p = env->p;
-    unsigned blocks = (unsigned)((env->n + 63) / 64);
+    static int lanes_cfg = 0;
+    if (!lanes_cfg) {
+        const char* s_env = getenv("V2P_LANES_PER_WAVE");
+        lanes_cfg = s_env ? atoi(s_env) : 64;
+        if (lanes_cfg < 1 || lanes_cfg > 64) lanes_cfg = 64;
+    }
+    a.lanes = lanes_cfg;
+    unsigned blocks = (unsigned)((env->n + a.lanes - 1) / a.lanes);
     if (env->p.enable_contact)
         hipLaunchKernelGGL(physics_kernel<true>, dim3(blocks), dim3(64), 0, s, a);
     else
