@@ -79,17 +79,48 @@ int v2p_model_create(const v2p_model_desc* d, int device, v2p_model** out) {
             }
             h.kp[b] = kp[0]; h.kd[b] = kd[0]; h.arm[b] = ar[0];
         }
-        h.hull_offsets[b] = d->hull_offsets[b];
     }
-    h.hull_offsets[NB] = d->hull_offsets[NB];
-    for (int b = 0; b < NB; ++b) {
-        float r2 = 0.f;
-        for (int v = h.hull_offsets[b]; v < h.hull_offsets[b + 1]; ++v) {
-            for (int k = 0; k < 3; ++k) h.hull_verts[v][k] = d->hull_verts[3 * v + k];
-            float n2 = h.hull_verts[v][0] * h.hull_verts[v][0] + h.hull_verts[v][1] * h.hull_verts[v][1] + h.hull_verts[v][2] * h.hull_verts[v][2];
-            if (n2 > r2) r2 = n2;
+    {
+        int off = 0;
+        for (int b = 0; b < NB; ++b) {
+            int n = d->hull_offsets[b + 1] - d->hull_offsets[b];
+            int np = (n + HULL_PAD - 1) / HULL_PAD * HULL_PAD;
+            if (n < 1 || n > 64) { set_error("v2p_model_create: body %d has %d hull vertices (1..64 supported)", b, n); delete m; return V2P_ERR_UNSUPPORTED; }
+            if (off + np > MAX_HULL_VERTS) { set_error("v2p_model_create: padded hull vertices exceed the limit %d", MAX_HULL_VERTS); delete m; return V2P_ERR_UNSUPPORTED; }
+            h.hull_offsets[b] = off;
+            h.hull_count[b] = n;
+            float r2 = 0.f;
+            for (int v = 0; v < np; ++v) {
+                const float* src = d->hull_verts + 3 * (d->hull_offsets[b] + (v < n ? v : n - 1));
+                for (int k = 0; k < 3; ++k) h.hull_verts[off + v][k] = src[k];
+                float n2 = src[0] * src[0] + src[1] * src[1] + src[2] * src[2];
+                if (n2 > r2) r2 = n2;
+            }
+            h.bound_radius[b] = sqrtf(r2);
+            off += np;
         }
-        h.bound_radius[b] = sqrtf(r2);
+        h.hull_offsets[NB] = off;
+    }
+    {
+        int k = 0;
+        for (int dpt = 0; dpt < MAX_DEPTH; ++dpt)
+            for (int b = 0; b < NB; ++b)
+                if (h.depth[b] == dpt) h.order[k++] = b;
+    }
+    {
+        int nchild[NB] = {0}, nslot = 1;
+        for (int b = 1; b < NB; ++b) nchild[h.parents[b]]++;
+        for (int b = 0; b < NB; ++b) h.lam_slot[b] = -1;
+        h.lam_slot[0] = 0;
+        for (int b = 1; b < NB; ++b) {
+            // a child that does not directly follow its parent needs the parent's Lambda from a saved slot
+            int p = h.parents[b];
+            if (p != b - 1 && h.lam_slot[p] < 0) {
+                if (nslot >= MAX_BRANCH) { set_error("v2p_model_create: more than %d branching links", MAX_BRANCH); delete m; return V2P_ERR_UNSUPPORTED; }
+                h.lam_slot[p] = nslot++;
+            }
+        }
+        (void)nchild;
     }
     m->device = device;
     m->dev = nullptr;
@@ -196,6 +227,7 @@ int v2p_env_create(const v2p_model* model, const v2p_mlib* mlib, const v2p_sim_c
     memcpy(p.term_heights, c->term_heights, sizeof(p.term_heights));
     memcpy(p.body_pos_weights, c->body_pos_weights, sizeof(p.body_pos_weights));
     memcpy(p.reward_specs, c->reward_specs, sizeof(p.reward_specs));
+    for (int b = 0; b < NB; ++b) p.aug[b] = b ? model->host.arm[b] + p.h * model->host.kd[b] + p.h * p.h * model->host.kp[b] : 0.f;
     DeviceGuard g(device);
     if (!g.ok) { set_error("v2p_env_create: cannot select device %d", device); delete e; return V2P_ERR_HIP; }
     size_t N = (size_t)n;
@@ -209,6 +241,10 @@ int v2p_env_create(const v2p_model* model, const v2p_mlib* mlib, const v2p_sim_c
     if (rc == V2P_OK) rc = check_hip(hipMemset(e->out, 0, sizeof(float) * OUT_SLOTS * N), "hipMemset(out)");
     if (rc == V2P_OK) rc = check_hip(hipMemset(e->ws, 0, sizeof(float) * (size_t)physics_ws_slots() * N), "hipMemset(ws)");
     if (rc == V2P_OK) rc = check_hip(hipMemset(e->contact_ids, 0xff, sizeof(int32_t) * NB * 4 * N), "hipMemset(contact_ids)");
+    if (rc == V2P_OK && getenv("V2P_PHASE_TIMING")) {
+        rc = check_hip(hipMalloc((void**)&e->prof, sizeof(long long) * 16), "hipMalloc(prof)");
+        if (rc == V2P_OK) rc = check_hip(hipMemset(e->prof, 0, sizeof(long long) * 16), "hipMemset(prof)");
+    }
     if (rc != V2P_OK) { v2p_env_destroy(e); return rc; }
     *out = e;
     return V2P_OK;
@@ -222,6 +258,13 @@ void v2p_env_destroy(v2p_env* e) {
     if (e->out) (void)hipFree(e->out);
     if (e->ws) (void)hipFree(e->ws);
     if (e->contact_ids) (void)hipFree(e->contact_ids);
+    if (e->prof) {
+        long long h[16];
+        if (hipMemcpy(h, e->prof, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess)
+            fprintf(stderr, "[v2p phase cycles, block 0] stage+pdload %lld pass1 %lld pass2 %lld root+pass3 %lld contacts %lld lambda %lld pgs %lld integrate %lld | block updates %lld touched-sum %lld substeps %lld | pgs: rows %lld back %lld root %lld fwd %lld\n",
+                    h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11], h[12], h[13], h[14]);
+        (void)hipFree(e->prof);
+    }
     delete e;
 }
 

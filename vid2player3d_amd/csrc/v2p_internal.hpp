@@ -14,7 +14,9 @@ constexpr int NACT = V2P_NUM_ACTIONS;
 constexpr int NOBS = V2P_NUM_OBS;
 constexpr int MSD = V2P_MOTION_STATE_DIM;
 constexpr int MAX_HULL_VERTS = 1536;
+constexpr int HULL_PAD = 8;
 constexpr int MAX_DEPTH = 12;
+constexpr int MAX_BRANCH = 3;  // links with more than one child (root + chest for SMPL)
 
 // offsets inside one packed motion-state row [331]
 constexpr int MS_ROOT_POS = 0, MS_ROOT_ROT = 3, MS_DOF_POS = 7, MS_ROOT_VEL = 76, MS_ROOT_ANG_VEL = 79, MS_DOF_VEL = 82, MS_KEY_POS = 151,
@@ -24,6 +26,8 @@ constexpr int MS_ROOT_POS = 0, MS_ROOT_ROT = 3, MS_DOF_POS = 7, MS_ROOT_VEL = 76
 struct DevModel {
     int32_t parents[NB];
     int32_t depth[NB];
+    int32_t order[NB];     // links in level (breadth-first) order: consecutive entries never depend on each other's results
+    int32_t lam_slot[NB];  // index into the saved-Lambda register sets for branching links (root = 0), -1 otherwise
     float local_pos[NB][3];
     float mass[NB];
     float com[NB][3];
@@ -32,9 +36,14 @@ struct DevModel {
     float kd[NB];
     float arm[NB];
     float bound_radius[NB];  // max |hull vertex| (contact culling)
-    int32_t hull_offsets[NB + 1];
+    int32_t hull_offsets[NB + 1];  // into hull_verts; every body's list is padded to a multiple of HULL_PAD (last vertex repeated)
+    int32_t hull_count[NB];        // real vertex count per body
     float hull_verts[MAX_HULL_VERTS][3];
 };
+
+// the model is immutable while kernels run: reading it through the constant address space keeps every
+// access a scalar load that the compiler may hoist and batch (stores to the workspace cannot clobber it)
+typedef const DevModel __attribute__((address_space(4))) ConstModel;
 
 struct DevTables {
     v2p_motion_tables t;
@@ -70,6 +79,7 @@ struct EnvParams {
     float term_heights[NB];
     float body_pos_weights[NB];
     float reward_specs[8];
+    float aug[NB];         // joint-diagonal augmentation armature + h kd + h^2 kp per link
 };
 
 }  // namespace v2p
@@ -88,6 +98,7 @@ struct v2p_env {
     float* out;               // SoA [OUT_SLOTS][N]: physics outputs before export
     float* ws;                // SoA [WS_SLOTS][N] physics workspace
     int32_t* contact_ids;     // [N,24,4] debug
+    long long* prof;          // [8] phase cycle counters when V2P_PHASE_TIMING is set (device), else NULL
 };
 
 namespace v2p {
