@@ -108,6 +108,25 @@ int v2p_model_create(const v2p_model_desc* d, int device, v2p_model** out) {
                 if (h.depth[b] == dpt) h.order[k++] = b;
     }
     {
+        int nch[NB] = {0};
+        h.max_depth = 0;
+        h.multi_child_levels = 0;
+        h.max_hull_count = 0;
+        for (int b = 0; b < NB; ++b) {
+            for (int k = 0; k < 3; ++k) h.children[b][k] = -1;
+            h.anc_mask[b] = 1 << b;
+            if (h.depth[b] > h.max_depth) h.max_depth = h.depth[b];
+            if (h.hull_count[b] > h.max_hull_count) h.max_hull_count = h.hull_count[b];
+        }
+        for (int b = 1; b < NB; ++b) {
+            int p = h.parents[b];
+            if (nch[p] >= 3) { set_error("v2p_model_create: link %d has more than 3 children", p); delete m; return V2P_ERR_UNSUPPORTED; }
+            h.children[p][nch[p]++] = b;
+            if (nch[p] > 1) h.multi_child_levels |= 1 << h.depth[b];
+            h.anc_mask[b] |= h.anc_mask[p];
+        }
+    }
+    {
         int nchild[NB] = {0}, nslot = 1;
         for (int b = 1; b < NB; ++b) nchild[h.parents[b]]++;
         for (int b = 0; b < NB; ++b) h.lam_slot[b] = -1;
@@ -283,7 +302,14 @@ int v2p_env_pre_physics(v2p_env* e, float* actions, void* stream) {
 int v2p_env_physics(v2p_env* e, void* stream) {
     if (!e) { set_error("v2p_env_physics: bad argument"); return V2P_ERR_INVALID; }
     DeviceGuard g(e->device);
-    return launch_env_physics(e, (hipStream_t)stream);
+    // two schedules of the same model: "ll" (default) = one link per lane, register resident;
+    // "lds" = one env per lane, LDS resident (kept as an independent cross-check, V2P_KERNEL=lds)
+    static int use_ll = -1;
+    if (use_ll < 0) {
+        const char* k = getenv("V2P_KERNEL");
+        use_ll = (k && !strcmp(k, "lds")) ? 0 : 1;
+    }
+    return use_ll ? launch_env_physics_ll(e, (hipStream_t)stream) : launch_env_physics(e, (hipStream_t)stream);
 }
 
 int v2p_env_export(v2p_env* e, void* stream) {

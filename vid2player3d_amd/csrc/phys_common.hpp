@@ -1,0 +1,35 @@
+// Declarations shared by the two physics kernels (physics.hip: one env per lane, LDS resident;
+// physics_ll.hip: one link per lane, register resident).
+#pragma once
+#include "phys_math.hpp"
+#include "v2p_internal.hpp"
+
+namespace v2p {
+
+// ---------------------------------------------------------------------------- global workspace layout
+// per-link slots of the global (structure-of-arrays [slot][env]) workspace: contact records + Lambda_b
+constexpr int GL = 0;     // 21 Lambda_b: La(6) Lb(9) Lc(6)
+constexpr int GCN = 21;   // 1  number of contacts
+constexpr int GCR = 22;   // 12 contact offsets from the body origin
+constexpr int GCB = 34;   // 4  contact bias
+constexpr int GCL = 38;   // 12 contact impulses (n, t1, t2)
+constexpr int LINK_SLOTS = 50;
+constexpr int WS_SLOTS = LINK_SLOTS * NB;
+
+
+struct PhysArgs {
+    const DevModel* __restrict__ model;
+    float* __restrict__ state;
+    const float* __restrict__ ctrl;
+    float* __restrict__ out;
+    float* __restrict__ ws;
+    int32_t* __restrict__ contact_ids;
+    long long* prof;  // optional cycle counters per phase (block 0), NULL = off
+    unsigned long long par_pack[2];  // parents[24] and level order[24], 5 bits each, 12 per word: the tree walks of the
+    unsigned long long ord_pack[2];  // impulse sweep decode them with scalar ALU ops instead of dependent scalar loads
+    int64_t n;
+    EnvParams p;
+};
+
+
+}  // namespace v2p

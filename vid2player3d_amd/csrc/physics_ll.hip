@@ -1,0 +1,588 @@
+// Articulated rigid-body step, LANE = LINK mapping: 32 lanes per environment (24 links + 8 idle), two
+// environments per wave64, every per-link quantity in registers.  Same model and same arithmetic per
+// link as physics.hip (see that file and oracle/phys/v2p_phys_oracle.c for the model); what changes is
+// the schedule:
+//
+//   * the three tree recursions run level-synchronously (max depth 8 instead of 23 sequential links);
+//     parent -> child and child -> parent transfers are cross-lane pulls (ds_bpermute) inside the wave
+//   * contact generation is parallel over bodies (each lane scans its own hull)
+//   * the block Gauss-Seidel sweep visits, per environment, only the bodies that environment touches
+//     (k-th touched body of both environments at once), and the impulse propagation is again level
+//     synchronous: leaf -> root along the path, root -> leaves for every link
+//   * no LDS or global workspace: the kernel reads the state once, keeps it in registers for the 4
+//     substeps and writes it once
+//
+// The sequential semantics of the Gauss-Seidel sweep (bodies ascending, points in slot order, rows
+// n, t1, t2) are unchanged, so results agree with the one-env-per-lane kernel to rounding.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "phys_common.hpp"
+
+namespace v2p {
+
+constexpr int LPE = 32;  // lanes per environment
+
+__device__ __forceinline__ float pull(float v, int src_lane) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
+}
+__device__ __forceinline__ V3 pull(V3 v, int s) { return V3{pull(v.x, s), pull(v.y, s), pull(v.z, s)}; }
+__device__ __forceinline__ Q4 pull(Q4 q, int s) { return Q4{pull(q.x, s), pull(q.y, s), pull(q.z, s), pull(q.w, s)}; }
+__device__ __forceinline__ Sym3 pull(const Sym3& a, int s) {
+    return Sym3{pull(a.xx, s), pull(a.xy, s), pull(a.xz, s), pull(a.yy, s), pull(a.yz, s), pull(a.zz, s)};
+}
+__device__ __forceinline__ M3 pull(const M3& a, int s) {
+    M3 r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.m[i] = pull(a.m[i], s);
+    return r;
+}
+__device__ __forceinline__ V3 sel(bool c, V3 a, V3 b) { return V3{c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z}; }
+__device__ __forceinline__ Sym3 operator+(const Sym3& a, const Sym3& b) {
+    return Sym3{a.xx + b.xx, a.xy + b.xy, a.xz + b.xz, a.yy + b.yy, a.yz + b.yz, a.zz + b.zz};
+}
+__device__ __forceinline__ Sym3 mask(bool c, const Sym3& a) {
+    return Sym3{c ? a.xx : 0.f, c ? a.xy : 0.f, c ? a.xz : 0.f, c ? a.yy : 0.f, c ? a.yz : 0.f, c ? a.zz : 0.f};
+}
+__device__ __forceinline__ V3 mask(bool c, V3 a) { return V3{c ? a.x : 0.f, c ? a.y : 0.f, c ? a.z : 0.f}; }
+
+template <bool CONTACT>
+__global__ __launch_bounds__(64) void physics_ll_kernel(PhysArgs a) {
+    const int64_t N = a.n;
+    const int lane = threadIdx.x;
+    const int half = lane >> 5;
+    const int lb = lane & (LPE - 1);
+    const bool valid = lb < NB;
+    const int b = valid ? lb : 0;  // idle lanes shadow link 0 and never commit anything
+    const int base = lane & LPE;
+    int64_t e = (int64_t)blockIdx.x * 2 + half;
+    const bool live_env = e < N;
+    if (e >= N) e = N - 1;
+    ConstModel& M = *(ConstModel*)a.model;
+    float* __restrict__ st = a.state;
+    const EnvParams& P = a.p;
+    const float h = P.h;
+    const int maxd = M.max_depth;
+    const int multi = M.multi_child_levels;
+
+    // ---- per-lane model constants
+    const int par = b ? M.parents[b] : 0;
+    const int plane = base + par;
+    const int dep = valid ? M.depth[b] : 99;
+    const int c0 = M.children[b][0], c1 = M.children[b][1], c2 = M.children[b][2];
+    const bool has0 = valid && c0 >= 0, has1 = valid && c1 >= 0, has2 = valid && c2 >= 0;
+    const int cl0 = has0 ? base + c0 : lane, cl1 = has1 ? base + c1 : lane, cl2 = has2 ? base + c2 : lane;
+    const V3 lpos{M.local_pos[b][0], M.local_pos[b][1], M.local_pos[b][2]};
+    const float mass = M.mass[b];
+    const V3 com{M.com[b][0], M.com[b][1], M.com[b][2]};
+    const Sym3 Ib{M.inertia[b][0], M.inertia[b][1], M.inertia[b][2], M.inertia[b][3], M.inertia[b][4], M.inertia[b][5]};
+    const float kp = M.kp[b], kd = M.kd[b];
+    const float aug = P.aug[b];
+    const int v0 = M.hull_offsets[b], nv = M.hull_count[b];
+    const float brad = M.bound_radius[b];
+
+    // ---- state: the root lane carries the root pose/velocity, every other lane its joint
+    Q4 q{0.f, 0.f, 0.f, 1.f}, jq{0.f, 0.f, 0.f, 1.f};
+    V3 x{0.f, 0.f, 0.f}, w{0.f, 0.f, 0.f}, xd{0.f, 0.f, 0.f}, wt{0.f, 0.f, 0.f}, tar{0.f, 0.f, 0.f};
+    if (b == 0) {
+        q = Q4{st[(ST_ROOT_QUAT + 0) * N + e], st[(ST_ROOT_QUAT + 1) * N + e], st[(ST_ROOT_QUAT + 2) * N + e], st[(ST_ROOT_QUAT + 3) * N + e]};
+        x = V3{st[(ST_ROOT_POS + 0) * N + e], st[(ST_ROOT_POS + 1) * N + e], st[(ST_ROOT_POS + 2) * N + e]};
+        xd = V3{st[(ST_VEL + 0) * N + e], st[(ST_VEL + 1) * N + e], st[(ST_VEL + 2) * N + e]};
+        w = V3{st[(ST_VEL + 3) * N + e], st[(ST_VEL + 4) * N + e], st[(ST_VEL + 5) * N + e]};
+    } else {
+        const int jb = ST_JQUAT + 4 * (b - 1), vb = ST_VEL + 6 + 3 * (b - 1), cb = CT_PD + 3 * (b - 1);
+        jq = Q4{st[(jb + 0) * N + e], st[(jb + 1) * N + e], st[(jb + 2) * N + e], st[(jb + 3) * N + e]};
+        wt = V3{st[(vb + 0) * N + e], st[(vb + 1) * N + e], st[(vb + 2) * N + e]};
+        tar = V3{a.ctrl[(cb + 0) * N + e], a.ctrl[(cb + 1) * N + e], a.ctrl[(cb + 2) * N + e]};
+    }
+    const V3 extF{a.ctrl[(CT_FORCE + 0) * N + e], a.ctrl[(CT_FORCE + 1) * N + e], a.ctrl[(CT_FORCE + 2) * N + e]};
+    const V3 extT{a.ctrl[(CT_TORQUE + 0) * N + e], a.ctrl[(CT_TORQUE + 1) * N + e], a.ctrl[(CT_TORQUE + 2) * N + e]};
+
+    V3 r{0.f, 0.f, 0.f};
+    V3 cforce{0.f, 0.f, 0.f}, dofforce{0.f, 0.f, 0.f};
+
+    for (int sub = 0; sub < P.nsub; ++sub) {
+        const bool wrench_on = sub < P.hold_sub;
+        const bool last = sub == P.nsub - 1;
+        // ================================================================ pass 1: kinematics, root -> leaves by level
+        V3 zw{0.f, 0.f, 0.f}, zv{0.f, 0.f, 0.f};
+        for (int d = 1; d <= maxd; ++d) {
+            Q4 pq = pull(q, plane);
+            V3 px = pull(x, plane), pw = pull(w, plane), pxd = pull(xd, plane);
+            if (dep == d) {
+                q = qnormalize(qmul(pq, jq));
+                r = mul(q2mat(pq), lpos);
+                x = px + r;
+                V3 wrel = mul(q2mat(q), wt);
+                w = pw + wrel;
+                V3 wpr = cross(pw, r);
+                xd = pxd + wpr;
+                zw = cross(pw, wrel);
+                zv = cross(pw, wpr);
+            }
+        }
+        // ---- per link, all lanes at once: joint torque, body inertia at its origin (world axes), bias force
+        const M3 R = q2mat(q);
+        V3 tau{0.f, 0.f, 0.f};
+        if (b != 0) tau = mul(R, kp * (tar - quat_to_expmap_stable(jq)) - (kd + h * kp) * wt);
+        Sym3 A;
+        M3 B;
+        Sym3 C{mass, 0.f, 0.f, mass, 0.f, mass};
+        V3 pn, pf;
+        {
+            V3 dc = mul(R, com);
+            V3 k0 = mul(Ib, V3{R.m[0], R.m[1], R.m[2]});
+            V3 k1 = mul(Ib, V3{R.m[3], R.m[4], R.m[5]});
+            V3 k2 = mul(Ib, V3{R.m[6], R.m[7], R.m[8]});
+            V3 r0 = row(R, 0), r1 = row(R, 1), r2 = row(R, 2);
+            Sym3 Ic{dot(r0, k0), dot(r0, k1), dot(r0, k2), dot(r1, k1), dot(r1, k2), dot(r2, k2)};
+            float dd = dot(dc, dc);
+            A = Sym3{Ic.xx + mass * (dd - dc.x * dc.x), Ic.xy - mass * dc.x * dc.y, Ic.xz - mass * dc.x * dc.z,
+                     Ic.yy + mass * (dd - dc.y * dc.y), Ic.yz - mass * dc.y * dc.z, Ic.zz + mass * (dd - dc.z * dc.z)};
+            B.m[0] = 0.f;            B.m[1] = -mass * dc.z;  B.m[2] = mass * dc.y;
+            B.m[3] = mass * dc.z;    B.m[4] = 0.f;           B.m[5] = -mass * dc.x;
+            B.m[6] = -mass * dc.y;   B.m[7] = mass * dc.x;   B.m[8] = 0.f;
+            V3 wwd = cross(w, cross(w, dc));
+            pf = mass * (wwd - V3{0.f, 0.f, P.gravity_z});
+            pn = cross(w, mul(Ic, w)) + cross(dc, pf);
+            if (b == 0 && wrench_on) {
+                pn = pn - extT - cross(dc, extF);  // force acts at the root COM
+                pf = pf - extF;
+            }
+        }
+
+        // ================================================================ pass 2: articulated inertia, leaves -> root by level
+        Sym3 Di{1.f, 0.f, 0.f, 1.f, 0.f, 1.f};
+        M3 E;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) E.m[i] = 0.f;
+        V3 u{0.f, 0.f, 0.f};
+        for (int d = maxd; d >= 1; --d) {
+            Sym3 cA{0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, cC{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            M3 cB;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) cB.m[i] = 0.f;
+            V3 cn{0.f, 0.f, 0.f}, cf{0.f, 0.f, 0.f};
+            if (dep == d) {
+                Sym3 D{A.xx + aug, A.xy, A.xz, A.yy + aug, A.yz, A.zz + aug};
+                Di = inv(D);
+                E = mul(Di, B);
+                u = tau - pn;
+                Sym3 Aa{aug * (1.f - aug * Di.xx), -aug * aug * Di.xy, -aug * aug * Di.xz, aug * (1.f - aug * Di.yy), -aug * aug * Di.yz,
+                        aug * (1.f - aug * Di.zz)};
+                M3 Ba;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) Ba.m[i] = aug * E.m[i];
+                V3 b0 = col(B, 0), b1 = col(B, 1), b2 = col(B, 2), e0 = col(E, 0), e1 = col(E, 1), e2 = col(E, 2);
+                Sym3 Ca{C.xx - dot(b0, e0), C.xy - dot(b0, e1), C.xz - dot(b0, e2), C.yy - dot(b1, e1), C.yz - dot(b1, e2), C.zz - dot(b2, e2)};
+                V3 Diu = mul(Di, u);
+                V3 pan = pn + mul(Aa, zw) + mul(Ba, zv) + (u - aug * Diu);
+                V3 paf = pf + V3{dot(col(Ba, 0), zw), dot(col(Ba, 1), zw), dot(col(Ba, 2), zw)} + mul(Ca, zv) +
+                         V3{dot(e0, u), dot(e1, u), dot(e2, u)};
+                // shift to the parent origin: S = [r]x Ca (columns r x Ca_col)
+                V3 s0 = cross(r, V3{Ca.xx, Ca.xy, Ca.xz}), s1 = cross(r, V3{Ca.xy, Ca.yy, Ca.yz}), s2 = cross(r, V3{Ca.xz, Ca.yz, Ca.zz});
+                cB.m[0] = Ba.m[0] + s0.x; cB.m[1] = Ba.m[1] + s1.x; cB.m[2] = Ba.m[2] + s2.x;
+                cB.m[3] = Ba.m[3] + s0.y; cB.m[4] = Ba.m[4] + s1.y; cB.m[5] = Ba.m[5] + s2.y;
+                cB.m[6] = Ba.m[6] + s0.z; cB.m[7] = Ba.m[7] + s1.z; cB.m[8] = Ba.m[8] + s2.z;
+                V3 t10 = cross(r, row(Ba, 0)), t11 = cross(r, row(Ba, 1)), t12 = cross(r, row(Ba, 2));
+                V3 sr0{s0.x, s1.x, s2.x}, sr1{s0.y, s1.y, s2.y}, sr2{s0.z, s1.z, s2.z};
+                V3 t20 = cross(r, sr0), t21 = cross(r, sr1), t22 = cross(r, sr2);
+                cA = Sym3{Aa.xx + 2.f * t10.x + t20.x, Aa.xy + t10.y + t11.x + t20.y, Aa.xz + t10.z + t12.x + t20.z,
+                          Aa.yy + 2.f * t11.y + t21.y, Aa.yz + t11.z + t12.y + t21.z, Aa.zz + 2.f * t12.z + t22.z};
+                cC = Ca;
+                cn = pan + cross(r, paf);
+                cf = paf;
+            }
+            // parents (depth d-1) pull their children's contributions; contributions of lanes that are not at depth d are zero
+            {
+                A = A + mask(has0, pull(cA, cl0));
+                C = C + mask(has0, pull(cC, cl0));
+                M3 t = pull(cB, cl0);
+#pragma unroll
+                for (int i = 0; i < 9; ++i) B.m[i] += has0 ? t.m[i] : 0.f;
+                pn = pn + mask(has0, pull(cn, cl0));
+                pf = pf + mask(has0, pull(cf, cl0));
+            }
+            if ((multi >> d) & 1) {
+                A = A + mask(has1, pull(cA, cl1)) + mask(has2, pull(cA, cl2));
+                C = C + mask(has1, pull(cC, cl1)) + mask(has2, pull(cC, cl2));
+                M3 t1 = pull(cB, cl1), t2 = pull(cB, cl2);
+#pragma unroll
+                for (int i = 0; i < 9; ++i) B.m[i] += (has1 ? t1.m[i] : 0.f) + (has2 ? t2.m[i] : 0.f);
+                pn = pn + mask(has1, pull(cn, cl1)) + mask(has2, pull(cn, cl2));
+                pf = pf + mask(has1, pull(cf, cl1)) + mask(has2, pull(cf, cl2));
+            }
+        }
+
+        // ================================================================ root: 6x6 solve (lane 0 of each env)
+        Blocks Lam;  // operational-space inverse inertia of this lane's link (root: inverse articulated inertia)
+        Lam.A = Lam.C = Sym3{1.f, 0.f, 0.f, 1.f, 0.f, 1.f};
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Lam.B.m[i] = 0.f;
+        V3 al{0.f, 0.f, 0.f}, ac{0.f, 0.f, 0.f}, dw{0.f, 0.f, 0.f}, dv{0.f, 0.f, 0.f};
+        if (lb == 0) {
+            float a6[21], inv6[21];
+            a6[tri(0, 0)] = A.xx; a6[tri(1, 0)] = A.xy; a6[tri(2, 0)] = A.xz; a6[tri(1, 1)] = A.yy; a6[tri(2, 1)] = A.yz; a6[tri(2, 2)] = A.zz;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) a6[tri(3 + i, j)] = B.m[3 * j + i];
+            a6[tri(3, 3)] = C.xx; a6[tri(4, 3)] = C.xy; a6[tri(5, 3)] = C.xz; a6[tri(4, 4)] = C.yy; a6[tri(5, 4)] = C.yz; a6[tri(5, 5)] = C.zz;
+            spd6_inverse(a6, inv6);
+            Lam.A = Sym3{inv6[tri(0, 0)], inv6[tri(1, 0)], inv6[tri(2, 0)], inv6[tri(1, 1)], inv6[tri(2, 1)], inv6[tri(2, 2)]};
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) Lam.B.m[3 * i + j] = inv6[tri(3 + j, i)];
+            Lam.C = Sym3{inv6[tri(3, 3)], inv6[tri(4, 3)], inv6[tri(5, 3)], inv6[tri(4, 4)], inv6[tri(5, 4)], inv6[tri(5, 5)]};
+            al = -(mul(Lam.A, pn) + mul(Lam.B, pf));
+            ac = -(V3{dot(col(Lam.B, 0), pn), dot(col(Lam.B, 1), pn), dot(col(Lam.B, 2), pn)} + mul(Lam.C, pf));
+            dw = h * al;
+            dv = h * ac;
+            w = w + dw;
+            xd = xd + dv;
+        }
+
+        // ================================================================ pass 3: accelerations -> v*, root -> leaves by level
+        for (int d = 1; d <= maxd; ++d) {
+            V3 alp = pull(al, plane), acp = pull(ac, plane), dwp = pull(dw, plane), dvp = pull(dv, plane);
+            if (dep == d) {
+                V3 aw = alp + zw;
+                V3 av = acp + cross(alp, r) + zv;
+                V3 qdd = mul(Di, u + aug * aw) - aw - mul(E, av);
+                al = aw + qdd;
+                ac = av;
+                dw = dwp + h * qdd;  // v* - v_old at the OLD configuration
+                dv = dvp + cross(dwp, r);
+                w = w + dw;
+                xd = xd + dv;
+            }
+        }
+
+        int cnt = 0;
+        V3 cr[4];
+        float cbias[4];
+        V3 clam[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { cr[c] = V3{0.f, 0.f, 0.f}; cbias[c] = 0.f; clam[c] = V3{0.f, 0.f, 0.f}; }
+        if (CONTACT) {
+            // ============================================================ contact generation: every lane scans its own hull
+            const float coff = P.contact_offset;
+            const bool near = valid && (x.z - brad < coff);
+            int sel4[4] = {-1, -1, -1, -1};
+            if (__any(near)) {
+                const int nvmax = M.max_hull_count;
+                int f0 = -1, f1 = -1, f2 = -1, f3 = -1, k0 = -1;
+                float zmin = 0.f;
+                for (int i = 0; i < nvmax; ++i) {
+                    const int vi = v0 + (i < nv ? i : 0);
+                    float z = x.z + R.m[6] * M.hull_verts[vi][0] + R.m[7] * M.hull_verts[vi][1] + R.m[8] * M.hull_verts[vi][2];
+                    bool c = near && (i < nv) && (z < coff);
+                    f0 = (c && cnt == 0) ? i : f0;
+                    f1 = (c && cnt == 1) ? i : f1;
+                    f2 = (c && cnt == 2) ? i : f2;
+                    f3 = (c && cnt == 3) ? i : f3;
+                    bool better = c && (k0 < 0 || z < zmin);
+                    k0 = better ? i : k0;
+                    zmin = better ? z : zmin;
+                    cnt += c ? 1 : 0;
+                }
+                int s0 = f0, s1 = f1, s2 = f2, s3 = f3, ns = cnt < 4 ? cnt : 4;
+                if (__any(cnt > 4)) {
+                    // manifold reduction: deepest, farthest from it, extreme on either side of that line
+                    const int kk0 = v0 + (k0 < 0 ? 0 : k0);
+                    V3 u0{M.hull_verts[kk0][0], M.hull_verts[kk0][1], M.hull_verts[kk0][2]};
+                    float p0x = x.x + R.m[0] * u0.x + R.m[1] * u0.y + R.m[2] * u0.z;
+                    float p0y = x.y + R.m[3] * u0.x + R.m[4] * u0.y + R.m[5] * u0.z;
+                    int k1 = -1;
+                    float best = -1.f;
+                    for (int i = 0; i < nvmax; ++i) {
+                        const int vi = v0 + (i < nv ? i : 0);
+                        float ux = M.hull_verts[vi][0], uy = M.hull_verts[vi][1], uz = M.hull_verts[vi][2];
+                        float z = x.z + R.m[6] * ux + R.m[7] * uy + R.m[8] * uz;
+                        float dx = x.x + R.m[0] * ux + R.m[1] * uy + R.m[2] * uz - p0x;
+                        float dy = x.y + R.m[3] * ux + R.m[4] * uy + R.m[5] * uz - p0y;
+                        float d2 = dx * dx + dy * dy;
+                        bool take = (i < nv) && (z < coff) && (i != k0) && (d2 > best);
+                        best = take ? d2 : best;
+                        k1 = take ? i : k1;
+                    }
+                    const int kk1 = v0 + (k1 < 0 ? 0 : k1);
+                    V3 u1{M.hull_verts[kk1][0], M.hull_verts[kk1][1], M.hull_verts[kk1][2]};
+                    float ex = x.x + R.m[0] * u1.x + R.m[1] * u1.y + R.m[2] * u1.z - p0x;
+                    float ey = x.y + R.m[3] * u1.x + R.m[4] * u1.y + R.m[5] * u1.z - p0y;
+                    int k2 = -1, k3 = -1;
+                    float amax = 0.f, amin = 0.f;
+                    for (int i = 0; i < nvmax; ++i) {
+                        const int vi = v0 + (i < nv ? i : 0);
+                        float ux = M.hull_verts[vi][0], uy = M.hull_verts[vi][1], uz = M.hull_verts[vi][2];
+                        float z = x.z + R.m[6] * ux + R.m[7] * uy + R.m[8] * uz;
+                        float dx = x.x + R.m[0] * ux + R.m[1] * uy + R.m[2] * uz - p0x;
+                        float dy = x.y + R.m[3] * ux + R.m[4] * uy + R.m[5] * uz - p0y;
+                        float area = ex * dy - ey * dx;
+                        bool cand = (i < nv) && (z < coff) && (i != k0) && (i != k1);
+                        bool up = cand && area > amax;
+                        bool dn = cand && area < amin;
+                        amax = up ? area : amax; k2 = up ? i : k2;
+                        amin = dn ? area : amin; k3 = dn ? i : k3;
+                    }
+                    if (cnt > 4) {
+                        s0 = k0; s1 = k1;
+                        s2 = k2 >= 0 ? k2 : k3;
+                        s3 = k2 >= 0 ? k3 : -1;
+                        ns = 2 + (k2 >= 0 ? 1 : 0) + (k3 >= 0 ? 1 : 0);
+                    }
+                }
+                cnt = ns;
+                sel4[0] = s0; sel4[1] = s1; sel4[2] = s2; sel4[3] = s3;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int vi = v0 + (sel4[c] < 0 ? 0 : sel4[c]);
+                    cr[c] = mul(R, V3{M.hull_verts[vi][0], M.hull_verts[vi][1], M.hull_verts[vi][2]});
+                    float dz = x.z + cr[c].z;
+                    cbias[c] = dz >= 0.f ? dz / h : fmaxf(P.erp * dz / h, -P.max_depen);
+                }
+            }
+            if (valid && live_env) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) a.contact_ids[(e * NB + b) * 4 + c] = c < cnt ? b * 64 + sel4[c] : -1;
+            }
+
+            const unsigned long long tb = __ballot(valid && cnt > 0);
+            const unsigned m0 = (unsigned)tb, m1 = (unsigned)(tb >> 32);
+            if ((m0 | m1) && P.n_iter > 0) {
+                // ======================================================== Lambda_b, root -> leaves by level
+                for (int d = 1; d <= maxd; ++d) {
+                    Blocks Lp;
+                    Lp.A = pull(Lam.A, plane);
+                    Lp.B = pull(Lam.B, plane);
+                    Lp.C = pull(Lam.C, plane);
+                    if (dep == d) {
+                        // G = X Lp X^T: Ga = La ; Gb = La [r]x + Lb ; Gc = Lc - [r]x Lb + Gb^T [r]x
+                        V3 la0{Lp.A.xx, Lp.A.xy, Lp.A.xz}, la1{Lp.A.xy, Lp.A.yy, Lp.A.yz}, la2{Lp.A.xz, Lp.A.yz, Lp.A.zz};
+                        M3 Gb;
+                        {
+                            V3 g0 = cross(la0, r) + row(Lp.B, 0), g1 = cross(la1, r) + row(Lp.B, 1), g2 = cross(la2, r) + row(Lp.B, 2);
+                            Gb.m[0] = g0.x; Gb.m[1] = g0.y; Gb.m[2] = g0.z; Gb.m[3] = g1.x; Gb.m[4] = g1.y; Gb.m[5] = g1.z; Gb.m[6] = g2.x; Gb.m[7] = g2.y; Gb.m[8] = g2.z;
+                        }
+                        Sym3 Gc;
+                        {
+                            V3 q0 = cross(col(Gb, 0), r), q1 = cross(col(Gb, 1), r), q2 = cross(col(Gb, 2), r);
+                            V3 n0 = cross(r, col(Lp.B, 0)), n1 = cross(r, col(Lp.B, 1)), n2 = cross(r, col(Lp.B, 2));
+                            Gc.xx = Lp.C.xx + q0.x - n0.x;
+                            Gc.xy = Lp.C.xy + q0.y - n1.x;
+                            Gc.xz = Lp.C.xz + q0.z - n2.x;
+                            Gc.yy = Lp.C.yy + q1.y - n1.y;
+                            Gc.yz = Lp.C.yz + q1.z - n2.y;
+                            Gc.zz = Lp.C.zz + q2.z - n2.z;
+                        }
+                        // Lambda_b = [Di 0; 0 0] + T^T G T,  T = [aug Di, 0; -E^T, 1]
+                        M3 DiM;
+                        DiM.m[0] = Di.xx; DiM.m[1] = Di.xy; DiM.m[2] = Di.xz; DiM.m[3] = Di.xy; DiM.m[4] = Di.yy; DiM.m[5] = Di.yz; DiM.m[6] = Di.xz; DiM.m[7] = Di.yz; DiM.m[8] = Di.zz;
+                        M3 H1, H2;
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+                            V3 gai = i == 0 ? la0 : (i == 1 ? la1 : la2);
+                            V3 gbi = row(Gb, i);
+                            V3 gbti = col(Gb, i);
+                            V3 gci = i == 0 ? V3{Gc.xx, Gc.xy, Gc.xz} : (i == 1 ? V3{Gc.xy, Gc.yy, Gc.yz} : V3{Gc.xz, Gc.yz, Gc.zz});
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) {
+                                V3 dj = col(DiM, j);
+                                V3 ej = row(E, j);
+                                H1.m[3 * i + j] = aug * dot(gai, dj) - dot(gbi, ej);
+                                H2.m[3 * i + j] = aug * dot(gbti, dj) - dot(gci, ej);
+                            }
+                        }
+                        M3 t;
+#pragma unroll
+                        for (int i = 0; i < 3; ++i)
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) t.m[3 * i + j] = aug * dot(row(DiM, i), col(H1, j)) - dot(row(E, i), col(H2, j));
+                        Lam.A = Sym3{Di.xx + t.m[0], Di.xy + 0.5f * (t.m[1] + t.m[3]), Di.xz + 0.5f * (t.m[2] + t.m[6]), Di.yy + t.m[4],
+                                     Di.yz + 0.5f * (t.m[5] + t.m[7]), Di.zz + t.m[8]};
+#pragma unroll
+                        for (int i = 0; i < 3; ++i)
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) {
+                                V3 gcj = j == 0 ? V3{Gc.xx, Gc.xy, Gc.xz} : (j == 1 ? V3{Gc.xy, Gc.yy, Gc.yz} : V3{Gc.xz, Gc.yz, Gc.zz});
+                                Lam.B.m[3 * i + j] = aug * dot(row(DiM, i), col(Gb, j)) - dot(row(E, i), gcj);
+                            }
+                        Lam.C = Gc;
+                    }
+                }
+
+                // ======================================================== block Gauss-Seidel: k-th touched body of each env at once
+                for (int it = 0; it < P.n_iter; ++it) {
+                    unsigned t0 = m0, t1 = m1;
+                    while (t0 | t1) {
+                        const int b0 = t0 ? __ffs(t0) - 1 : -1, b1 = t1 ? __ffs(t1) - 1 : -1;
+                        t0 &= t0 - 1;
+                        t1 &= t1 - 1;
+                        const int am0 = b0 >= 0 ? M.anc_mask[b0] : 0, am1 = b1 >= 0 ? M.anc_mask[b1] : 0;
+                        const int bsel = half ? b1 : b0;
+                        const int amask = half ? am1 : am0;
+                        const bool me = valid && (lb == bsel);
+                        const bool onpath = valid && ((amask >> lb) & 1);
+                        V3 un{0.f, 0.f, 0.f}, uf{0.f, 0.f, 0.f};
+                        if (me) {
+                            V3 wl = w, xl = xd;
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const bool active = c < cnt;
+                                V3 rr = cr[c];
+                                float ln = clam[c].x, l1 = clam[c].y, l2 = clam[c].z;
+#pragma unroll
+                                for (int ax = 0; ax < 3; ++ax) {
+                                    V3 dir = ax == 0 ? V3{0.f, 0.f, 1.f} : (ax == 1 ? V3{1.f, 0.f, 0.f} : V3{0.f, 1.f, 0.f});
+                                    V3 jn = cross(rr, dir);
+                                    V3 yw = mul(Lam.A, jn) + mul(Lam.B, dir);
+                                    V3 yv = V3{dot(col(Lam.B, 0), jn), dot(col(Lam.B, 1), jn), dot(col(Lam.B, 2), jn)} + mul(Lam.C, dir);
+                                    float wii = dot(jn, yw) + dot(dir, yv);
+                                    float rel = dot(jn, wl) + dot(dir, xl) + (ax == 0 ? cbias[c] : 0.f);
+                                    float old = ax == 0 ? ln : (ax == 1 ? l1 : l2);
+                                    float nl = old - rel * __builtin_amdgcn_rcpf(wii);
+                                    if (ax == 0) nl = fmaxf(nl, 0.f);
+                                    else { float lim = P.mu * ln; nl = fminf(fmaxf(nl, -lim), lim); }
+                                    float dl = active ? nl - old : 0.f;
+                                    if (ax == 0) ln += dl; else if (ax == 1) l1 += dl; else l2 += dl;
+                                    wl = wl + dl * yw;
+                                    xl = xl + dl * yv;
+                                    un = un + dl * jn;
+                                    uf = uf + dl * dir;
+                                }
+                                clam[c] = V3{ln, l1, l2};
+                            }
+                        }
+                        // ---- net impulse (un, uf) at the touched link: leaf -> root along the path, level by level
+                        V3 du{0.f, 0.f, 0.f};
+                        for (int d = maxd; d >= 1; --d) {
+                            V3 cn{0.f, 0.f, 0.f}, cf{0.f, 0.f, 0.f};
+                            if (dep == d && onpath) {
+                                du = un;
+                                V3 na = aug * mul(Di, un);
+                                V3 fa = uf - V3{dot(col(E, 0), un), dot(col(E, 1), un), dot(col(E, 2), un)};
+                                cn = na + cross(r, fa);
+                                cf = fa;
+                            }
+                            un = un + mask(has0, pull(cn, cl0));
+                            uf = uf + mask(has0, pull(cf, cl0));
+                            if ((multi >> d) & 1) {
+                                un = un + mask(has1, pull(cn, cl1)) + mask(has2, pull(cn, cl2));
+                                uf = uf + mask(has1, pull(cf, cl1)) + mask(has2, pull(cf, cl2));
+                            }
+                        }
+                        // root response, then root -> leaves: every link moves
+                        V3 ddw{0.f, 0.f, 0.f}, ddv{0.f, 0.f, 0.f};
+                        if (lb == 0) {
+                            ddw = mul(Lam.A, un) + mul(Lam.B, uf);
+                            ddv = V3{dot(col(Lam.B, 0), un), dot(col(Lam.B, 1), un), dot(col(Lam.B, 2), un)} + mul(Lam.C, uf);
+                            w = w + ddw;
+                            xd = xd + ddv;
+                        }
+                        for (int d = 1; d <= maxd; ++d) {
+                            V3 pdw = pull(ddw, plane), pdv = pull(ddv, plane);
+                            if (dep == d) {
+                                V3 av = pdv + cross(pdw, r);
+                                ddw = mul(Di, aug * pdw + du) - mul(E, av);
+                                ddv = av;
+                                w = w + ddw;
+                                xd = xd + ddv;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+
+        // ================================================================ velocities -> generalized, damping, clamp, integrate
+        const float sc = 1.f / (1.f + h * P.ang_damp);
+        const float wmax = P.max_ang_vel;
+        {
+            Q4 pq = pull(q, plane);
+            V3 pw = pull(w, plane);
+            if (b != 0) {
+                V3 wn = mulT(R, w - pw);               // joint rate, body axes (undamped)
+                Q4 jold = qnormalize(qmul(qconj(pq), q));  // joint quaternion of the old configuration
+                if (last) dofforce = kp * (tar - quat_to_expmap_stable(jold) - h * wn) - kd * wn;
+                wn = sc * wn;
+                float n2 = dot(wn, wn);
+                if (n2 > wmax * wmax) wn = (wmax * rsqrtf(n2)) * wn;
+                wt = wn;
+                jq = qnormalize(qmul(jold, rotvec_to_quat(h * wn)));  // body-frame rate: right multiply
+            } else {
+                V3 w0 = sc * w;
+                float n2 = dot(w0, w0);
+                if (n2 > wmax * wmax) w0 = (wmax * rsqrtf(n2)) * w0;
+                w = w0;
+                x = x + h * xd;
+                q = qnormalize(qmul(rotvec_to_quat(h * w0), q));  // world-frame rate: left multiply
+            }
+        }
+        if (CONTACT && last) {
+            const float ih = 1.f / h;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < cnt) { cforce.z += clam[c].x * ih; cforce.x += clam[c].y * ih; cforce.y += clam[c].z * ih; }
+        }
+    }
+
+    // ==================================================================== final kinematics -> state, rigid-body state, dof_pos
+    for (int d = 1; d <= maxd; ++d) {
+        Q4 pq = pull(q, plane);
+        V3 px = pull(x, plane), pw = pull(w, plane), pxd = pull(xd, plane);
+        if (dep == d) {
+            q = qnormalize(qmul(pq, jq));
+            V3 rr = mul(q2mat(pq), lpos);
+            x = px + rr;
+            w = pw + mul(q2mat(q), wt);
+            xd = pxd + cross(pw, rr);
+        }
+    }
+    if (valid && live_env) {
+        if (b == 0) {
+            st[(ST_ROOT_QUAT + 0) * N + e] = q.x; st[(ST_ROOT_QUAT + 1) * N + e] = q.y; st[(ST_ROOT_QUAT + 2) * N + e] = q.z; st[(ST_ROOT_QUAT + 3) * N + e] = q.w;
+            st[(ST_ROOT_POS + 0) * N + e] = x.x; st[(ST_ROOT_POS + 1) * N + e] = x.y; st[(ST_ROOT_POS + 2) * N + e] = x.z;
+            st[(ST_VEL + 0) * N + e] = xd.x; st[(ST_VEL + 1) * N + e] = xd.y; st[(ST_VEL + 2) * N + e] = xd.z;
+            st[(ST_VEL + 3) * N + e] = w.x; st[(ST_VEL + 4) * N + e] = w.y; st[(ST_VEL + 5) * N + e] = w.z;
+        } else {
+            const int jb = ST_JQUAT + 4 * (b - 1), vb = ST_VEL + 6 + 3 * (b - 1);
+            st[(jb + 0) * N + e] = jq.x; st[(jb + 1) * N + e] = jq.y; st[(jb + 2) * N + e] = jq.z; st[(jb + 3) * N + e] = jq.w;
+            st[(vb + 0) * N + e] = wt.x; st[(vb + 1) * N + e] = wt.y; st[(vb + 2) * N + e] = wt.z;
+            V3 qe = quat_to_expmap_stable(jq);
+            const int op = OUT_DOF_POS + 3 * (b - 1), of = OUT_DOF_FORCE + 3 * (b - 1);
+            a.out[(op + 0) * N + e] = qe.x; a.out[(op + 1) * N + e] = qe.y; a.out[(op + 2) * N + e] = qe.z;
+            a.out[(of + 0) * N + e] = dofforce.x; a.out[(of + 1) * N + e] = dofforce.y; a.out[(of + 2) * N + e] = dofforce.z;
+        }
+        const int ob = OUT_RB + 13 * b;
+        a.out[(ob + 0) * N + e] = x.x; a.out[(ob + 1) * N + e] = x.y; a.out[(ob + 2) * N + e] = x.z;
+        a.out[(ob + 3) * N + e] = q.x; a.out[(ob + 4) * N + e] = q.y; a.out[(ob + 5) * N + e] = q.z; a.out[(ob + 6) * N + e] = q.w;
+        a.out[(ob + 7) * N + e] = xd.x; a.out[(ob + 8) * N + e] = xd.y; a.out[(ob + 9) * N + e] = xd.z;
+        a.out[(ob + 10) * N + e] = w.x; a.out[(ob + 11) * N + e] = w.y; a.out[(ob + 12) * N + e] = w.z;
+        a.out[(OUT_CONTACT + 3 * b + 0) * N + e] = cforce.x;
+        a.out[(OUT_CONTACT + 3 * b + 1) * N + e] = cforce.y;
+        a.out[(OUT_CONTACT + 3 * b + 2) * N + e] = cforce.z;
+    }
+}
+
+int launch_env_physics_ll(v2p_env* env, hipStream_t s) {
+    PhysArgs a = {};
+    a.model = env->model->dev;
+    a.state = env->state;
+    a.ctrl = env->ctrl;
+    a.out = env->out;
+    a.ws = env->ws;
+    a.contact_ids = env->contact_ids;
+    a.prof = nullptr;
+    a.n = env->n;
+    a.p = env->p;
+    unsigned blocks = (unsigned)((env->n + 1) / 2);
+    if (env->p.enable_contact)
+        hipLaunchKernelGGL(physics_ll_kernel<true>, dim3(blocks), dim3(64), 0, s, a);
+    else
+        hipLaunchKernelGGL(physics_ll_kernel<false>, dim3(blocks), dim3(64), 0, s, a);
+    return check_hip(hipGetLastError(), "physics_ll_kernel");
+}
+
+}  // namespace v2p

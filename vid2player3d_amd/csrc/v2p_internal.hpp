@@ -27,6 +27,11 @@ struct DevModel {
     int32_t parents[NB];
     int32_t depth[NB];
     int32_t order[NB];     // links in level (breadth-first) order: consecutive entries never depend on each other's results
+    int32_t children[NB][3];  // up to 3 children per link, -1 = none (lane = link kernel)
+    int32_t anc_mask[NB];     // bit i set when link i is an ancestor of (or is) the link
+    int32_t max_depth;
+    int32_t multi_child_levels;  // bit d set when some link at depth d-1 has more than one child
+    int32_t max_hull_count;
     int32_t lam_slot[NB];  // index into the saved-Lambda register sets for branching links (root = 0), -1 otherwise
     float local_pos[NB][3];
     float mass[NB];
@@ -127,6 +132,7 @@ int launch_obs_imitation(int64_t n, const float* body_pos, const float* body_rot
 int launch_env_reset(v2p_env* e, const int64_t* env_ids, int64_t n, const float* motion_times, hipStream_t s);
 int launch_env_pre(v2p_env* e, float* actions, hipStream_t s);
 int launch_env_physics(v2p_env* e, hipStream_t s);
+int launch_env_physics_ll(v2p_env* e, hipStream_t s);
 int launch_env_export(v2p_env* e, hipStream_t s);
 int launch_env_post(v2p_env* e, hipStream_t s);
 int launch_env_push_state(v2p_env* e, const int64_t* env_ids, int64_t n, int with_rb, hipStream_t s);
