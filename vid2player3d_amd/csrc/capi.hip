@@ -111,6 +111,7 @@ int v2p_model_create(const v2p_model_desc* d, int device, v2p_model** out) {
         int nch[NB] = {0};
         h.max_depth = 0;
         h.multi_child_levels = 0;
+        h.nonchain_levels = 0;
         h.max_hull_count = 0;
         for (int b = 0; b < NB; ++b) {
             for (int k = 0; k < 3; ++k) h.children[b][k] = -1;
@@ -124,7 +125,14 @@ int v2p_model_create(const v2p_model_desc* d, int device, v2p_model** out) {
             h.children[p][nch[p]++] = b;
             if (nch[p] > 1) h.multi_child_levels |= 1 << h.depth[b];
             h.anc_mask[b] |= h.anc_mask[p];
+            if (p != b - 1) h.nonchain_levels |= 1 << h.depth[b];
+            if (h.children[p][0] != p + 1) { set_error("v2p_model_create: links must be in depth-first order (first child of %d is %d)", p, h.children[p][0]); delete m; return V2P_ERR_UNSUPPORTED; }
         }
+    }
+    for (int b = 0; b < NB; ++b) {
+        h.desc_mask[b] = 0;
+        for (int j = 0; j < NB; ++j)
+            if ((h.anc_mask[j] >> b) & 1) h.desc_mask[b] |= 1 << j;
     }
     {
         int nchild[NB] = {0}, nslot = 1;

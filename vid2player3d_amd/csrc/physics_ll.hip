@@ -38,6 +38,40 @@ __device__ __forceinline__ M3 pull(const M3& a, int s) {
     for (int i = 0; i < 9; ++i) r.m[i] = pull(a.m[i], s);
     return r;
 }
+// lane i <- lane i-1 / lane i+1 through the DPP network (VALU speed, no LDS round trip); links are in depth-first order,
+// so the parent of a chain link is the previous lane and the first child of any link is the next lane
+__device__ __forceinline__ float from_prev(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false)); }
+__device__ __forceinline__ float from_next(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false)); }
+__device__ __forceinline__ V3 from_next(V3 v) { return V3{from_next(v.x), from_next(v.y), from_next(v.z)}; }
+__device__ __forceinline__ Sym3 from_next(const Sym3& a) {
+    return Sym3{from_next(a.xx), from_next(a.xy), from_next(a.xz), from_next(a.yy), from_next(a.yz), from_next(a.zz)};
+}
+__device__ __forceinline__ M3 from_next(const M3& a) {
+    M3 r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.m[i] = from_next(a.m[i]);
+    return r;
+}
+// value of the parent lane: DPP for chain links, ds_bpermute only on the levels that have a link whose parent is not the previous lane
+struct ParentPull {
+    int plane;
+    bool chain;
+    __device__ __forceinline__ float operator()(float v, bool lvl_nonchain) const {
+        (void)lvl_nonchain;
+        return pull(v, plane);
+    }
+    __device__ __forceinline__ V3 operator()(V3 v, bool l) const { return V3{(*this)(v.x, l), (*this)(v.y, l), (*this)(v.z, l)}; }
+    __device__ __forceinline__ Q4 operator()(Q4 q, bool l) const { return Q4{(*this)(q.x, l), (*this)(q.y, l), (*this)(q.z, l), (*this)(q.w, l)}; }
+    __device__ __forceinline__ Sym3 operator()(const Sym3& a, bool l) const {
+        return Sym3{(*this)(a.xx, l), (*this)(a.xy, l), (*this)(a.xz, l), (*this)(a.yy, l), (*this)(a.yz, l), (*this)(a.zz, l)};
+    }
+    __device__ __forceinline__ M3 operator()(const M3& a, bool l) const {
+        M3 r;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) r.m[i] = (*this)(a.m[i], l);
+        return r;
+    }
+};
 __device__ __forceinline__ V3 sel(bool c, V3 a, V3 b) { return V3{c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z}; }
 __device__ __forceinline__ Sym3 operator+(const Sym3& a, const Sym3& b) {
     return Sym3{a.xx + b.xx, a.xy + b.xy, a.xz + b.xz, a.yy + b.yy, a.yz + b.yz, a.zz + b.zz};
@@ -46,6 +80,9 @@ __device__ __forceinline__ Sym3 mask(bool c, const Sym3& a) {
     return Sym3{c ? a.xx : 0.f, c ? a.xy : 0.f, c ? a.xz : 0.f, c ? a.yy : 0.f, c ? a.yz : 0.f, c ? a.zz : 0.f};
 }
 __device__ __forceinline__ V3 mask(bool c, V3 a) { return V3{c ? a.x : 0.f, c ? a.y : 0.f, c ? a.z : 0.f}; }
+
+#define LLSUB(k) do { if (a.prof) { long long t_ = clock64(); if (blockIdx.x == 0 && lane == 0) atomicAdd((unsigned long long*)&a.prof[k], (unsigned long long)(t_ - tsub)); tsub = t_; } } while (0)
+#define LLPH(k) do { if (a.prof) { long long t_ = clock64(); if (blockIdx.x == 0 && lane == 0) atomicAdd((unsigned long long*)&a.prof[k], (unsigned long long)(t_ - tprev)); tprev = t_; } } while (0)
 
 template <bool CONTACT>
 __global__ __launch_bounds__(64) void physics_ll_kernel(PhysArgs a) {
@@ -65,10 +102,20 @@ __global__ __launch_bounds__(64) void physics_ll_kernel(PhysArgs a) {
     const float h = P.h;
     const int maxd = M.max_depth;
     const int multi = M.multi_child_levels;
+    const int nonchain = M.nonchain_levels;
+
+    // ---- hull vertices of the (lane-uniform) body model -> LDS, padded to float4: per-lane gathers in contact generation
+    __shared__ float4 hv[MAX_HULL_VERTS];
+    if (CONTACT) {
+        const int nhv = M.hull_offsets[NB];
+        for (int i = lane; i < nhv; i += 64) hv[i] = make_float4(M.hull_verts[i][0], M.hull_verts[i][1], M.hull_verts[i][2], 0.f);
+        __syncthreads();
+    }
 
     // ---- per-lane model constants
     const int par = b ? M.parents[b] : 0;
     const int plane = base + par;
+    const ParentPull pp{plane, par == b - 1};
     const int dep = valid ? M.depth[b] : 99;
     const int c0 = M.children[b][0], c1 = M.children[b][1], c2 = M.children[b][2];
     const bool has0 = valid && c0 >= 0, has1 = valid && c1 >= 0, has2 = valid && c2 >= 0;
@@ -81,6 +128,7 @@ __global__ __launch_bounds__(64) void physics_ll_kernel(PhysArgs a) {
     const float aug = P.aug[b];
     const int v0 = M.hull_offsets[b], nv = M.hull_count[b];
     const float brad = M.bound_radius[b];
+    const int desc = M.desc_mask[b];  // links of the subtree rooted here (self included)
 
     // ---- state: the root lane carries the root pose/velocity, every other lane its joint
     Q4 q{0.f, 0.f, 0.f, 1.f}, jq{0.f, 0.f, 0.f, 1.f};
@@ -99,17 +147,20 @@ __global__ __launch_bounds__(64) void physics_ll_kernel(PhysArgs a) {
     const V3 extF{a.ctrl[(CT_FORCE + 0) * N + e], a.ctrl[(CT_FORCE + 1) * N + e], a.ctrl[(CT_FORCE + 2) * N + e]};
     const V3 extT{a.ctrl[(CT_TORQUE + 0) * N + e], a.ctrl[(CT_TORQUE + 1) * N + e], a.ctrl[(CT_TORQUE + 2) * N + e]};
 
+    long long tprev = a.prof ? clock64() : 0;
     V3 r{0.f, 0.f, 0.f};
     V3 cforce{0.f, 0.f, 0.f}, dofforce{0.f, 0.f, 0.f};
 
     for (int sub = 0; sub < P.nsub; ++sub) {
         const bool wrench_on = sub < P.hold_sub;
         const bool last = sub == P.nsub - 1;
+        LLPH(0);
         // ================================================================ pass 1: kinematics, root -> leaves by level
         V3 zw{0.f, 0.f, 0.f}, zv{0.f, 0.f, 0.f};
         for (int d = 1; d <= maxd; ++d) {
-            Q4 pq = pull(q, plane);
-            V3 px = pull(x, plane), pw = pull(w, plane), pxd = pull(xd, plane);
+            const bool nc = (nonchain >> d) & 1;
+            Q4 pq = pp(q, nc);
+            V3 px = pp(x, nc), pw = pp(w, nc), pxd = pp(xd, nc);
             if (dep == d) {
                 q = qnormalize(qmul(pq, jq));
                 r = mul(q2mat(pq), lpos);
@@ -152,6 +203,7 @@ __global__ __launch_bounds__(64) void physics_ll_kernel(PhysArgs a) {
             }
         }
 
+        LLPH(1);
         // ================================================================ pass 2: articulated inertia, leaves -> root by level
         Sym3 Di{1.f, 0.f, 0.f, 1.f, 0.f, 1.f};
         M3 E;
@@ -196,13 +248,13 @@ __global__ __launch_bounds__(64) void physics_ll_kernel(PhysArgs a) {
             }
             // parents (depth d-1) pull their children's contributions; contributions of lanes that are not at depth d are zero
             {
-                A = A + mask(has0, pull(cA, cl0));
-                C = C + mask(has0, pull(cC, cl0));
-                M3 t = pull(cB, cl0);
+                A = A + mask(has0, from_next(cA));
+                C = C + mask(has0, from_next(cC));
+                M3 t = from_next(cB);
 #pragma unroll
                 for (int i = 0; i < 9; ++i) B.m[i] += has0 ? t.m[i] : 0.f;
-                pn = pn + mask(has0, pull(cn, cl0));
-                pf = pf + mask(has0, pull(cf, cl0));
+                pn = pn + mask(has0, from_next(cn));
+                pf = pf + mask(has0, from_next(cf));
             }
             if ((multi >> d) & 1) {
                 A = A + mask(has1, pull(cA, cl1)) + mask(has2, pull(cA, cl2));
@@ -215,6 +267,7 @@ __global__ __launch_bounds__(64) void physics_ll_kernel(PhysArgs a) {
             }
         }
 
+        LLPH(2);
         // ================================================================ root: 6x6 solve (lane 0 of each env)
         Blocks Lam;  // operational-space inverse inertia of this lane's link (root: inverse articulated inertia)
         Lam.A = Lam.C = Sym3{1.f, 0.f, 0.f, 1.f, 0.f, 1.f};
@@ -246,7 +299,8 @@ __global__ __launch_bounds__(64) void physics_ll_kernel(PhysArgs a) {
 
         // ================================================================ pass 3: accelerations -> v*, root -> leaves by level
         for (int d = 1; d <= maxd; ++d) {
-            V3 alp = pull(al, plane), acp = pull(ac, plane), dwp = pull(dw, plane), dvp = pull(dv, plane);
+            const bool nc = (nonchain >> d) & 1;
+            V3 alp = pp(al, nc), acp = pp(ac, nc), dwp = pp(dw, nc), dvp = pp(dv, nc);
             if (dep == d) {
                 V3 aw = alp + zw;
                 V3 av = acp + cross(alp, r) + zv;
@@ -260,6 +314,7 @@ __global__ __launch_bounds__(64) void physics_ll_kernel(PhysArgs a) {
             }
         }
 
+        LLPH(3);
         int cnt = 0;
         V3 cr[4];
         float cbias[4];
@@ -268,66 +323,75 @@ __global__ __launch_bounds__(64) void physics_ll_kernel(PhysArgs a) {
         for (int c = 0; c < 4; ++c) { cr[c] = V3{0.f, 0.f, 0.f}; cbias[c] = 0.f; clam[c] = V3{0.f, 0.f, 0.f}; }
         if (CONTACT) {
             // ============================================================ contact generation: every lane scans its own hull
+            // pass A marks the candidate vertices (z < contact_offset) in a per-lane 64-bit mask; the manifold reduction then
+            // walks only the candidates.  Hull vertices come from the LDS copy of the model (staged once per launch).
             const float coff = P.contact_offset;
             const bool near = valid && (x.z - brad < coff);
             int sel4[4] = {-1, -1, -1, -1};
             if (__any(near)) {
                 const int nvmax = M.max_hull_count;
-                int f0 = -1, f1 = -1, f2 = -1, f3 = -1, k0 = -1;
+                unsigned long long cm = 0ull;
+                int k0 = -1;
                 float zmin = 0.f;
+#pragma unroll 4
                 for (int i = 0; i < nvmax; ++i) {
-                    const int vi = v0 + (i < nv ? i : 0);
-                    float z = x.z + R.m[6] * M.hull_verts[vi][0] + R.m[7] * M.hull_verts[vi][1] + R.m[8] * M.hull_verts[vi][2];
+                    const float4 hvv = hv[v0 + (i < nv ? i : 0)];
+                    float z = x.z + R.m[6] * hvv.x + R.m[7] * hvv.y + R.m[8] * hvv.z;
                     bool c = near && (i < nv) && (z < coff);
-                    f0 = (c && cnt == 0) ? i : f0;
-                    f1 = (c && cnt == 1) ? i : f1;
-                    f2 = (c && cnt == 2) ? i : f2;
-                    f3 = (c && cnt == 3) ? i : f3;
+                    cm |= (unsigned long long)(c ? 1u : 0u) << i;
                     bool better = c && (k0 < 0 || z < zmin);
                     k0 = better ? i : k0;
                     zmin = better ? z : zmin;
-                    cnt += c ? 1 : 0;
                 }
-                int s0 = f0, s1 = f1, s2 = f2, s3 = f3, ns = cnt < 4 ? cnt : 4;
+                cnt = __popcll(cm);
+                // the first four candidates in index order
+                unsigned long long t = cm;
+                int s0 = t ? __ffsll((long long)t) - 1 : -1; t &= t - 1;
+                int s1 = t ? __ffsll((long long)t) - 1 : -1; t &= t - 1;
+                int s2 = t ? __ffsll((long long)t) - 1 : -1; t &= t - 1;
+                int s3 = t ? __ffsll((long long)t) - 1 : -1;
+                int ns = cnt < 4 ? cnt : 4;
                 if (__any(cnt > 4)) {
                     // manifold reduction: deepest, farthest from it, extreme on either side of that line
-                    const int kk0 = v0 + (k0 < 0 ? 0 : k0);
-                    V3 u0{M.hull_verts[kk0][0], M.hull_verts[kk0][1], M.hull_verts[kk0][2]};
+                    const bool big = cnt > 4;
+                    const float4 u0 = hv[v0 + (k0 < 0 ? 0 : k0)];
                     float p0x = x.x + R.m[0] * u0.x + R.m[1] * u0.y + R.m[2] * u0.z;
                     float p0y = x.y + R.m[3] * u0.x + R.m[4] * u0.y + R.m[5] * u0.z;
                     int k1 = -1;
                     float best = -1.f;
-                    for (int i = 0; i < nvmax; ++i) {
-                        const int vi = v0 + (i < nv ? i : 0);
-                        float ux = M.hull_verts[vi][0], uy = M.hull_verts[vi][1], uz = M.hull_verts[vi][2];
-                        float z = x.z + R.m[6] * ux + R.m[7] * uy + R.m[8] * uz;
-                        float dx = x.x + R.m[0] * ux + R.m[1] * uy + R.m[2] * uz - p0x;
-                        float dy = x.y + R.m[3] * ux + R.m[4] * uy + R.m[5] * uz - p0y;
+                    unsigned long long rem = big ? (cm & ~(1ull << (k0 < 0 ? 0 : k0))) : 0ull;
+                    while (__any(rem != 0ull)) {
+                        const bool on = rem != 0ull;
+                        const int i = on ? __ffsll((long long)rem) - 1 : 0;
+                        rem &= rem - 1;
+                        const float4 uu = hv[v0 + i];
+                        float dx = x.x + R.m[0] * uu.x + R.m[1] * uu.y + R.m[2] * uu.z - p0x;
+                        float dy = x.y + R.m[3] * uu.x + R.m[4] * uu.y + R.m[5] * uu.z - p0y;
                         float d2 = dx * dx + dy * dy;
-                        bool take = (i < nv) && (z < coff) && (i != k0) && (d2 > best);
+                        bool take = on && (d2 > best);
                         best = take ? d2 : best;
                         k1 = take ? i : k1;
                     }
-                    const int kk1 = v0 + (k1 < 0 ? 0 : k1);
-                    V3 u1{M.hull_verts[kk1][0], M.hull_verts[kk1][1], M.hull_verts[kk1][2]};
+                    const float4 u1 = hv[v0 + (k1 < 0 ? 0 : k1)];
                     float ex = x.x + R.m[0] * u1.x + R.m[1] * u1.y + R.m[2] * u1.z - p0x;
                     float ey = x.y + R.m[3] * u1.x + R.m[4] * u1.y + R.m[5] * u1.z - p0y;
                     int k2 = -1, k3 = -1;
                     float amax = 0.f, amin = 0.f;
-                    for (int i = 0; i < nvmax; ++i) {
-                        const int vi = v0 + (i < nv ? i : 0);
-                        float ux = M.hull_verts[vi][0], uy = M.hull_verts[vi][1], uz = M.hull_verts[vi][2];
-                        float z = x.z + R.m[6] * ux + R.m[7] * uy + R.m[8] * uz;
-                        float dx = x.x + R.m[0] * ux + R.m[1] * uy + R.m[2] * uz - p0x;
-                        float dy = x.y + R.m[3] * ux + R.m[4] * uy + R.m[5] * uz - p0y;
+                    rem = big ? (cm & ~(1ull << (k0 < 0 ? 0 : k0)) & ~(1ull << (k1 < 0 ? 0 : k1))) : 0ull;
+                    while (__any(rem != 0ull)) {
+                        const bool on = rem != 0ull;
+                        const int i = on ? __ffsll((long long)rem) - 1 : 0;
+                        rem &= rem - 1;
+                        const float4 uu = hv[v0 + i];
+                        float dx = x.x + R.m[0] * uu.x + R.m[1] * uu.y + R.m[2] * uu.z - p0x;
+                        float dy = x.y + R.m[3] * uu.x + R.m[4] * uu.y + R.m[5] * uu.z - p0y;
                         float area = ex * dy - ey * dx;
-                        bool cand = (i < nv) && (z < coff) && (i != k0) && (i != k1);
-                        bool up = cand && area > amax;
-                        bool dn = cand && area < amin;
+                        bool up = on && area > amax;
+                        bool dn = on && area < amin;
                         amax = up ? area : amax; k2 = up ? i : k2;
                         amin = dn ? area : amin; k3 = dn ? i : k3;
                     }
-                    if (cnt > 4) {
+                    if (big) {
                         s0 = k0; s1 = k1;
                         s2 = k2 >= 0 ? k2 : k3;
                         s3 = k2 >= 0 ? k3 : -1;
@@ -338,8 +402,8 @@ __global__ __launch_bounds__(64) void physics_ll_kernel(PhysArgs a) {
                 sel4[0] = s0; sel4[1] = s1; sel4[2] = s2; sel4[3] = s3;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const int vi = v0 + (sel4[c] < 0 ? 0 : sel4[c]);
-                    cr[c] = mul(R, V3{M.hull_verts[vi][0], M.hull_verts[vi][1], M.hull_verts[vi][2]});
+                    const float4 uu = hv[v0 + (sel4[c] < 0 ? 0 : sel4[c])];
+                    cr[c] = mul(R, V3{uu.x, uu.y, uu.z});
                     float dz = x.z + cr[c].z;
                     cbias[c] = dz >= 0.f ? dz / h : fmaxf(P.erp * dz / h, -P.max_depen);
                 }
@@ -351,13 +415,23 @@ __global__ __launch_bounds__(64) void physics_ll_kernel(PhysArgs a) {
 
             const unsigned long long tb = __ballot(valid && cnt > 0);
             const unsigned m0 = (unsigned)tb, m1 = (unsigned)(tb >> 32);
+            if (a.prof && blockIdx.x == 0 && lane == 0) { atomicAdd((unsigned long long*)&a.prof[9], (unsigned long long)(__popc(m0) + __popc(m1))); atomicAdd((unsigned long long*)&a.prof[10], 1ull); }
             if ((m0 | m1) && P.n_iter > 0) {
+                // deepest touched link of either env: links below it are never read during the sweep, so Lambda and the
+                // per-update propagation stop there; their velocities catch up once at the end (the propagation is linear)
+                int dneed = 1;
+                for (unsigned t = m0 | m1; t; t &= t - 1) {
+                    const int dd = M.depth[__ffs(t) - 1];
+                    dneed = dd > dneed ? dd : dneed;
+                }
+                LLPH(4);
                 // ======================================================== Lambda_b, root -> leaves by level
-                for (int d = 1; d <= maxd; ++d) {
+                for (int d = 1; d <= dneed; ++d) {
                     Blocks Lp;
-                    Lp.A = pull(Lam.A, plane);
-                    Lp.B = pull(Lam.B, plane);
-                    Lp.C = pull(Lam.C, plane);
+                    const bool nc = (nonchain >> d) & 1;
+                    Lp.A = pp(Lam.A, nc);
+                    Lp.B = pp(Lam.B, nc);
+                    Lp.C = pp(Lam.C, nc);
                     if (dep == d) {
                         // G = X Lp X^T: Ga = La ; Gb = La [r]x + Lb ; Gc = Lc - [r]x Lb + Gb^T [r]x
                         V3 la0{Lp.A.xx, Lp.A.xy, Lp.A.xz}, la1{Lp.A.xy, Lp.A.yy, Lp.A.yz}, la2{Lp.A.xz, Lp.A.yz, Lp.A.zz};
@@ -413,6 +487,8 @@ __global__ __launch_bounds__(64) void physics_ll_kernel(PhysArgs a) {
                     }
                 }
 
+                LLPH(5);
+                V3 accw{0.f, 0.f, 0.f}, accv{0.f, 0.f, 0.f};  // total delta-velocity of this link over the whole sweep
                 // ======================================================== block Gauss-Seidel: k-th touched body of each env at once
                 for (int it = 0; it < P.n_iter; ++it) {
                     unsigned t0 = m0, t1 = m1;
@@ -420,11 +496,11 @@ __global__ __launch_bounds__(64) void physics_ll_kernel(PhysArgs a) {
                         const int b0 = t0 ? __ffs(t0) - 1 : -1, b1 = t1 ? __ffs(t1) - 1 : -1;
                         t0 &= t0 - 1;
                         t1 &= t1 - 1;
-                        const int am0 = b0 >= 0 ? M.anc_mask[b0] : 0, am1 = b1 >= 0 ? M.anc_mask[b1] : 0;
                         const int bsel = half ? b1 : b0;
-                        const int amask = half ? am1 : am0;
                         const bool me = valid && (lb == bsel);
-                        const bool onpath = valid && ((amask >> lb) & 1);
+                        const bool onpath = valid && bsel >= 0 && ((desc >> bsel) & 1);  // this link is the touched one or one of its ancestors
+                        long long tsub = a.prof ? clock64() : 0;
+                        if (a.prof && blockIdx.x == 0 && lane == 0) atomicAdd((unsigned long long*)&a.prof[8], 1ull);
                         V3 un{0.f, 0.f, 0.f}, uf{0.f, 0.f, 0.f};
                         if (me) {
                             V3 wl = w, xl = xd;
@@ -455,9 +531,11 @@ __global__ __launch_bounds__(64) void physics_ll_kernel(PhysArgs a) {
                                 clam[c] = V3{ln, l1, l2};
                             }
                         }
+                        LLSUB(11);
                         // ---- net impulse (un, uf) at the touched link: leaf -> root along the path, level by level
                         V3 du{0.f, 0.f, 0.f};
-                        for (int d = maxd; d >= 1; --d) {
+                        for (int d = dneed; d >= 1; --d) {
+                            if (!__any(onpath && dep == d)) continue;  // nothing to hand up from this level
                             V3 cn{0.f, 0.f, 0.f}, cf{0.f, 0.f, 0.f};
                             if (dep == d && onpath) {
                                 du = un;
@@ -466,13 +544,14 @@ __global__ __launch_bounds__(64) void physics_ll_kernel(PhysArgs a) {
                                 cn = na + cross(r, fa);
                                 cf = fa;
                             }
-                            un = un + mask(has0, pull(cn, cl0));
-                            uf = uf + mask(has0, pull(cf, cl0));
+                            un = un + mask(has0, from_next(cn));
+                            uf = uf + mask(has0, from_next(cf));
                             if ((multi >> d) & 1) {
                                 un = un + mask(has1, pull(cn, cl1)) + mask(has2, pull(cn, cl2));
                                 uf = uf + mask(has1, pull(cf, cl1)) + mask(has2, pull(cf, cl2));
                             }
                         }
+                        LLSUB(12);
                         // root response, then root -> leaves: every link moves
                         V3 ddw{0.f, 0.f, 0.f}, ddv{0.f, 0.f, 0.f};
                         if (lb == 0) {
@@ -480,28 +559,47 @@ __global__ __launch_bounds__(64) void physics_ll_kernel(PhysArgs a) {
                             ddv = V3{dot(col(Lam.B, 0), un), dot(col(Lam.B, 1), un), dot(col(Lam.B, 2), un)} + mul(Lam.C, uf);
                             w = w + ddw;
                             xd = xd + ddv;
+                            accw = accw + ddw;
+                            accv = accv + ddv;
                         }
-                        for (int d = 1; d <= maxd; ++d) {
-                            V3 pdw = pull(ddw, plane), pdv = pull(ddv, plane);
+                        for (int d = 1; d <= dneed; ++d) {
+                            const bool nc = (nonchain >> d) & 1;
+                            V3 pdw = pp(ddw, nc), pdv = pp(ddv, nc);
                             if (dep == d) {
                                 V3 av = pdv + cross(pdw, r);
                                 ddw = mul(Di, aug * pdw + du) - mul(E, av);
                                 ddv = av;
                                 w = w + ddw;
                                 xd = xd + ddv;
+                                accw = accw + ddw;
+                                accv = accv + ddv;
                             }
                         }
+                        LLSUB(14);
+                    }
+                }
+                // links below the deepest touched one: one catch-up pass with the accumulated motion of their parents
+                for (int d = dneed + 1; d <= maxd; ++d) {
+                    const bool nc = (nonchain >> d) & 1;
+                    V3 pdw = pp(accw, nc), pdv = pp(accv, nc);
+                    if (dep == d) {
+                        V3 av = pdv + cross(pdw, r);
+                        accw = mul(Di, aug * pdw) - mul(E, av);
+                        accv = av;
+                        w = w + accw;
+                        xd = xd + accv;
                     }
                 }
             }
         }
 
+        LLPH(6);
         // ================================================================ velocities -> generalized, damping, clamp, integrate
         const float sc = 1.f / (1.f + h * P.ang_damp);
         const float wmax = P.max_ang_vel;
         {
-            Q4 pq = pull(q, plane);
-            V3 pw = pull(w, plane);
+            Q4 pq = pp(q, true);
+            V3 pw = pp(w, true);
             if (b != 0) {
                 V3 wn = mulT(R, w - pw);               // joint rate, body axes (undamped)
                 Q4 jold = qnormalize(qmul(qconj(pq), q));  // joint quaternion of the old configuration
@@ -528,10 +626,12 @@ __global__ __launch_bounds__(64) void physics_ll_kernel(PhysArgs a) {
         }
     }
 
+    LLPH(7);
     // ==================================================================== final kinematics -> state, rigid-body state, dof_pos
     for (int d = 1; d <= maxd; ++d) {
-        Q4 pq = pull(q, plane);
-        V3 px = pull(x, plane), pw = pull(w, plane), pxd = pull(xd, plane);
+        const bool nc = (nonchain >> d) & 1;
+        Q4 pq = pp(q, nc);
+        V3 px = pp(x, nc), pw = pp(w, nc), pxd = pp(xd, nc);
         if (dep == d) {
             q = qnormalize(qmul(pq, jq));
             V3 rr = mul(q2mat(pq), lpos);
@@ -574,7 +674,7 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s) {
     a.out = env->out;
     a.ws = env->ws;
     a.contact_ids = env->contact_ids;
-    a.prof = nullptr;
+    a.prof = env->prof;
     a.n = env->n;
     a.p = env->p;
     unsigned blocks = (unsigned)((env->n + 1) / 2);

@@ -29,9 +29,11 @@ struct DevModel {
     int32_t order[NB];     // links in level (breadth-first) order: consecutive entries never depend on each other's results
     int32_t children[NB][3];  // up to 3 children per link, -1 = none (lane = link kernel)
     int32_t anc_mask[NB];     // bit i set when link i is an ancestor of (or is) the link
+    int32_t desc_mask[NB];    // bit i set when link i is in the subtree of the link (self included)
     int32_t max_depth;
     int32_t multi_child_levels;  // bit d set when some link at depth d-1 has more than one child
     int32_t max_hull_count;
+    int32_t nonchain_levels;     // bit d set when some link at depth d does not directly follow its parent (parent != link - 1)
     int32_t lam_slot[NB];  // index into the saved-Lambda register sets for branching links (root = 0), -1 otherwise
     float local_pos[NB][3];
     float mass[NB];
