@@ -198,6 +198,11 @@ int v2p_env_post_physics(v2p_env* e, void* stream);                   /* humanoi
  * `with_rb_state`) buffers into the engine's internal structure-of-arrays state. */
 int v2p_env_push_state(v2p_env* e, const int64_t* env_ids, int64_t n, int with_rb_state, void* stream);
 
+/* Two schedules of the same physics model are built: 0 = one LINK per lane (default: 32 lanes per env, state in
+ * registers, level-synchronous tree recursions), 1 = one ENV per lane (LDS-resident workspace).  They agree to float32
+ * rounding; the second one is kept as an independent cross-check (tests) and for A/B profiling. */
+int v2p_env_set_schedule(v2p_env* e, int schedule);
+
 /* index (0/1) of the CURRENT target inside v2p_env_buffers.target; the other one is the previous target */
 int v2p_env_target_index(const v2p_env* e);
 

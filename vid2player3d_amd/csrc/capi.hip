@@ -238,6 +238,10 @@ int v2p_env_create(const v2p_model* model, const v2p_mlib* mlib, const v2p_sim_c
     e->n = n;
     e->device = device;
     e->motion_id = env_motion_id;
+    {
+        const char* k = getenv("V2P_KERNEL");  // default schedule; v2p_env_set_schedule overrides it
+        e->schedule = (k && !strcmp(k, "lds")) ? 1 : 0;
+    }
     EnvParams& p = e->p;
     p.h = c->sim_dt / (float)c->substeps;
     p.nsub = c->substeps * c->control_freq_inv;
@@ -310,14 +314,7 @@ int v2p_env_pre_physics(v2p_env* e, float* actions, void* stream) {
 int v2p_env_physics(v2p_env* e, void* stream) {
     if (!e) { set_error("v2p_env_physics: bad argument"); return V2P_ERR_INVALID; }
     DeviceGuard g(e->device);
-    // two schedules of the same model: "ll" (default) = one link per lane, register resident;
-    // "lds" = one env per lane, LDS resident (kept as an independent cross-check, V2P_KERNEL=lds)
-    static int use_ll = -1;
-    if (use_ll < 0) {
-        const char* k = getenv("V2P_KERNEL");
-        use_ll = (k && !strcmp(k, "lds")) ? 0 : 1;
-    }
-    return use_ll ? launch_env_physics_ll(e, (hipStream_t)stream) : launch_env_physics(e, (hipStream_t)stream);
+    return e->schedule == 0 ? launch_env_physics_ll(e, (hipStream_t)stream) : launch_env_physics(e, (hipStream_t)stream);
 }
 
 int v2p_env_export(v2p_env* e, void* stream) {
@@ -344,6 +341,12 @@ int v2p_env_push_state(v2p_env* e, const int64_t* env_ids, int64_t n, int with_r
     if (!e || n < 0 || n > e->n) { set_error("v2p_env_push_state: bad argument"); return V2P_ERR_INVALID; }
     DeviceGuard g(e->device);
     return launch_env_push_state(e, env_ids, env_ids ? n : e->n, with_rb_state, (hipStream_t)stream);
+}
+
+int v2p_env_set_schedule(v2p_env* e, int schedule) {
+    if (!e || (schedule != 0 && schedule != 1)) { set_error("v2p_env_set_schedule: bad argument"); return V2P_ERR_INVALID; }
+    e->schedule = schedule;
+    return V2P_OK;
 }
 
 int v2p_env_target_index(const v2p_env* e) { return e ? e->cur_target : V2P_ERR_INVALID; }

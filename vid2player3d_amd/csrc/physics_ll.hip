@@ -144,8 +144,6 @@ __global__ __launch_bounds__(64) void physics_ll_kernel(PhysArgs a) {
         wt = V3{st[(vb + 0) * N + e], st[(vb + 1) * N + e], st[(vb + 2) * N + e]};
         tar = V3{a.ctrl[(cb + 0) * N + e], a.ctrl[(cb + 1) * N + e], a.ctrl[(cb + 2) * N + e]};
     }
-    const V3 extF{a.ctrl[(CT_FORCE + 0) * N + e], a.ctrl[(CT_FORCE + 1) * N + e], a.ctrl[(CT_FORCE + 2) * N + e]};
-    const V3 extT{a.ctrl[(CT_TORQUE + 0) * N + e], a.ctrl[(CT_TORQUE + 1) * N + e], a.ctrl[(CT_TORQUE + 2) * N + e]};
 
     long long tprev = a.prof ? clock64() : 0;
     V3 r{0.f, 0.f, 0.f};
@@ -174,14 +172,14 @@ __global__ __launch_bounds__(64) void physics_ll_kernel(PhysArgs a) {
             }
         }
         // ---- per link, all lanes at once: joint torque, body inertia at its origin (world axes), bias force
-        const M3 R = q2mat(q);
         V3 tau{0.f, 0.f, 0.f};
-        if (b != 0) tau = mul(R, kp * (tar - quat_to_expmap_stable(jq)) - (kd + h * kp) * wt);
         Sym3 A;
         M3 B;
         Sym3 C{mass, 0.f, 0.f, mass, 0.f, mass};
         V3 pn, pf;
         {
+            const M3 R = q2mat(q);
+            if (b != 0) tau = mul(R, kp * (tar - quat_to_expmap_stable(jq)) - (kd + h * kp) * wt);
             V3 dc = mul(R, com);
             V3 k0 = mul(Ib, V3{R.m[0], R.m[1], R.m[2]});
             V3 k1 = mul(Ib, V3{R.m[3], R.m[4], R.m[5]});
@@ -198,6 +196,8 @@ __global__ __launch_bounds__(64) void physics_ll_kernel(PhysArgs a) {
             pf = mass * (wwd - V3{0.f, 0.f, P.gravity_z});
             pn = cross(w, mul(Ic, w)) + cross(dc, pf);
             if (b == 0 && wrench_on) {
+                const V3 extF{a.ctrl[(CT_FORCE + 0) * N + e], a.ctrl[(CT_FORCE + 1) * N + e], a.ctrl[(CT_FORCE + 2) * N + e]};
+                const V3 extT{a.ctrl[(CT_TORQUE + 0) * N + e], a.ctrl[(CT_TORQUE + 1) * N + e], a.ctrl[(CT_TORQUE + 2) * N + e]};
                 pn = pn - extT - cross(dc, extF);  // force acts at the root COM
                 pf = pf - extF;
             }
@@ -257,13 +257,18 @@ __global__ __launch_bounds__(64) void physics_ll_kernel(PhysArgs a) {
                 pf = pf + mask(has0, from_next(cf));
             }
             if ((multi >> d) & 1) {
-                A = A + mask(has1, pull(cA, cl1)) + mask(has2, pull(cA, cl2));
-                C = C + mask(has1, pull(cC, cl1)) + mask(has2, pull(cC, cl2));
-                M3 t1 = pull(cB, cl1), t2 = pull(cB, cl2);
+#pragma unroll 1
+                for (int sl = 1; sl <= 2; ++sl) {  // one extra child at a time keeps the register peak down
+                    const int cl = sl == 1 ? cl1 : cl2;
+                    const bool hs = sl == 1 ? has1 : has2;
+                    A = A + mask(hs, pull(cA, cl));
+                    C = C + mask(hs, pull(cC, cl));
+                    M3 t1 = pull(cB, cl);
 #pragma unroll
-                for (int i = 0; i < 9; ++i) B.m[i] += (has1 ? t1.m[i] : 0.f) + (has2 ? t2.m[i] : 0.f);
-                pn = pn + mask(has1, pull(cn, cl1)) + mask(has2, pull(cn, cl2));
-                pf = pf + mask(has1, pull(cf, cl1)) + mask(has2, pull(cf, cl2));
+                    for (int i = 0; i < 9; ++i) B.m[i] += hs ? t1.m[i] : 0.f;
+                    pn = pn + mask(hs, pull(cn, cl));
+                    pf = pf + mask(hs, pull(cf, cl));
+                }
             }
         }
 
@@ -329,6 +334,7 @@ __global__ __launch_bounds__(64) void physics_ll_kernel(PhysArgs a) {
             const bool near = valid && (x.z - brad < coff);
             int sel4[4] = {-1, -1, -1, -1};
             if (__any(near)) {
+                const M3 R = q2mat(q);
                 const int nvmax = M.max_hull_count;
                 unsigned long long cm = 0ull;
                 int k0 = -1;
@@ -601,7 +607,7 @@ __global__ __launch_bounds__(64) void physics_ll_kernel(PhysArgs a) {
             Q4 pq = pp(q, true);
             V3 pw = pp(w, true);
             if (b != 0) {
-                V3 wn = mulT(R, w - pw);               // joint rate, body axes (undamped)
+                V3 wn = mulT(q2mat(q), w - pw);               // joint rate, body axes (undamped)
                 Q4 jold = qnormalize(qmul(qconj(pq), q));  // joint quaternion of the old configuration
                 if (last) dofforce = kp * (tar - quat_to_expmap_stable(jold) - h * wn) - kd * wn;
                 wn = sc * wn;

@@ -99,6 +99,7 @@ struct v2p_env {
     int64_t n;
     int device;
     int cur_target;           // index of the current target buffer
+    int schedule;             // 0 = link per lane (physics_ll.hip), 1 = env per lane (physics.hip)
     const int64_t* motion_id; // [N] device (borrowed)
     float* state;             // SoA [STATE_SLOTS][N]
     float* ctrl;              // SoA [CTRL_SLOTS][N]: pd target 69, wrench 6

@@ -470,6 +470,11 @@ class HumanoidSMPLIM:
         n = self.num_envs if env_ids is None else env_ids.shape[0]
         _lib.check(self._lib.v2p_env_push_state(self._h_env, _lib.ptr(env_ids), n, int(with_rb_state), self._stream()), "v2p_env_push_state")
 
+    def set_schedule(self, name):
+        """'link_per_lane' (default) or 'env_per_lane': two GPU schedules of the same physics model."""
+        kind = {"link_per_lane": 0, "env_per_lane": 1}[name]
+        _lib.check(self._lib.v2p_env_set_schedule(self._h_env, kind), "v2p_env_set_schedule")
+
     def debug_contacts(self):
         out = torch.empty((self.num_envs, self.num_bodies, 4), dtype=torch.int32, device=self.device)
         _lib.check(self._lib.v2p_env_debug_contacts(self._h_env, _lib.ptr(out), self._stream()), "v2p_env_debug_contacts")
