@@ -13,7 +13,7 @@ context window) runs INSIDE the timed region, as in the reference's play_steps. 
 excluded.  Envs shard across ranks with no data-path collective ("scaling": "weak").
 
 One JSON line on rank 0, with
-  roofline      dominant kernel = physics_kernel: algorithmic HBM bytes of one step (SURVEY.md 8d:
+  roofline      dominant kernel = physics_ll_kernel: algorithmic HBM bytes of one step (SURVEY.md 8d:
                 9,896 B per env-step x envs per launch) / its mean duration measured here with HIP
                 events on the launch stream; peak = 8 TB/s.
   cpu_baseline  the oracle (C physics restatement + numpy task ops) timed on this host's cores on a
@@ -123,7 +123,10 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from vid2player3d_amd import build
-    build.build()
+    if local_rank == 0:
+        build.build()  # no-op when the in-tree .so is current; one rank per node compiles otherwise
+    if dist is not None:
+        dist.barrier()
     n = args.num_envs
     task = build_task(n, local_rank, seed=7 + rank, contact=not args.no_contact)  # per-rank seed like run.py:37
     dev = task.device
@@ -192,7 +195,7 @@ def main():
                                    % (n, "PD control only (no contact solve)" if args.no_contact else "full contact PGS (4 substeps x 4 iterations)", HORIZON),
                        "num_envs_per_gpu": n, "global_envs": world * n, "parallelism": "env-sharded x%d, no data-path collective" % world,
                        "alive_fraction_at_end": alive},
-            "roofline": {"bound": "hbm", "kernel": "physics_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "physics_ll_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": phys_ms,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n,
                          "note": "latency/VALU bound, not HBM bound: see DESIGN.md"},

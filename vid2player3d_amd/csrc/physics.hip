@@ -125,14 +125,14 @@ __global__ __launch_bounds__(L) void physics_kernel(PhysArgs a) {
     auto ld_q = [&](int i) { float4 q = SG(i, 0); return Q4{q.x, q.y, q.z, q.w}; };
 
     // ---- stage the generalized state into LDS (global state is read once and written once per launch)
-    SG(0, 0) = f4(st[(ST_ROOT_QUAT + 0) * N + e], st[(ST_ROOT_QUAT + 1) * N + e], st[(ST_ROOT_QUAT + 2) * N + e], st[(ST_ROOT_QUAT + 3) * N + e]);
-    SG(0, 1) = f4(st[(ST_ROOT_POS + 0) * N + e], st[(ST_ROOT_POS + 1) * N + e], st[(ST_ROOT_POS + 2) * N + e], 0.f);
-    SG(0, 2) = f4(st[(ST_VEL + 3) * N + e], st[(ST_VEL + 4) * N + e], st[(ST_VEL + 5) * N + e], st[(ST_VEL + 0) * N + e]);
-    SG(0, 3) = f4(st[(ST_VEL + 1) * N + e], st[(ST_VEL + 2) * N + e], 0.f, 0.f);
+    SG(0, 0) = f4(st[SIDX(ST_ROOT_QUAT + 0)], st[SIDX(ST_ROOT_QUAT + 1)], st[SIDX(ST_ROOT_QUAT + 2)], st[SIDX(ST_ROOT_QUAT + 3)]);
+    SG(0, 1) = f4(st[SIDX(ST_ROOT_POS + 0)], st[SIDX(ST_ROOT_POS + 1)], st[SIDX(ST_ROOT_POS + 2)], 0.f);
+    SG(0, 2) = f4(st[SIDX(ST_VEL + 3)], st[SIDX(ST_VEL + 4)], st[SIDX(ST_VEL + 5)], st[SIDX(ST_VEL + 0)]);
+    SG(0, 3) = f4(st[SIDX(ST_VEL + 1)], st[SIDX(ST_VEL + 2)], 0.f, 0.f);
     for (int b = 1; b < NB; ++b) {
         const int jb = ST_JQUAT + 4 * (b - 1), vb = ST_VEL + 6 + 3 * (b - 1);
-        SG(b, 8) = f4(st[(jb + 0) * N + e], st[(jb + 1) * N + e], st[(jb + 2) * N + e], st[(jb + 3) * N + e]);
-        SG(b, 9) = f4(st[(vb + 0) * N + e], st[(vb + 1) * N + e], st[(vb + 2) * N + e], 0.f);
+        SG(b, 8) = f4(st[SIDX(jb + 0)], st[SIDX(jb + 1)], st[SIDX(jb + 2)], st[SIDX(jb + 3)]);
+        SG(b, 9) = f4(st[SIDX(vb + 0)], st[SIDX(vb + 1)], st[SIDX(vb + 2)], 0.f);
     }
 
     for (int sub = 0; sub < P.nsub; ++sub) {
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(L) void physics_kernel(PhysArgs a) {
         const bool last = sub == P.nsub - 1;
         for (int b = 1; b < NB; ++b) {
             const int cb = CT_PD + 3 * (b - 1);
-            SG(b, 11) = f4(a.ctrl[(cb + 0) * N + e], a.ctrl[(cb + 1) * N + e], a.ctrl[(cb + 2) * N + e], 0.f);
+            SG(b, 11) = f4(a.ctrl[CIDX(cb + 0)], a.ctrl[CIDX(cb + 1)], a.ctrl[CIDX(cb + 2)], 0.f);
         }
         PHASE(0);
         // ================================================================ pass 1: root -> leaves
@@ -195,8 +195,8 @@ __global__ __launch_bounds__(L) void physics_kernel(PhysArgs a) {
             V3 fl = m * (wwd - V3{0.f, 0.f, P.gravity_z});
             V3 nn = cross(w, mul(Ic, w)) + cross(d, fl);
             if (b == 0 && wrench_on) {
-                V3 F{a.ctrl[(CT_FORCE + 0) * N + e], a.ctrl[(CT_FORCE + 1) * N + e], a.ctrl[(CT_FORCE + 2) * N + e]};
-                V3 T{a.ctrl[(CT_TORQUE + 0) * N + e], a.ctrl[(CT_TORQUE + 1) * N + e], a.ctrl[(CT_TORQUE + 2) * N + e]};
+                V3 F{a.ctrl[CIDX(CT_FORCE + 0)], a.ctrl[CIDX(CT_FORCE + 1)], a.ctrl[CIDX(CT_FORCE + 2)]};
+                V3 T{a.ctrl[CIDX(CT_TORQUE + 0)], a.ctrl[CIDX(CT_TORQUE + 1)], a.ctrl[CIDX(CT_TORQUE + 2)]};
                 nn = nn - T - cross(d, F);  // force acts at the root COM
                 fl = fl - F;
             }
@@ -669,10 +669,10 @@ __global__ __launch_bounds__(L) void physics_kernel(PhysArgs a) {
                 // joint drive torque actually applied over the substep (implicit form)
                 V3 qe = quat_to_expmap_stable(jq);
                 const int cb = CT_PD + 3 * (b - 1);
-                V3 tar{a.ctrl[(cb + 0) * N + e], a.ctrl[(cb + 1) * N + e], a.ctrl[(cb + 2) * N + e]};
+                V3 tar{a.ctrl[CIDX(cb + 0)], a.ctrl[CIDX(cb + 1)], a.ctrl[CIDX(cb + 2)]};
                 V3 tf = M.kp[b] * (tar - qe - h * wt) - M.kd[b] * wt;
                 const int ob = OUT_DOF_FORCE + 3 * (b - 1);
-                a.out[(ob + 0) * N + e] = tf.x; a.out[(ob + 1) * N + e] = tf.y; a.out[(ob + 2) * N + e] = tf.z;
+                a.out[OIDX(ob + 0)] = tf.x; a.out[OIDX(ob + 1)] = tf.y; a.out[OIDX(ob + 2)] = tf.z;
             }
             wt = sc * wt;
             float n2 = dot(wt, wt);
@@ -701,9 +701,9 @@ __global__ __launch_bounds__(L) void physics_kernel(PhysArgs a) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
                     if (c < cnt) { f.z += G(b, GCL + 3 * c); f.x += G(b, GCL + 3 * c + 1); f.y += G(b, GCL + 3 * c + 2); }
-                a.out[(OUT_CONTACT + 3 * b + 0) * N + e] = f.x * ih;
-                a.out[(OUT_CONTACT + 3 * b + 1) * N + e] = f.y * ih;
-                a.out[(OUT_CONTACT + 3 * b + 2) * N + e] = f.z * ih;
+                a.out[OIDX(OUT_CONTACT + 3 * b + 0)] = f.x * ih;
+                a.out[OIDX(OUT_CONTACT + 3 * b + 1)] = f.y * ih;
+                a.out[OIDX(OUT_CONTACT + 3 * b + 2)] = f.z * ih;
             }
         }
     }
@@ -720,17 +720,17 @@ __global__ __launch_bounds__(L) void physics_kernel(PhysArgs a) {
             x = xyz(SG(0, 1));
             w = xyz(g2);
             xd = V3{g2.w, g3.x, g3.y};
-            st[(ST_ROOT_QUAT + 0) * N + e] = q.x; st[(ST_ROOT_QUAT + 1) * N + e] = q.y; st[(ST_ROOT_QUAT + 2) * N + e] = q.z; st[(ST_ROOT_QUAT + 3) * N + e] = q.w;
-            st[(ST_ROOT_POS + 0) * N + e] = x.x; st[(ST_ROOT_POS + 1) * N + e] = x.y; st[(ST_ROOT_POS + 2) * N + e] = x.z;
-            st[(ST_VEL + 0) * N + e] = xd.x; st[(ST_VEL + 1) * N + e] = xd.y; st[(ST_VEL + 2) * N + e] = xd.z;
-            st[(ST_VEL + 3) * N + e] = w.x; st[(ST_VEL + 4) * N + e] = w.y; st[(ST_VEL + 5) * N + e] = w.z;
+            st[SIDX(ST_ROOT_QUAT + 0)] = q.x; st[SIDX(ST_ROOT_QUAT + 1)] = q.y; st[SIDX(ST_ROOT_QUAT + 2)] = q.z; st[SIDX(ST_ROOT_QUAT + 3)] = q.w;
+            st[SIDX(ST_ROOT_POS + 0)] = x.x; st[SIDX(ST_ROOT_POS + 1)] = x.y; st[SIDX(ST_ROOT_POS + 2)] = x.z;
+            st[SIDX(ST_VEL + 0)] = xd.x; st[SIDX(ST_VEL + 1)] = xd.y; st[SIDX(ST_VEL + 2)] = xd.z;
+            st[SIDX(ST_VEL + 3)] = w.x; st[SIDX(ST_VEL + 4)] = w.y; st[SIDX(ST_VEL + 5)] = w.z;
         } else {
             float4 jq4 = SG(b, 8), wt4 = SG(b, 9), pg2 = SG(par, 2), pg3 = SG(par, 3);
             Q4 jq{jq4.x, jq4.y, jq4.z, jq4.w};
             V3 wt = xyz(wt4);
             const int jb = ST_JQUAT + 4 * (b - 1), vb = ST_VEL + 6 + 3 * (b - 1);
-            st[(jb + 0) * N + e] = jq.x; st[(jb + 1) * N + e] = jq.y; st[(jb + 2) * N + e] = jq.z; st[(jb + 3) * N + e] = jq.w;
-            st[(vb + 0) * N + e] = wt.x; st[(vb + 1) * N + e] = wt.y; st[(vb + 2) * N + e] = wt.z;
+            st[SIDX(jb + 0)] = jq.x; st[SIDX(jb + 1)] = jq.y; st[SIDX(jb + 2)] = jq.z; st[SIDX(jb + 3)] = jq.w;
+            st[SIDX(vb + 0)] = wt.x; st[SIDX(vb + 1)] = wt.y; st[SIDX(vb + 2)] = wt.z;
             Q4 qp = ld_q(par);
             V3 xp = xyz(SG(par, 1)), wp = xyz(pg2), xdp{pg2.w, pg3.x, pg3.y};
             q = qnormalize(qmul(qp, jq));
@@ -740,20 +740,20 @@ __global__ __launch_bounds__(L) void physics_kernel(PhysArgs a) {
             xd = xdp + cross(wp, r);
             V3 qe = quat_to_expmap_stable(jq);
             const int ob = OUT_DOF_POS + 3 * (b - 1);
-            a.out[(ob + 0) * N + e] = qe.x; a.out[(ob + 1) * N + e] = qe.y; a.out[(ob + 2) * N + e] = qe.z;
+            a.out[OIDX(ob + 0)] = qe.x; a.out[OIDX(ob + 1)] = qe.y; a.out[OIDX(ob + 2)] = qe.z;
             SG(b, 0) = f4(q.x, q.y, q.z, q.w);
             SG(b, 1) = f4(x.x, x.y, x.z, 0.f);
             SG(b, 2) = f4(w.x, w.y, w.z, xd.x);
             SG(b, 3) = f4(xd.y, xd.z, 0.f, 0.f);
         }
         const int ob = OUT_RB + 13 * b;
-        a.out[(ob + 0) * N + e] = x.x; a.out[(ob + 1) * N + e] = x.y; a.out[(ob + 2) * N + e] = x.z;
-        a.out[(ob + 3) * N + e] = q.x; a.out[(ob + 4) * N + e] = q.y; a.out[(ob + 5) * N + e] = q.z; a.out[(ob + 6) * N + e] = q.w;
-        a.out[(ob + 7) * N + e] = xd.x; a.out[(ob + 8) * N + e] = xd.y; a.out[(ob + 9) * N + e] = xd.z;
-        a.out[(ob + 10) * N + e] = w.x; a.out[(ob + 11) * N + e] = w.y; a.out[(ob + 12) * N + e] = w.z;
+        a.out[OIDX(ob + 0)] = x.x; a.out[OIDX(ob + 1)] = x.y; a.out[OIDX(ob + 2)] = x.z;
+        a.out[OIDX(ob + 3)] = q.x; a.out[OIDX(ob + 4)] = q.y; a.out[OIDX(ob + 5)] = q.z; a.out[OIDX(ob + 6)] = q.w;
+        a.out[OIDX(ob + 7)] = xd.x; a.out[OIDX(ob + 8)] = xd.y; a.out[OIDX(ob + 9)] = xd.z;
+        a.out[OIDX(ob + 10)] = w.x; a.out[OIDX(ob + 11)] = w.y; a.out[OIDX(ob + 12)] = w.z;
     }
     if (!CONTACT) {
-        for (int k = 0; k < NB * 3; ++k) a.out[(OUT_CONTACT + k) * N + e] = 0.f;
+        for (int k = 0; k < NB * 3; ++k) a.out[OIDX(OUT_CONTACT + k)] = 0.f;
     }
 }
 

@@ -134,15 +134,15 @@ __global__ __launch_bounds__(64) void physics_ll_kernel(PhysArgs a) {
     Q4 q{0.f, 0.f, 0.f, 1.f}, jq{0.f, 0.f, 0.f, 1.f};
     V3 x{0.f, 0.f, 0.f}, w{0.f, 0.f, 0.f}, xd{0.f, 0.f, 0.f}, wt{0.f, 0.f, 0.f}, tar{0.f, 0.f, 0.f};
     if (b == 0) {
-        q = Q4{st[(ST_ROOT_QUAT + 0) * N + e], st[(ST_ROOT_QUAT + 1) * N + e], st[(ST_ROOT_QUAT + 2) * N + e], st[(ST_ROOT_QUAT + 3) * N + e]};
-        x = V3{st[(ST_ROOT_POS + 0) * N + e], st[(ST_ROOT_POS + 1) * N + e], st[(ST_ROOT_POS + 2) * N + e]};
-        xd = V3{st[(ST_VEL + 0) * N + e], st[(ST_VEL + 1) * N + e], st[(ST_VEL + 2) * N + e]};
-        w = V3{st[(ST_VEL + 3) * N + e], st[(ST_VEL + 4) * N + e], st[(ST_VEL + 5) * N + e]};
+        q = Q4{st[SIDX(ST_ROOT_QUAT + 0)], st[SIDX(ST_ROOT_QUAT + 1)], st[SIDX(ST_ROOT_QUAT + 2)], st[SIDX(ST_ROOT_QUAT + 3)]};
+        x = V3{st[SIDX(ST_ROOT_POS + 0)], st[SIDX(ST_ROOT_POS + 1)], st[SIDX(ST_ROOT_POS + 2)]};
+        xd = V3{st[SIDX(ST_VEL + 0)], st[SIDX(ST_VEL + 1)], st[SIDX(ST_VEL + 2)]};
+        w = V3{st[SIDX(ST_VEL + 3)], st[SIDX(ST_VEL + 4)], st[SIDX(ST_VEL + 5)]};
     } else {
         const int jb = ST_JQUAT + 4 * (b - 1), vb = ST_VEL + 6 + 3 * (b - 1), cb = CT_PD + 3 * (b - 1);
-        jq = Q4{st[(jb + 0) * N + e], st[(jb + 1) * N + e], st[(jb + 2) * N + e], st[(jb + 3) * N + e]};
-        wt = V3{st[(vb + 0) * N + e], st[(vb + 1) * N + e], st[(vb + 2) * N + e]};
-        tar = V3{a.ctrl[(cb + 0) * N + e], a.ctrl[(cb + 1) * N + e], a.ctrl[(cb + 2) * N + e]};
+        jq = Q4{st[SIDX(jb + 0)], st[SIDX(jb + 1)], st[SIDX(jb + 2)], st[SIDX(jb + 3)]};
+        wt = V3{st[SIDX(vb + 0)], st[SIDX(vb + 1)], st[SIDX(vb + 2)]};
+        tar = V3{a.ctrl[CIDX(cb + 0)], a.ctrl[CIDX(cb + 1)], a.ctrl[CIDX(cb + 2)]};
     }
 
     long long tprev = a.prof ? clock64() : 0;
@@ -196,8 +196,8 @@ __global__ __launch_bounds__(64) void physics_ll_kernel(PhysArgs a) {
             pf = mass * (wwd - V3{0.f, 0.f, P.gravity_z});
             pn = cross(w, mul(Ic, w)) + cross(dc, pf);
             if (b == 0 && wrench_on) {
-                const V3 extF{a.ctrl[(CT_FORCE + 0) * N + e], a.ctrl[(CT_FORCE + 1) * N + e], a.ctrl[(CT_FORCE + 2) * N + e]};
-                const V3 extT{a.ctrl[(CT_TORQUE + 0) * N + e], a.ctrl[(CT_TORQUE + 1) * N + e], a.ctrl[(CT_TORQUE + 2) * N + e]};
+                const V3 extF{a.ctrl[CIDX(CT_FORCE + 0)], a.ctrl[CIDX(CT_FORCE + 1)], a.ctrl[CIDX(CT_FORCE + 2)]};
+                const V3 extT{a.ctrl[CIDX(CT_TORQUE + 0)], a.ctrl[CIDX(CT_TORQUE + 1)], a.ctrl[CIDX(CT_TORQUE + 2)]};
                 pn = pn - extT - cross(dc, extF);  // force acts at the root COM
                 pf = pf - extF;
             }
@@ -648,27 +648,27 @@ __global__ __launch_bounds__(64) void physics_ll_kernel(PhysArgs a) {
     }
     if (valid && live_env) {
         if (b == 0) {
-            st[(ST_ROOT_QUAT + 0) * N + e] = q.x; st[(ST_ROOT_QUAT + 1) * N + e] = q.y; st[(ST_ROOT_QUAT + 2) * N + e] = q.z; st[(ST_ROOT_QUAT + 3) * N + e] = q.w;
-            st[(ST_ROOT_POS + 0) * N + e] = x.x; st[(ST_ROOT_POS + 1) * N + e] = x.y; st[(ST_ROOT_POS + 2) * N + e] = x.z;
-            st[(ST_VEL + 0) * N + e] = xd.x; st[(ST_VEL + 1) * N + e] = xd.y; st[(ST_VEL + 2) * N + e] = xd.z;
-            st[(ST_VEL + 3) * N + e] = w.x; st[(ST_VEL + 4) * N + e] = w.y; st[(ST_VEL + 5) * N + e] = w.z;
+            st[SIDX(ST_ROOT_QUAT + 0)] = q.x; st[SIDX(ST_ROOT_QUAT + 1)] = q.y; st[SIDX(ST_ROOT_QUAT + 2)] = q.z; st[SIDX(ST_ROOT_QUAT + 3)] = q.w;
+            st[SIDX(ST_ROOT_POS + 0)] = x.x; st[SIDX(ST_ROOT_POS + 1)] = x.y; st[SIDX(ST_ROOT_POS + 2)] = x.z;
+            st[SIDX(ST_VEL + 0)] = xd.x; st[SIDX(ST_VEL + 1)] = xd.y; st[SIDX(ST_VEL + 2)] = xd.z;
+            st[SIDX(ST_VEL + 3)] = w.x; st[SIDX(ST_VEL + 4)] = w.y; st[SIDX(ST_VEL + 5)] = w.z;
         } else {
             const int jb = ST_JQUAT + 4 * (b - 1), vb = ST_VEL + 6 + 3 * (b - 1);
-            st[(jb + 0) * N + e] = jq.x; st[(jb + 1) * N + e] = jq.y; st[(jb + 2) * N + e] = jq.z; st[(jb + 3) * N + e] = jq.w;
-            st[(vb + 0) * N + e] = wt.x; st[(vb + 1) * N + e] = wt.y; st[(vb + 2) * N + e] = wt.z;
+            st[SIDX(jb + 0)] = jq.x; st[SIDX(jb + 1)] = jq.y; st[SIDX(jb + 2)] = jq.z; st[SIDX(jb + 3)] = jq.w;
+            st[SIDX(vb + 0)] = wt.x; st[SIDX(vb + 1)] = wt.y; st[SIDX(vb + 2)] = wt.z;
             V3 qe = quat_to_expmap_stable(jq);
             const int op = OUT_DOF_POS + 3 * (b - 1), of = OUT_DOF_FORCE + 3 * (b - 1);
-            a.out[(op + 0) * N + e] = qe.x; a.out[(op + 1) * N + e] = qe.y; a.out[(op + 2) * N + e] = qe.z;
-            a.out[(of + 0) * N + e] = dofforce.x; a.out[(of + 1) * N + e] = dofforce.y; a.out[(of + 2) * N + e] = dofforce.z;
+            a.out[OIDX(op + 0)] = qe.x; a.out[OIDX(op + 1)] = qe.y; a.out[OIDX(op + 2)] = qe.z;
+            a.out[OIDX(of + 0)] = dofforce.x; a.out[OIDX(of + 1)] = dofforce.y; a.out[OIDX(of + 2)] = dofforce.z;
         }
         const int ob = OUT_RB + 13 * b;
-        a.out[(ob + 0) * N + e] = x.x; a.out[(ob + 1) * N + e] = x.y; a.out[(ob + 2) * N + e] = x.z;
-        a.out[(ob + 3) * N + e] = q.x; a.out[(ob + 4) * N + e] = q.y; a.out[(ob + 5) * N + e] = q.z; a.out[(ob + 6) * N + e] = q.w;
-        a.out[(ob + 7) * N + e] = xd.x; a.out[(ob + 8) * N + e] = xd.y; a.out[(ob + 9) * N + e] = xd.z;
-        a.out[(ob + 10) * N + e] = w.x; a.out[(ob + 11) * N + e] = w.y; a.out[(ob + 12) * N + e] = w.z;
-        a.out[(OUT_CONTACT + 3 * b + 0) * N + e] = cforce.x;
-        a.out[(OUT_CONTACT + 3 * b + 1) * N + e] = cforce.y;
-        a.out[(OUT_CONTACT + 3 * b + 2) * N + e] = cforce.z;
+        a.out[OIDX(ob + 0)] = x.x; a.out[OIDX(ob + 1)] = x.y; a.out[OIDX(ob + 2)] = x.z;
+        a.out[OIDX(ob + 3)] = q.x; a.out[OIDX(ob + 4)] = q.y; a.out[OIDX(ob + 5)] = q.z; a.out[OIDX(ob + 6)] = q.w;
+        a.out[OIDX(ob + 7)] = xd.x; a.out[OIDX(ob + 8)] = xd.y; a.out[OIDX(ob + 9)] = xd.z;
+        a.out[OIDX(ob + 10)] = w.x; a.out[OIDX(ob + 11)] = w.y; a.out[OIDX(ob + 12)] = w.z;
+        a.out[OIDX(OUT_CONTACT + 3 * b + 0)] = cforce.x;
+        a.out[OIDX(OUT_CONTACT + 3 * b + 1)] = cforce.y;
+        a.out[OIDX(OUT_CONTACT + 3 * b + 2)] = cforce.z;
     }
 }
 

@@ -265,12 +265,12 @@ __global__ __launch_bounds__(EB_BLOCK) void env_reset_kernel(EnvView v, const in
     if (j == 0) {
         float* r = v.b.root_states + e * 13;
         st3(r, s.pos); st4(r + 3, s.rot); st3(r + 7, s.root_vel); st3(r + 10, s.root_ang_vel);
-        v.state[(ST_ROOT_POS + 0) * N + e] = s.pos.x; v.state[(ST_ROOT_POS + 1) * N + e] = s.pos.y; v.state[(ST_ROOT_POS + 2) * N + e] = s.pos.z;
+        v.state[SIDX(ST_ROOT_POS + 0)] = s.pos.x; v.state[SIDX(ST_ROOT_POS + 1)] = s.pos.y; v.state[SIDX(ST_ROOT_POS + 2)] = s.pos.z;
         Q4 rq = qnormalize(s.rot);
-        v.state[(ST_ROOT_QUAT + 0) * N + e] = rq.x; v.state[(ST_ROOT_QUAT + 1) * N + e] = rq.y;
-        v.state[(ST_ROOT_QUAT + 2) * N + e] = rq.z; v.state[(ST_ROOT_QUAT + 3) * N + e] = rq.w;
-        v.state[(ST_VEL + 0) * N + e] = s.root_vel.x; v.state[(ST_VEL + 1) * N + e] = s.root_vel.y; v.state[(ST_VEL + 2) * N + e] = s.root_vel.z;
-        v.state[(ST_VEL + 3) * N + e] = s.root_ang_vel.x; v.state[(ST_VEL + 4) * N + e] = s.root_ang_vel.y; v.state[(ST_VEL + 5) * N + e] = s.root_ang_vel.z;
+        v.state[SIDX(ST_ROOT_QUAT + 0)] = rq.x; v.state[SIDX(ST_ROOT_QUAT + 1)] = rq.y;
+        v.state[SIDX(ST_ROOT_QUAT + 2)] = rq.z; v.state[SIDX(ST_ROOT_QUAT + 3)] = rq.w;
+        v.state[SIDX(ST_VEL + 0)] = s.root_vel.x; v.state[SIDX(ST_VEL + 1)] = s.root_vel.y; v.state[SIDX(ST_VEL + 2)] = s.root_vel.z;
+        v.state[SIDX(ST_VEL + 3)] = s.root_ang_vel.x; v.state[SIDX(ST_VEL + 4)] = s.root_ang_vel.y; v.state[SIDX(ST_VEL + 5)] = s.root_ang_vel.z;
         v.b.cur_time[e] = t0;
         v.b.reset_time[e] = t0;
         v.b.progress[e] = 0;
@@ -282,9 +282,9 @@ __global__ __launch_bounds__(EB_BLOCK) void env_reset_kernel(EnvView v, const in
         // gym.set_dof_state_tensor_indexed: the engine's joint quaternion is rebuilt from the exp-map dof_pos
         Q4 jq = ref_exp_map_to_quat(s.dof_pos);
         int base = ST_JQUAT + 4 * (j - 1);
-        v.state[(base + 0) * N + e] = jq.x; v.state[(base + 1) * N + e] = jq.y; v.state[(base + 2) * N + e] = jq.z; v.state[(base + 3) * N + e] = jq.w;
+        v.state[SIDX(base + 0)] = jq.x; v.state[SIDX(base + 1)] = jq.y; v.state[SIDX(base + 2)] = jq.z; v.state[SIDX(base + 3)] = jq.w;
         int vb = ST_VEL + 6 + 3 * (j - 1);
-        v.state[(vb + 0) * N + e] = s.dof_vel.x; v.state[(vb + 1) * N + e] = s.dof_vel.y; v.state[(vb + 2) * N + e] = s.dof_vel.z;
+        v.state[SIDX(vb + 0)] = s.dof_vel.x; v.state[SIDX(vb + 1)] = s.dof_vel.y; v.state[SIDX(vb + 2)] = s.dof_vel.z;
     }
     write_obs(v, e, j, s.pos, s.rot, zero, zero, s.dof_pos, s.dof_vel);
     // target = state one control step ahead (_set_target_motion_state :594-624)
@@ -348,7 +348,7 @@ __global__ void env_pre_kernel(EnvView v, float* __restrict__ actions) {
         float q = v.b.dof_state[(e * NDOF + a) * 2];
         float tar = fmaxf(fminf(act, q + v.p.pd_tar_lim), q - v.p.pd_tar_lim);
         v.b.pd_target[e * NDOF + a] = tar;
-        v.ctrl[(CT_PD + a) * N + e] = tar;
+        v.ctrl[CIDX(CT_PD + a)] = tar;
     } else if (a == NDOF || a == NDOF + 3) {
         // residual root wrench, rotated into the heading frame of the root body
         float a1 = dead ? 0.f : actions[tid + 1], a2 = dead ? 0.f : actions[tid + 2];
@@ -357,7 +357,7 @@ __global__ void env_pre_kernel(EnvView v, float* __restrict__ actions) {
         Q4 hq = ref_heading_quat(ref_calc_heading(rq));
         V3 w = ref_quat_rotate(hq, V3{act * sc, a1 * sc, a2 * sc});
         int base = a == NDOF ? CT_FORCE : CT_TORQUE;
-        v.ctrl[(base + 0) * N + e] = w.x; v.ctrl[(base + 1) * N + e] = w.y; v.ctrl[(base + 2) * N + e] = w.z;
+        v.ctrl[CIDX(base + 0)] = w.x; v.ctrl[CIDX(base + 1)] = w.y; v.ctrl[CIDX(base + 2)] = w.z;
     }
 }
 
@@ -378,21 +378,21 @@ __global__ __launch_bounds__(EB_BLOCK) void env_export_kernel(EnvView v) {
     const int64_t N = v.n;
     float* rb = v.b.rb_state + (e * NB + j) * 13;
 #pragma unroll
-    for (int k = 0; k < 13; ++k) rb[k] = v.out[(OUT_RB + j * 13 + k) * N + e];
+    for (int k = 0; k < 13; ++k) rb[k] = v.out[OIDX(OUT_RB + j * 13 + k)];
     float* cf = v.b.contact_force + (e * NB + j) * 3;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) cf[k] = v.out[(OUT_CONTACT + j * 3 + k) * N + e];
+    for (int k = 0; k < 3; ++k) cf[k] = v.out[OIDX(OUT_CONTACT + j * 3 + k)];
     if (j == 0) {
         float* r = v.b.root_states + e * 13;
 #pragma unroll
-        for (int k = 0; k < 13; ++k) r[k] = v.out[(OUT_RB + k) * N + e];
+        for (int k = 0; k < 13; ++k) r[k] = v.out[OIDX(OUT_RB + k)];
     } else {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             int d = 3 * (j - 1) + k;
-            v.b.dof_state[(e * NDOF + d) * 2] = v.out[(OUT_DOF_POS + d) * N + e];
-            v.b.dof_state[(e * NDOF + d) * 2 + 1] = v.state[(ST_VEL + 6 + d) * N + e];
-            v.b.dof_force[e * NDOF + d] = v.out[(OUT_DOF_FORCE + d) * N + e];
+            v.b.dof_state[(e * NDOF + d) * 2] = v.out[OIDX(OUT_DOF_POS + d)];
+            v.b.dof_state[(e * NDOF + d) * 2 + 1] = v.state[SIDX(ST_VEL + 6 + d)];
+            v.b.dof_force[e * NDOF + d] = v.out[OIDX(OUT_DOF_FORCE + d)];
         }
     }
 }
@@ -413,18 +413,18 @@ __global__ __launch_bounds__(EB_BLOCK) void env_push_state_kernel(EnvView v, con
     const int64_t N = v.n;
     if (j == 0) {
         const float* r = v.b.root_states + e * 13;
-        for (int k = 0; k < 3; ++k) v.state[(ST_ROOT_POS + k) * N + e] = r[k];
+        for (int k = 0; k < 3; ++k) v.state[SIDX(ST_ROOT_POS + k)] = r[k];
         Q4 q = qnormalize(ld4(r + 3));
-        v.state[(ST_ROOT_QUAT + 0) * N + e] = q.x; v.state[(ST_ROOT_QUAT + 1) * N + e] = q.y;
-        v.state[(ST_ROOT_QUAT + 2) * N + e] = q.z; v.state[(ST_ROOT_QUAT + 3) * N + e] = q.w;
-        for (int k = 0; k < 6; ++k) v.state[(ST_VEL + k) * N + e] = r[7 + k];
+        v.state[SIDX(ST_ROOT_QUAT + 0)] = q.x; v.state[SIDX(ST_ROOT_QUAT + 1)] = q.y;
+        v.state[SIDX(ST_ROOT_QUAT + 2)] = q.z; v.state[SIDX(ST_ROOT_QUAT + 3)] = q.w;
+        for (int k = 0; k < 6; ++k) v.state[SIDX(ST_VEL + k)] = r[7 + k];
     } else {
         const float* d = v.b.dof_state + (e * NDOF + 3 * (j - 1)) * 2;
         Q4 jq = ref_exp_map_to_quat(V3{d[0], d[2], d[4]});
         int base = ST_JQUAT + 4 * (j - 1);
-        v.state[(base + 0) * N + e] = jq.x; v.state[(base + 1) * N + e] = jq.y; v.state[(base + 2) * N + e] = jq.z; v.state[(base + 3) * N + e] = jq.w;
+        v.state[SIDX(base + 0)] = jq.x; v.state[SIDX(base + 1)] = jq.y; v.state[SIDX(base + 2)] = jq.z; v.state[SIDX(base + 3)] = jq.w;
         int vb = ST_VEL + 6 + 3 * (j - 1);
-        v.state[(vb + 0) * N + e] = d[1]; v.state[(vb + 1) * N + e] = d[3]; v.state[(vb + 2) * N + e] = d[5];
+        v.state[SIDX(vb + 0)] = d[1]; v.state[SIDX(vb + 1)] = d[3]; v.state[SIDX(vb + 2)] = d[5];
     }
 }
 

@@ -101,9 +101,9 @@ struct v2p_env {
     int cur_target;           // index of the current target buffer
     int schedule;             // 0 = link per lane (physics_ll.hip), 1 = env per lane (physics.hip)
     const int64_t* motion_id; // [N] device (borrowed)
-    float* state;             // SoA [STATE_SLOTS][N]
-    float* ctrl;              // SoA [CTRL_SLOTS][N]: pd target 69, wrench 6
-    float* out;               // SoA [OUT_SLOTS][N]: physics outputs before export
+    float* state;             // [N][STATE_SLOTS]
+    float* ctrl;              // [N][CTRL_SLOTS]: pd target 69, wrench 6
+    float* out;               // [N][OUT_SLOTS]: physics outputs before export
     float* ws;                // SoA [WS_SLOTS][N] physics workspace
     int32_t* contact_ids;     // [N,24,4] debug
     long long* prof;          // [8] phase cycle counters when V2P_PHASE_TIMING is set (device), else NULL
@@ -117,6 +117,12 @@ constexpr int CT_PD = 0, CT_FORCE = NDOF, CT_TORQUE = NDOF + 3, CTRL_SLOTS = NDO
 // physics outputs (SoA): rigid-body state 24x13, dof_pos 69, contact force 72, dof force 69
 constexpr int OUT_RB = 0, OUT_DOF_POS = NB * 13, OUT_CONTACT = OUT_DOF_POS + NDOF, OUT_DOF_FORCE = OUT_CONTACT + NB * 3,
               OUT_SLOTS = OUT_DOF_FORCE + NDOF;
+
+// engine-owned arrays are ENV-MAJOR: [env][slot].  One workgroup of the link-per-lane kernel owns whole envs, so its
+// loads/stores stay inside one XCD's L2 and merge into full lines (slot-major put every line under 8 XCDs: 4x write traffic)
+#define SIDX(slot) ((int64_t)e * v2p::STATE_SLOTS + (slot))
+#define CIDX(slot) ((int64_t)e * v2p::CTRL_SLOTS + (slot))
+#define OIDX(slot) ((int64_t)e * v2p::OUT_SLOTS + (slot))
 
 void set_error(const char* fmt, ...);
 int check_hip(hipError_t e, const char* what);
