@@ -35,11 +35,22 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     objs = []
-    flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-function"]
+    # -fno-slp-vectorize: the SLP vectoriser packs adjacent fp32 ops into v_pk_* on 64-bit register pairs, which costs the
+    # physics kernels ~160 registers of pressure (1 instead of 2 waves/SIMD) and is slower next to dependent chains anyway
+    flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-fno-vectorize", "-fno-slp-vectorize", "-Wall",
+             "-Wno-unused-function"]
     procs = []
     for s in SOURCES:
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
-        cmd = [_hipcc()] + flags + ["-c", os.path.join(CSRC, s), "-o", obj]
+        fl = list(flags)
+        if s in ("motion_state.hip", "task_ops.hip"):
+            # the task-side kernels restate torch elementwise code: no FMA contraction, so that ill-conditioned spots of the
+            # reference itself (acos of a dot product next to 1 in slerp / angle-axis) round the way torch rounds them
+            fl = [f if f != "-ffp-contract=fast" else "-ffp-contract=off" for f in fl]
+        extra = os.environ.get("V2P_FLAGS_" + s.split(".")[0].upper())  # experiments: per-file flag override, e.g. V2P_FLAGS_PHYSICS_LL="-O1"
+        if extra:
+            fl = [f for f in fl if f != "-O3"] + extra.split()
+        cmd = [_hipcc()] + fl + ["-c", os.path.join(CSRC, s), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -85,7 +85,7 @@ __device__ __forceinline__ V3 mask(bool c, V3 a) { return V3{c ? a.x : 0.f, c ? 
 #define LLPH(k) do { if (a.prof) { long long t_ = clock64(); if (blockIdx.x == 0 && lane == 0) atomicAdd((unsigned long long*)&a.prof[k], (unsigned long long)(t_ - tprev)); tprev = t_; } } while (0)
 
 template <bool CONTACT>
-__global__ __launch_bounds__(64) void physics_ll_kernel(PhysArgs a) {
+__global__ __launch_bounds__(64, 2) void physics_ll_kernel(PhysArgs a) {
     const int64_t N = a.n;
     const int lane = threadIdx.x;
     const int half = lane >> 5;
@@ -120,14 +120,7 @@ __global__ __launch_bounds__(64) void physics_ll_kernel(PhysArgs a) {
     const int c0 = M.children[b][0], c1 = M.children[b][1], c2 = M.children[b][2];
     const bool has0 = valid && c0 >= 0, has1 = valid && c1 >= 0, has2 = valid && c2 >= 0;
     const int cl0 = has0 ? base + c0 : lane, cl1 = has1 ? base + c1 : lane, cl2 = has2 ? base + c2 : lane;
-    const V3 lpos{M.local_pos[b][0], M.local_pos[b][1], M.local_pos[b][2]};
-    const float mass = M.mass[b];
-    const V3 com{M.com[b][0], M.com[b][1], M.com[b][2]};
-    const Sym3 Ib{M.inertia[b][0], M.inertia[b][1], M.inertia[b][2], M.inertia[b][3], M.inertia[b][4], M.inertia[b][5]};
-    const float kp = M.kp[b], kd = M.kd[b];
     const float aug = P.aug[b];
-    const int v0 = M.hull_offsets[b], nv = M.hull_count[b];
-    const float brad = M.bound_radius[b];
     const int desc = M.desc_mask[b];  // links of the subtree rooted here (self included)
 
     // ---- state: the root lane carries the root pose/velocity, every other lane its joint
@@ -147,12 +140,17 @@ __global__ __launch_bounds__(64) void physics_ll_kernel(PhysArgs a) {
 
     long long tprev = a.prof ? clock64() : 0;
     V3 r{0.f, 0.f, 0.f};
-    V3 cforce{0.f, 0.f, 0.f}, dofforce{0.f, 0.f, 0.f};
 
     for (int sub = 0; sub < P.nsub; ++sub) {
         const bool wrench_on = sub < P.hold_sub;
         const bool last = sub == P.nsub - 1;
         LLPH(0);
+        // per-link model constants are (re)loaded where they are used (L1/K$ hits) instead of pinning ~20 registers for the whole
+        // kernel; the opaque index keeps the compiler from hoisting the loads back out of the substep loop
+        int bo = b;
+        asm volatile("" : "+v"(bo));
+        const V3 lpos{M.local_pos[bo][0], M.local_pos[bo][1], M.local_pos[bo][2]};
+        const float kp = M.kp[bo], kd = M.kd[bo];
         // ================================================================ pass 1: kinematics, root -> leaves by level
         V3 zw{0.f, 0.f, 0.f}, zv{0.f, 0.f, 0.f};
         for (int d = 1; d <= maxd; ++d) {
@@ -172,6 +170,11 @@ __global__ __launch_bounds__(64) void physics_ll_kernel(PhysArgs a) {
             }
         }
         // ---- per link, all lanes at once: joint torque, body inertia at its origin (world axes), bias force
+        // mass properties are needed once per substep: reload them (L1/K$ hits) instead of pinning 10 registers for the
+        // whole kernel; the opaque index keeps the loads from being hoisted back out of the loop
+        const float mass = M.mass[bo];
+        const V3 com{M.com[bo][0], M.com[bo][1], M.com[bo][2]};
+        const Sym3 Ib{M.inertia[bo][0], M.inertia[bo][1], M.inertia[bo][2], M.inertia[bo][3], M.inertia[bo][4], M.inertia[bo][5]};
         V3 tau{0.f, 0.f, 0.f};
         Sym3 A;
         M3 B;
@@ -331,7 +334,8 @@ __global__ __launch_bounds__(64) void physics_ll_kernel(PhysArgs a) {
             // pass A marks the candidate vertices (z < contact_offset) in a per-lane 64-bit mask; the manifold reduction then
             // walks only the candidates.  Hull vertices come from the LDS copy of the model (staged once per launch).
             const float coff = P.contact_offset;
-            const bool near = valid && (x.z - brad < coff);
+            const int v0 = M.hull_offsets[bo], nv = M.hull_count[bo];
+            const bool near = valid && (x.z - M.bound_radius[bo] < coff);
             int sel4[4] = {-1, -1, -1, -1};
             if (__any(near)) {
                 const M3 R = q2mat(q);
@@ -609,7 +613,11 @@ __global__ __launch_bounds__(64) void physics_ll_kernel(PhysArgs a) {
             if (b != 0) {
                 V3 wn = mulT(q2mat(q), w - pw);               // joint rate, body axes (undamped)
                 Q4 jold = qnormalize(qmul(qconj(pq), q));  // joint quaternion of the old configuration
-                if (last) dofforce = kp * (tar - quat_to_expmap_stable(jold) - h * wn) - kd * wn;
+                if (last && valid && live_env) {  // joint drive torque actually applied over the substep (implicit form)
+                    V3 tf = kp * (tar - quat_to_expmap_stable(jold) - h * wn) - kd * wn;
+                    const int of = OUT_DOF_FORCE + 3 * (b - 1);
+                    a.out[OIDX(of + 0)] = tf.x; a.out[OIDX(of + 1)] = tf.y; a.out[OIDX(of + 2)] = tf.z;
+                }
                 wn = sc * wn;
                 float n2 = dot(wn, wn);
                 if (n2 > wmax * wmax) wn = (wmax * rsqrtf(n2)) * wn;
@@ -624,16 +632,24 @@ __global__ __launch_bounds__(64) void physics_ll_kernel(PhysArgs a) {
                 q = qnormalize(qmul(rotvec_to_quat(h * w0), q));  // world-frame rate: left multiply
             }
         }
-        if (CONTACT && last) {
-            const float ih = 1.f / h;
+        if (last && valid && live_env) {
+            // net contact force per body = sum of impulses / h  (refresh_net_contact_force_tensor)
+            V3 cforce{0.f, 0.f, 0.f};
+            if (CONTACT) {
+                const float ih = 1.f / h;
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (c < cnt) { cforce.z += clam[c].x * ih; cforce.x += clam[c].y * ih; cforce.y += clam[c].z * ih; }
+                for (int c = 0; c < 4; ++c)
+                    if (c < cnt) { cforce.z += clam[c].x * ih; cforce.x += clam[c].y * ih; cforce.y += clam[c].z * ih; }
+            }
+            a.out[OIDX(OUT_CONTACT + 3 * b + 0)] = cforce.x;
+            a.out[OIDX(OUT_CONTACT + 3 * b + 1)] = cforce.y;
+            a.out[OIDX(OUT_CONTACT + 3 * b + 2)] = cforce.z;
         }
     }
 
     LLPH(7);
     // ==================================================================== final kinematics -> state, rigid-body state, dof_pos
+    const V3 lpos{M.local_pos[b][0], M.local_pos[b][1], M.local_pos[b][2]};
     for (int d = 1; d <= maxd; ++d) {
         const bool nc = (nonchain >> d) & 1;
         Q4 pq = pp(q, nc);
@@ -657,18 +673,14 @@ __global__ __launch_bounds__(64) void physics_ll_kernel(PhysArgs a) {
             st[SIDX(jb + 0)] = jq.x; st[SIDX(jb + 1)] = jq.y; st[SIDX(jb + 2)] = jq.z; st[SIDX(jb + 3)] = jq.w;
             st[SIDX(vb + 0)] = wt.x; st[SIDX(vb + 1)] = wt.y; st[SIDX(vb + 2)] = wt.z;
             V3 qe = quat_to_expmap_stable(jq);
-            const int op = OUT_DOF_POS + 3 * (b - 1), of = OUT_DOF_FORCE + 3 * (b - 1);
+            const int op = OUT_DOF_POS + 3 * (b - 1);
             a.out[OIDX(op + 0)] = qe.x; a.out[OIDX(op + 1)] = qe.y; a.out[OIDX(op + 2)] = qe.z;
-            a.out[OIDX(of + 0)] = dofforce.x; a.out[OIDX(of + 1)] = dofforce.y; a.out[OIDX(of + 2)] = dofforce.z;
         }
         const int ob = OUT_RB + 13 * b;
         a.out[OIDX(ob + 0)] = x.x; a.out[OIDX(ob + 1)] = x.y; a.out[OIDX(ob + 2)] = x.z;
         a.out[OIDX(ob + 3)] = q.x; a.out[OIDX(ob + 4)] = q.y; a.out[OIDX(ob + 5)] = q.z; a.out[OIDX(ob + 6)] = q.w;
         a.out[OIDX(ob + 7)] = xd.x; a.out[OIDX(ob + 8)] = xd.y; a.out[OIDX(ob + 9)] = xd.z;
         a.out[OIDX(ob + 10)] = w.x; a.out[OIDX(ob + 11)] = w.y; a.out[OIDX(ob + 12)] = w.z;
-        a.out[OIDX(OUT_CONTACT + 3 * b + 0)] = cforce.x;
-        a.out[OIDX(OUT_CONTACT + 3 * b + 1)] = cforce.y;
-        a.out[OIDX(OUT_CONTACT + 3 * b + 2)] = cforce.z;
     }
 }
 
