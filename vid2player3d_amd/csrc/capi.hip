@@ -100,6 +100,8 @@ int v2p_model_create(const v2p_model_desc* d, int device, v2p_model** out) {
             off += np;
         }
         h.hull_offsets[NB] = off;
+        h.hull_cofs[0] = 0;
+        for (int b = 0; b < NB; ++b) h.hull_cofs[b + 1] = h.hull_cofs[b] + h.hull_count[b];
     }
     {
         int k = 0;

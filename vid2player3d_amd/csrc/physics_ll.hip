@@ -105,10 +105,13 @@ __global__ __launch_bounds__(64, 2) void physics_ll_kernel(PhysArgs a) {
     const int nonchain = M.nonchain_levels;
 
     // ---- hull vertices of the (lane-uniform) body model -> LDS, padded to float4: per-lane gathers in contact generation
-    __shared__ float4 hv[MAX_HULL_VERTS];
+    // (unpadded copy, dynamic size: 1182 x 16 B = 18.5 KB lets 8 workgroups = 2 waves per SIMD share a CU's 160 KB)
+    extern __shared__ float4 hv[];
     if (CONTACT) {
-        const int nhv = M.hull_offsets[NB];
-        for (int i = lane; i < nhv; i += 64) hv[i] = make_float4(M.hull_verts[i][0], M.hull_verts[i][1], M.hull_verts[i][2], 0.f);
+        for (int bb = 0; bb < NB; ++bb) {
+            const int src = M.hull_offsets[bb], dst = M.hull_cofs[bb], n = M.hull_count[bb];
+            for (int i = lane; i < n; i += 64) hv[dst + i] = make_float4(M.hull_verts[src + i][0], M.hull_verts[src + i][1], M.hull_verts[src + i][2], 0.f);
+        }
         __syncthreads();
     }
 
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(64, 2) void physics_ll_kernel(PhysArgs a) {
             // pass A marks the candidate vertices (z < contact_offset) in a per-lane 64-bit mask; the manifold reduction then
             // walks only the candidates.  Hull vertices come from the LDS copy of the model (staged once per launch).
             const float coff = P.contact_offset;
-            const int v0 = M.hull_offsets[bo], nv = M.hull_count[bo];
+            const int v0 = M.hull_cofs[bo], nv = M.hull_count[bo];
             const bool near = valid && (x.z - M.bound_radius[bo] < coff);
             int sel4[4] = {-1, -1, -1, -1};
             if (__any(near)) {
@@ -696,8 +699,9 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s) {
     a.n = env->n;
     a.p = env->p;
     unsigned blocks = (unsigned)((env->n + 1) / 2);
+    const size_t lds = env->p.enable_contact ? sizeof(float4) * (size_t)env->model->host.hull_cofs[NB] : 0;
     if (env->p.enable_contact)
-        hipLaunchKernelGGL(physics_ll_kernel<true>, dim3(blocks), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(physics_ll_kernel<true>, dim3(blocks), dim3(64), lds, s, a);
     else
         hipLaunchKernelGGL(physics_ll_kernel<false>, dim3(blocks), dim3(64), 0, s, a);
     return check_hip(hipGetLastError(), "physics_ll_kernel");

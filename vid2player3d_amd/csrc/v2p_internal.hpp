@@ -45,6 +45,7 @@ struct DevModel {
     float bound_radius[NB];  // max |hull vertex| (contact culling)
     int32_t hull_offsets[NB + 1];  // into hull_verts; every body's list is padded to a multiple of HULL_PAD (last vertex repeated)
     int32_t hull_count[NB];        // real vertex count per body
+    int32_t hull_cofs[NB + 1];     // offsets of the unpadded lists (LDS copy of the link-per-lane kernel)
     float hull_verts[MAX_HULL_VERTS][3];
 };
 
