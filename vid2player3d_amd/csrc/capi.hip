@@ -321,6 +321,7 @@ int v2p_env_physics(v2p_env* e, void* stream) {
 
 int v2p_env_export(v2p_env* e, void* stream) {
     if (!e) { set_error("v2p_env_export: bad argument"); return V2P_ERR_INVALID; }
+    if (e->schedule == 0) return V2P_OK;  // the link-per-lane kernel writes the exposed tensors itself
     DeviceGuard g(e->device);
     return launch_env_export(e, (hipStream_t)stream);
 }

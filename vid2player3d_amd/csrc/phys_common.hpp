@@ -24,6 +24,12 @@ struct PhysArgs {
     float* __restrict__ out;
     float* __restrict__ ws;
     int32_t* __restrict__ contact_ids;
+    // the caller's row-major tensors (link-per-lane kernel writes them directly: lane = body gives contiguous rows)
+    float* __restrict__ x_root;     // [N,13]
+    float* __restrict__ x_dof;      // [N,69,2]
+    float* __restrict__ x_rb;       // [N,24,13]
+    float* __restrict__ x_contact;  // [N,24,3]
+    float* __restrict__ x_dof_force;  // [N,69]
     long long* prof;  // optional cycle counters per phase (block 0), NULL = off
     unsigned long long par_pack[2];  // parents[24] and level order[24], 5 bits each, 12 per word: the tree walks of the
     unsigned long long ord_pack[2];  // impulse sweep decode them with scalar ALU ops instead of dependent scalar loads

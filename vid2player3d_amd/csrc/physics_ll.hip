@@ -618,8 +618,8 @@ __global__ __launch_bounds__(64, 2) void physics_ll_kernel(PhysArgs a) {
                 Q4 jold = qnormalize(qmul(qconj(pq), q));  // joint quaternion of the old configuration
                 if (last && valid && live_env) {  // joint drive torque actually applied over the substep (implicit form)
                     V3 tf = kp * (tar - quat_to_expmap_stable(jold) - h * wn) - kd * wn;
-                    const int of = OUT_DOF_FORCE + 3 * (b - 1);
-                    a.out[OIDX(of + 0)] = tf.x; a.out[OIDX(of + 1)] = tf.y; a.out[OIDX(of + 2)] = tf.z;
+                    float* of = a.x_dof_force + e * NDOF + 3 * (b - 1);
+                    of[0] = tf.x; of[1] = tf.y; of[2] = tf.z;
                 }
                 wn = sc * wn;
                 float n2 = dot(wn, wn);
@@ -644,9 +644,8 @@ __global__ __launch_bounds__(64, 2) void physics_ll_kernel(PhysArgs a) {
                 for (int c = 0; c < 4; ++c)
                     if (c < cnt) { cforce.z += clam[c].x * ih; cforce.x += clam[c].y * ih; cforce.y += clam[c].z * ih; }
             }
-            a.out[OIDX(OUT_CONTACT + 3 * b + 0)] = cforce.x;
-            a.out[OIDX(OUT_CONTACT + 3 * b + 1)] = cforce.y;
-            a.out[OIDX(OUT_CONTACT + 3 * b + 2)] = cforce.z;
+            float* oc = a.x_contact + (e * NB + b) * 3;
+            oc[0] = cforce.x; oc[1] = cforce.y; oc[2] = cforce.z;
         }
     }
 
@@ -675,15 +674,24 @@ __global__ __launch_bounds__(64, 2) void physics_ll_kernel(PhysArgs a) {
             const int jb = ST_JQUAT + 4 * (b - 1), vb = ST_VEL + 6 + 3 * (b - 1);
             st[SIDX(jb + 0)] = jq.x; st[SIDX(jb + 1)] = jq.y; st[SIDX(jb + 2)] = jq.z; st[SIDX(jb + 3)] = jq.w;
             st[SIDX(vb + 0)] = wt.x; st[SIDX(vb + 1)] = wt.y; st[SIDX(vb + 2)] = wt.z;
+            // exposed dof state: (exp-map position, joint rate) interleaved like gym's dof state tensor
             V3 qe = quat_to_expmap_stable(jq);
-            const int op = OUT_DOF_POS + 3 * (b - 1);
-            a.out[OIDX(op + 0)] = qe.x; a.out[OIDX(op + 1)] = qe.y; a.out[OIDX(op + 2)] = qe.z;
+            float* od = a.x_dof + (e * NDOF + 3 * (b - 1)) * 2;
+            od[0] = qe.x; od[1] = wt.x; od[2] = qe.y; od[3] = wt.y; od[4] = qe.z; od[5] = wt.z;
         }
-        const int ob = OUT_RB + 13 * b;
-        a.out[OIDX(ob + 0)] = x.x; a.out[OIDX(ob + 1)] = x.y; a.out[OIDX(ob + 2)] = x.z;
-        a.out[OIDX(ob + 3)] = q.x; a.out[OIDX(ob + 4)] = q.y; a.out[OIDX(ob + 5)] = q.z; a.out[OIDX(ob + 6)] = q.w;
-        a.out[OIDX(ob + 7)] = xd.x; a.out[OIDX(ob + 8)] = xd.y; a.out[OIDX(ob + 9)] = xd.z;
-        a.out[OIDX(ob + 10)] = w.x; a.out[OIDX(ob + 11)] = w.y; a.out[OIDX(ob + 12)] = w.z;
+        // rigid-body state row of this link (and the root state = rigid body 0): 13 contiguous floats per lane
+        float* ob = a.x_rb + (e * NB + b) * 13;
+        ob[0] = x.x; ob[1] = x.y; ob[2] = x.z;
+        ob[3] = q.x; ob[4] = q.y; ob[5] = q.z; ob[6] = q.w;
+        ob[7] = xd.x; ob[8] = xd.y; ob[9] = xd.z;
+        ob[10] = w.x; ob[11] = w.y; ob[12] = w.z;
+        if (b == 0) {
+            float* orr = a.x_root + e * 13;
+            orr[0] = x.x; orr[1] = x.y; orr[2] = x.z;
+            orr[3] = q.x; orr[4] = q.y; orr[5] = q.z; orr[6] = q.w;
+            orr[7] = xd.x; orr[8] = xd.y; orr[9] = xd.z;
+            orr[10] = w.x; orr[11] = w.y; orr[12] = w.z;
+        }
     }
 }
 
@@ -695,6 +703,11 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s) {
     a.out = env->out;
     a.ws = env->ws;
     a.contact_ids = env->contact_ids;
+    a.x_root = env->buf.root_states;
+    a.x_dof = env->buf.dof_state;
+    a.x_rb = env->buf.rb_state;
+    a.x_contact = env->buf.contact_force;
+    a.x_dof_force = env->buf.dof_force;
     a.prof = env->prof;
     a.n = env->n;
     a.p = env->p;
