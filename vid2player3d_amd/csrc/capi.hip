@@ -294,7 +294,11 @@ void v2p_env_destroy(v2p_env* e) {
     if (e->prof) {
         long long h[16];
         if (hipMemcpy(h, e->prof, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess)
-            fprintf(stderr, "[v2p phase cycles, block 0] stage+pdload %lld pass1 %lld pass2 %lld root+pass3 %lld contacts %lld lambda %lld pgs %lld integrate %lld | block updates %lld touched-sum %lld substeps %lld | pgs: rows %lld back %lld root %lld fwd %lld\n",
+            fprintf(stderr,
+                    "[v2p phase cycles, workgroup 0] link-per-lane: counter k = phase k-1 of {pass1, pass2, root+pass3, contacts, lambda, sweep, "
+                    "integrate}; env-per-lane: {stage, pass1, pass2, root+pass3, contacts, lambda, sweep, integrate}: "
+                    "%lld %lld %lld %lld %lld %lld %lld %lld | block updates %lld touched-sum %lld substeps %lld | "
+                    "sweep: rows %lld up %lld root %lld down %lld\n",
                     h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11], h[12], h[13], h[14]);
         (void)hipFree(e->prof);
     }

@@ -9,8 +9,10 @@
 //   * the block Gauss-Seidel sweep visits, per environment, only the bodies that environment touches
 //     (k-th touched body of both environments at once), and the impulse propagation is again level
 //     synchronous: leaf -> root along the path, root -> leaves for every link
-//   * no LDS or global workspace: the kernel reads the state once, keeps it in registers for the 4
-//     substeps and writes it once
+//   * no global workspace: the kernel reads the state once, keeps it in registers for the 4 substeps and
+//     writes the state and the caller's row-major tensors once (lane = body gives contiguous rows); LDS
+//     only holds a copy of the hull vertices of the body model
+//   * 256 VGPRs, 2 waves per SIMD (needs -fno-slp-vectorize: SLP packing costs ~160 registers here)
 //
 // The sequential semantics of the Gauss-Seidel sweep (bodies ascending, points in slot order, rows
 // n, t1, t2) are unchanged, so results agree with the one-env-per-lane kernel to rounding.
@@ -38,9 +40,9 @@ __device__ __forceinline__ M3 pull(const M3& a, int s) {
     for (int i = 0; i < 9; ++i) r.m[i] = pull(a.m[i], s);
     return r;
 }
-// lane i <- lane i-1 / lane i+1 through the DPP network (VALU speed, no LDS round trip); links are in depth-first order,
-// so the parent of a chain link is the previous lane and the first child of any link is the next lane
-__device__ __forceinline__ float from_prev(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false)); }
+// lane i <- lane i+1 through the DPP network (wave_shl:1, VALU speed, no LDS round trip): links are in depth-first order, so the
+// first child of any link is the next lane.  (The mirror image for parents, wave_shr:1 + a select against the non-chain links,
+// measured slower than a plain ds_bpermute and is not used.)
 __device__ __forceinline__ float from_next(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false)); }
 __device__ __forceinline__ V3 from_next(V3 v) { return V3{from_next(v.x), from_next(v.y), from_next(v.z)}; }
 __device__ __forceinline__ Sym3 from_next(const Sym3& a) {
@@ -52,14 +54,11 @@ __device__ __forceinline__ M3 from_next(const M3& a) {
     for (int i = 0; i < 9; ++i) r.m[i] = from_next(a.m[i]);
     return r;
 }
-// value of the parent lane: DPP for chain links, ds_bpermute only on the levels that have a link whose parent is not the previous lane
+// value held by the parent lane (ds_bpermute); the level flag is kept in the signature for schedule experiments
 struct ParentPull {
     int plane;
     bool chain;
-    __device__ __forceinline__ float operator()(float v, bool lvl_nonchain) const {
-        (void)lvl_nonchain;
-        return pull(v, plane);
-    }
+    __device__ __forceinline__ float operator()(float v, bool) const { return pull(v, plane); }
     __device__ __forceinline__ V3 operator()(V3 v, bool l) const { return V3{(*this)(v.x, l), (*this)(v.y, l), (*this)(v.z, l)}; }
     __device__ __forceinline__ Q4 operator()(Q4 q, bool l) const { return Q4{(*this)(q.x, l), (*this)(q.y, l), (*this)(q.z, l), (*this)(q.w, l)}; }
     __device__ __forceinline__ Sym3 operator()(const Sym3& a, bool l) const {
@@ -72,7 +71,6 @@ struct ParentPull {
         return r;
     }
 };
-__device__ __forceinline__ V3 sel(bool c, V3 a, V3 b) { return V3{c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z}; }
 __device__ __forceinline__ Sym3 operator+(const Sym3& a, const Sym3& b) {
     return Sym3{a.xx + b.xx, a.xy + b.xy, a.xz + b.xz, a.yy + b.yy, a.yz + b.yz, a.zz + b.zz};
 }
@@ -122,7 +120,7 @@ __global__ __launch_bounds__(64, 2) void physics_ll_kernel(PhysArgs a) {
     const int dep = valid ? M.depth[b] : 99;
     const int c0 = M.children[b][0], c1 = M.children[b][1], c2 = M.children[b][2];
     const bool has0 = valid && c0 >= 0, has1 = valid && c1 >= 0, has2 = valid && c2 >= 0;
-    const int cl0 = has0 ? base + c0 : lane, cl1 = has1 ? base + c1 : lane, cl2 = has2 ? base + c2 : lane;
+    const int cl1 = has1 ? base + c1 : lane, cl2 = has2 ? base + c2 : lane;
     const float aug = P.aug[b];
     const int desc = M.desc_mask[b];  // links of the subtree rooted here (self included)
 

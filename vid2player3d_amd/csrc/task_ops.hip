@@ -254,7 +254,6 @@ __global__ __launch_bounds__(EB_BLOCK) void env_reset_kernel(EnvView v, const in
     float t0 = motion_times[i];
     FrameRef fr = frame_lookup(v.t, mid, t0, 1, v.p.ground_tolerance);
     BodySample s = sample_body_values(v.t, fr, j);
-    const int64_t N = v.n;
     // exposed tensors
     float* rb = v.b.rb_state + (e * NB + j) * 13;
     st3(rb, s.pos);
@@ -340,7 +339,6 @@ __global__ void env_pre_kernel(EnvView v, float* __restrict__ actions) {
     int64_t e = tid / NACT;
     int a = (int)(tid - e * NACT);
     if (e >= v.n) return;
-    const int64_t N = v.n;
     bool dead = v.b.reset[e] == 1;
     float act = actions[tid];
     if (dead) { act = 0.f; actions[tid] = 0.f; }  // in place on the caller's tensor, like the reference
@@ -375,7 +373,6 @@ __global__ __launch_bounds__(EB_BLOCK) void env_export_kernel(EnvView v) {
     int le = threadIdx.x / NB, j = threadIdx.x % NB;
     int64_t e = (int64_t)blockIdx.x * ENVS_PER_BLOCK + le;
     if (e >= v.n) return;
-    const int64_t N = v.n;
     float* rb = v.b.rb_state + (e * NB + j) * 13;
 #pragma unroll
     for (int k = 0; k < 13; ++k) rb[k] = v.out[OIDX(OUT_RB + j * 13 + k)];
@@ -410,7 +407,6 @@ __global__ __launch_bounds__(EB_BLOCK) void env_push_state_kernel(EnvView v, con
     int64_t i = (int64_t)blockIdx.x * ENVS_PER_BLOCK + le;
     if (i >= n) return;
     int64_t e = env_ids ? env_ids[i] : i;
-    const int64_t N = v.n;
     if (j == 0) {
         const float* r = v.b.root_states + e * 13;
         for (int k = 0; k < 3; ++k) v.state[SIDX(ST_ROOT_POS + k)] = r[k];
