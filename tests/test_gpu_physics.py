@@ -22,9 +22,9 @@ def mlib():
     return MotionLib(synth_tables(seed=5, num_clips=8, min_frames=60, max_frames=120), DEV)
 
 
-def _run_pair(mlib, n, contact, seed, lift=0.0, vel_sigma=0.5, steps=1):
+def _run_pair(mlib, n, contact, seed, lift=0.0, vel_sigma=0.5, steps=1, hold="first_sim"):
     rng = np.random.default_rng(seed)
-    task = make_task(n, mlib, enable_contact=contact)
+    task = make_task(n, mlib, enable_contact=contact, residual_force_hold=hold)
     times = T(rng.uniform(0.1, 1.0, size=n))
     task.reset_with_times(None, times)
     # perturb the reference state so that the drives, Coriolis terms and contacts all have work to do
@@ -58,7 +58,7 @@ def _run_pair(mlib, n, contact, seed, lift=0.0, vel_sigma=0.5, steps=1):
         close(pd_tar, pd_ref, 1e-6, "pd target")
         res = {"root": [], "dpos": [], "dvel": [], "rb": [], "cf": [], "df": [], "ids": []}
         for e in range(n):
-            cf, df, ids = oracles[e].step(pd_target=pd_tar[e], ext_force=force[e], ext_torque=torque[e], nsub=4, hold=2)
+            cf, df, ids = oracles[e].step(pd_target=pd_tar[e], ext_force=force[e], ext_torque=torque[e], nsub=4, hold=2 if hold == "first_sim" else 4)
             r, p, v, rb = oracles[e].get_state()
             for k, x in zip(("root", "dpos", "dvel", "rb", "cf", "df", "ids"), (r, p, v, rb, cf, df, ids)):
                 res[k].append(x)
@@ -90,6 +90,14 @@ def test_pd_only_step_matches_oracle(mlib):
     (got, ref), = _run_pair(mlib, 32, contact=False, seed=1, lift=0.5)
     _compare(got, ref, "no-contact")
     assert np.abs(got["cf"]).max() == 0.0
+
+
+def test_residual_wrench_held_for_all_simulate_calls(mlib):
+    """residual_force_hold='all': the root wrench acts during all 4 substeps (the other reading of Isaac Gym's force lifetime)."""
+    (got, ref), = _run_pair(mlib, 16, contact=False, seed=7, lift=0.5, hold="all")
+    _compare(got, ref, "hold=all")
+    (got2, _), = _run_pair(mlib, 16, contact=False, seed=7, lift=0.5, hold="first_sim")
+    assert np.abs(got["root"][:, 7:10] - got2["root"][:, 7:10]).max() > 1e-4  # and it does change the result
 
 
 def test_contact_step_matches_oracle(mlib):

@@ -159,3 +159,21 @@ def test_partial_reset_only_touches_selected_envs(mlib):
     assert not torch.equal(after[1], before[1]) and not torch.equal(after[6], before[6])
     assert torch.allclose(task._cur_ref_motion_times[ids], torch.tensor([0.5, 0.7], device=DEV))
     task.close()
+
+
+def test_termination_head_height_is_configurable(mlib):
+    """djokovic_im differs from amass_im by terminationHeadHeight (-0.5 instead of 1.0, cfg/djokovic_im.yaml:21): with the head
+    forced below 1 m the amass config terminates, the djokovic config does not."""
+    res = {}
+    for name, hh in (("amass", 1.0), ("djokovic", -0.5)):
+        task = make_task(4, mlib, terminationHeadHeight=hh)
+        task.reset_with_times(None, torch.full((4,), 0.2, device=DEV))
+        a = torch.cat([task._target_dof_pos.clone(), torch.zeros((4, 6), device=DEV)], dim=1).contiguous()
+        for _ in range(3):
+            task.pre_physics_step(a.clone())
+            task._rigid_body_state.view(4, 24, 13)[:, 13, 2] = 0.7   # head at 0.7 m (teacher-forced)
+            task.post_physics_step()
+        res[name] = (N(task.reset_buf).copy(), N(task._terminate_buf).copy())
+        task.close()
+    assert res["amass"][1].all() and res["amass"][0].all()
+    assert not res["djokovic"][1].any() and not res["djokovic"][0].any()
