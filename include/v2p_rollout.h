@@ -117,7 +117,16 @@ int v2p_reset_flags(int64_t n, const int64_t* progress, const float* rb_pos, con
  * root_height_obs = True. */
 int v2p_obs_imitation(int64_t n, const float* body_pos, const float* body_rot, const float* tgt_pos, const float* tgt_rot,
                       const float* dof_pos, const float* dof_vel, const float* tgt_dof_pos, const float* body_vel,
-                      const float* body_ang_vel, const float* motion_bodies /*[n,11]*/, float* obs /*[n,734]*/, void* stream);
+                      const float* body_ang_vel, const float* motion_bodies /*[n,11]*/,
+                      const float* norm_mean /*[734] nullable*/, const float* norm_std /*[734] nullable*/, float norm_clip,
+                      float* obs /*[n,734]*/, void* stream);
+/* ... with RunningNorm.forward in eval mode fused when norm_mean/norm_std are given: clamp((x-mean)/(std+1e-8), +-clip)
+ * (models/running_norm.py:32-43). */
+
+/* GAE reverse scan of the PPO rollout, CommonAgent.discount_values (learning/common_agent.py:423-435):
+ * fdones [T,N], values / rewards / next_values / advs [T,N,1] (device). */
+int v2p_gae(int64_t horizon, int64_t n, const float* fdones, const float* values, const float* rewards, const float* next_values,
+            float gamma, float tau, float* advs, void* stream);
 
 /* ---- environments -----------------------------------------------------------------------
  * Simulation + task parameters (cfg/amass_im.yaml:3-52, utils/config.py:190-222). */

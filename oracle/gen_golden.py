@@ -193,6 +193,25 @@ def gen_task_ops():
     o734 = him.compute_humanoid_observations_imitation(T(body_pos), T(body_rot), T(tgt_pos), T(tgt_rot), T(dof_pos), T(dof_vel), T(tgt_dof_pos), T(body_vel),
                       T(body_ang_vel), T(mb), True, True)
     out.update(obs734_motion_bodies=mb, obs734=npf(o734))
+    # RunningNorm in eval mode on top of it (embodied_pose/models/running_norm.py:32-43)
+    from models.running_norm import RunningNorm
+    rn = RunningNorm(734)
+    rn.train()
+    rn(o734 * 1.0)
+    rn(o734 * 0.5 + 0.1)
+    rn.eval()
+    out.update(rn_mean=npf(rn.mean), rn_std=npf(rn.std), obs734_normed=npf(rn(o734)))
+
+    # GAE scan (embodied_pose/learning/common_agent.py:423-435), called unbound on a stand-in for the agent
+    from learning.common_agent import CommonAgent
+    tt, ne = 32, 40
+    fd = (rng.uniform(size=(tt, ne)) < 0.1).astype(f32)
+    vals = rng.normal(size=(tt, ne, 1)).astype(f32)
+    rews = rng.uniform(0, 1, size=(tt, ne, 1)).astype(f32)
+    nvals = rng.normal(size=(tt, ne, 1)).astype(f32)
+    agent = types.SimpleNamespace(horizon_length=tt, gamma=0.99, tau=0.95)
+    advs = CommonAgent.discount_values(agent, T(fd), T(vals), T(rews), T(nvals))
+    out.update(gae_fdones=fd, gae_values=vals, gae_rewards=rews, gae_next_values=nvals, gae_advs=npf(advs), gae_gamma=np.float32(0.99), gae_tau=np.float32(0.95))
     np.savez_compressed(os.path.join(OUT, "task_ops.npz"), **out)
 
 

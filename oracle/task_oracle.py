@@ -325,6 +325,24 @@ def obs_imitation_734(body_pos, body_rot, tgt_pos, tgt_rot, dof_pos, dof_vel, tg
                            rel_dof, rel_body_pos, rel_body_rot, motion_bodies], axis=-1).astype(F)
 
 
+def running_norm_eval(x, mean, std, clip=5.0):
+    """embodied_pose/models/running_norm.py:32-43 in eval mode with n > 0."""
+    return np.clip((x - mean) / (std + F(1e-8)), -F(clip), F(clip)).astype(F)
+
+
+def discount_values(fdones, values, rewards, next_values, gamma, tau):
+    """GAE reverse scan, embodied_pose/learning/common_agent.py:423-435.  [T,N], [T,N,1] x3 -> [T,N,1]."""
+    t_len = rewards.shape[0]
+    advs = np.zeros_like(rewards)
+    last = np.zeros_like(rewards[0])
+    for t in reversed(range(t_len)):
+        not_done = (F(1) - fdones[t])[:, None]
+        delta = rewards[t] + F(gamma) * next_values[t] - values[t]
+        last = (delta + F(gamma) * F(tau) * not_done * last).astype(F)
+        advs[t] = last
+    return advs
+
+
 # --------------------------------------------------------------------------------------------
 # the task state machine around the physics step
 # --------------------------------------------------------------------------------------------

@@ -52,7 +52,7 @@ def test_collectives_world_size_2():
     full = (np.arange(32 * 12, dtype=np.float32).reshape(32, 12) * 0.37 - 3.0)
     mask = (np.arange(32 * 12).reshape(32, 12) % 5 != 0).astype(np.float64)
     mean = (full * mask).sum() / mask.sum()
-    std = np.sqrt((full.astype(np.float64) ** 2 * mask).sum() / mask.sum() - mean ** 2)
+    std = np.sqrt(((full.astype(np.float64) - mean) ** 2 * mask).sum() / (mask.sum() - 1))  # unbiased, like torch.std
     for rank, gathered, m, s, c, norm, lo, hi in res:
         assert np.array_equal(gathered, full)
         assert abs(m - mean) < 1e-5 and abs(s - std) < 1e-5 and c == mask.sum()

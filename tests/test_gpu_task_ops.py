@@ -103,8 +103,34 @@ def test_obs_imitation_734_matches_reference_golden(golden_task_ops):
     obs = torch.empty((n, 734), device=DEV)
     args = [T(g[k]) for k in ("body_pos", "body_rot", "tgt_pos", "tgt_rot", "dof_pos", "dof_vel", "tgt_dof_pos", "body_vel", "body_ang_vel",
                               "obs734_motion_bodies")]
-    _lib.check(lib.v2p_obs_imitation(n, *[_lib.ptr(a) for a in args], _lib.ptr(obs), None), "v2p_obs_imitation")
+    _lib.check(lib.v2p_obs_imitation(n, *[_lib.ptr(a) for a in args], None, None, 0.0, _lib.ptr(obs), None), "v2p_obs_imitation")
     close(N(obs), g["obs734"], 5e-6, "obs734")
+    # with RunningNorm (eval) fused
+    mean, std = T(g["rn_mean"]), T(g["rn_std"])
+    _lib.check(lib.v2p_obs_imitation(n, *[_lib.ptr(a) for a in args], _lib.ptr(mean), _lib.ptr(std), 5.0, _lib.ptr(obs), None), "v2p_obs_imitation")
+    close(N(obs), g["obs734_normed"], 2e-5, "obs734 normalised")
+
+
+def test_gae_matches_reference_golden(golden_task_ops):
+    from vid2player3d_amd import _lib
+
+    g = golden_task_ops
+    lib = _lib.load()
+    t, n = g["gae_fdones"].shape
+    fd, va, rw, nv = T(g["gae_fdones"]), T(g["gae_values"]), T(g["gae_rewards"]), T(g["gae_next_values"])
+    adv = torch.empty((t, n, 1), device=DEV)
+    _lib.check(lib.v2p_gae(t, n, _lib.ptr(fd), _lib.ptr(va), _lib.ptr(rw), _lib.ptr(nv), float(g["gae_gamma"]), float(g["gae_tau"]), _lib.ptr(adv), None),
+               "v2p_gae")
+    close(N(adv), g["gae_advs"], 2e-6, "gae")
+    # full rollout size: 32 x 8192, against the numpy restatement
+    rng = np.random.default_rng(1)
+    t, n = 32, 8192
+    fd_h = (rng.uniform(size=(t, n)) < 0.05).astype(np.float32)
+    va_h, rw_h, nv_h = (rng.normal(size=(t, n, 1)).astype(np.float32) for _ in range(3))
+    fd, va, rw, nv = T(fd_h), T(va_h), T(rw_h), T(nv_h)
+    adv = torch.empty((t, n, 1), device=DEV)
+    _lib.check(lib.v2p_gae(t, n, _lib.ptr(fd), _lib.ptr(va), _lib.ptr(rw), _lib.ptr(nv), 0.99, 0.95, _lib.ptr(adv), None), "v2p_gae")
+    close(N(adv), O.discount_values(fd_h, va_h, rw_h, nv_h, 0.99, 0.95), 1e-5, "gae 32x8192")
 
 
 def test_env_trace_replay_matches_reference(mlib, golden_env_trace):

@@ -61,6 +61,13 @@ def test_obs734(golden_task_ops):
     close(o, g["obs734"], 5e-6, "obs734")
 
 
+def test_running_norm_and_gae(golden_task_ops):
+    g = golden_task_ops
+    close(T.running_norm_eval(g["obs734"], g["rn_mean"], g["rn_std"]), g["obs734_normed"], 5e-6, "running norm")
+    adv = T.discount_values(g["gae_fdones"], g["gae_values"], g["gae_rewards"], g["gae_next_values"], float(g["gae_gamma"]), float(g["gae_tau"]))
+    close(adv, g["gae_advs"], 2e-6, "gae")
+
+
 def test_env_trace(golden_tables, golden_env_trace):
     """The task state machine replayed against the reference HumanoidSMPLIM trace (teacher-forced physics)."""
     g = golden_env_trace

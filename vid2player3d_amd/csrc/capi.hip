@@ -212,10 +212,17 @@ int v2p_reset_flags(int64_t n, const int64_t* progress, const float* rb_pos, con
 
 int v2p_obs_imitation(int64_t n, const float* body_pos, const float* body_rot, const float* tgt_pos, const float* tgt_rot,
                       const float* dof_pos, const float* dof_vel, const float* tgt_dof_pos, const float* body_vel,
-                      const float* body_ang_vel, const float* motion_bodies, float* obs, void* stream) {
-    if (n < 0) { set_error("v2p_obs_imitation: bad argument"); return V2P_ERR_INVALID; }
+                      const float* body_ang_vel, const float* motion_bodies, const float* norm_mean, const float* norm_std, float norm_clip,
+                      float* obs, void* stream) {
+    if (n < 0 || ((norm_mean == nullptr) != (norm_std == nullptr))) { set_error("v2p_obs_imitation: bad argument"); return V2P_ERR_INVALID; }
     return launch_obs_imitation(n, body_pos, body_rot, tgt_pos, tgt_rot, dof_pos, dof_vel, tgt_dof_pos, body_vel, body_ang_vel,
-                                motion_bodies, obs, (hipStream_t)stream);
+                                motion_bodies, norm_mean, norm_std, norm_clip, obs, (hipStream_t)stream);
+}
+
+int v2p_gae(int64_t horizon, int64_t n, const float* fdones, const float* values, const float* rewards, const float* next_values, float gamma,
+            float tau, float* advs, void* stream) {
+    if (horizon < 0 || n < 0) { set_error("v2p_gae: bad argument"); return V2P_ERR_INVALID; }
+    return launch_gae(horizon, n, fdones, values, rewards, next_values, gamma, tau, advs, (hipStream_t)stream);
 }
 
 int v2p_env_create(const v2p_model* model, const v2p_mlib* mlib, const v2p_sim_cfg* c, const int64_t* env_motion_id, int64_t n,

@@ -143,6 +143,7 @@ __global__ __launch_bounds__(EB_BLOCK) void obs_imitation_kernel(int64_t n, cons
                                                                  const float* __restrict__ dof_pos, const float* __restrict__ dof_vel,
                                                                  const float* __restrict__ tgt_dof_pos, const float* __restrict__ body_vel,
                                                                  const float* __restrict__ body_ang_vel, const float* __restrict__ motion_bodies,
+                                                                 const float* __restrict__ nmean, const float* __restrict__ nstd, float nclip,
                                                                  float* __restrict__ obs) {
     int le = threadIdx.x / NB, j = threadIdx.x % NB;
     int64_t e = (int64_t)blockIdx.x * ENVS_PER_BLOCK + le;
@@ -188,16 +189,51 @@ __global__ __launch_bounds__(EB_BLOCK) void obs_imitation_kernel(int64_t n, cons
         o[436] = cosf(dh); o[437] = sinf(dh);
     }
     if (j < 11) o[723 + j] = motion_bodies[e * 11 + j];
+    if (nmean) {
+        // RunningNorm (eval) fused: the row was just written by this workgroup's 24 threads of env e
+        __syncthreads();
+        for (int k = j; k < 734; k += NB) {
+            float y = (o[k] - nmean[k]) / (nstd[k] + 1e-8f);
+            o[k] = fminf(fmaxf(y, -nclip), nclip);
+        }
+    }
 }
 
 int launch_obs_imitation(int64_t n, const float* body_pos, const float* body_rot, const float* tgt_pos, const float* tgt_rot,
                          const float* dof_pos, const float* dof_vel, const float* tgt_dof_pos, const float* body_vel,
-                         const float* body_ang_vel, const float* motion_bodies, float* obs, hipStream_t s) {
+                         const float* body_ang_vel, const float* motion_bodies, const float* nmean, const float* nstd, float nclip, float* obs,
+                         hipStream_t s) {
     if (n <= 0) return V2P_OK;
     unsigned blocks = (unsigned)((n + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK);
     hipLaunchKernelGGL(obs_imitation_kernel, dim3(blocks), dim3(EB_BLOCK), 0, s, n, body_pos, body_rot, tgt_pos, tgt_rot, dof_pos, dof_vel,
-                       tgt_dof_pos, body_vel, body_ang_vel, motion_bodies, obs);
+                       tgt_dof_pos, body_vel, body_ang_vel, motion_bodies, nmean, nstd, nclip, obs);
     return check_hip(hipGetLastError(), "obs_imitation_kernel");
+}
+
+// ------------------------------------------------------------------------------------------
+// GAE reverse scan (CommonAgent.discount_values, learning/common_agent.py:423-435): one thread per env, T steps
+// ------------------------------------------------------------------------------------------
+__global__ void gae_kernel(int64_t horizon, int64_t n, const float* __restrict__ fdones, const float* __restrict__ values,
+                           const float* __restrict__ rewards, const float* __restrict__ next_values, float gamma, float tau,
+                           float* __restrict__ advs) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    float last = 0.f;
+    for (int64_t t = horizon - 1; t >= 0; --t) {
+        const int64_t i = t * n + e;
+        float not_done = 1.f - fdones[i];
+        float delta = rewards[i] + gamma * next_values[i] - values[i];
+        last = delta + gamma * tau * not_done * last;
+        advs[i] = last;
+    }
+}
+
+int launch_gae(int64_t horizon, int64_t n, const float* fdones, const float* values, const float* rewards, const float* next_values, float gamma,
+               float tau, float* advs, hipStream_t s) {
+    if (n <= 0 || horizon <= 0) return V2P_OK;
+    unsigned blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(gae_kernel, dim3(blocks), dim3(256), 0, s, horizon, n, fdones, values, rewards, next_values, gamma, tau, advs);
+    return check_hip(hipGetLastError(), "gae_kernel");
 }
 
 // ------------------------------------------------------------------------------------------

@@ -138,7 +138,10 @@ int launch_reset_flags(int64_t n, const int64_t* progress, const float* rb_pos, 
                        const float* clip_len, float max_len, int early, int64_t* reset_out, int64_t* term_out, hipStream_t s);
 int launch_obs_imitation(int64_t n, const float* body_pos, const float* body_rot, const float* tgt_pos, const float* tgt_rot,
                          const float* dof_pos, const float* dof_vel, const float* tgt_dof_pos, const float* body_vel,
-                         const float* body_ang_vel, const float* motion_bodies, float* obs, hipStream_t s);
+                         const float* body_ang_vel, const float* motion_bodies, const float* nmean, const float* nstd, float nclip, float* obs,
+                         hipStream_t s);
+int launch_gae(int64_t horizon, int64_t n, const float* fdones, const float* values, const float* rewards, const float* next_values, float gamma,
+               float tau, float* advs, hipStream_t s);
 int launch_env_reset(v2p_env* e, const int64_t* env_ids, int64_t n, const float* motion_times, hipStream_t s);
 int launch_env_pre(v2p_env* e, float* actions, hipStream_t s);
 int launch_env_physics(v2p_env* e, hipStream_t s);

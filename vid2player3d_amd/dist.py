@@ -34,14 +34,15 @@ def all_gather_advantages(adv, group=None):
 
 
 def global_advantage_stats(adv, mask=None, group=None):
-    """Global masked mean / std (unbiased=False) of the advantages from a 3-number all-reduce."""
+    """Global masked mean / std of the advantages from a 3-number all-reduce.  The std is the unbiased one
+    (torch's default, which `valid_advs.std()` in im_agent.py:470 uses)."""
     a = adv.double()
     m = torch.ones_like(a) if mask is None else mask.double().expand_as(a)
     s = torch.stack([(a * m).sum(), (a * a * m).sum(), m.sum()])
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
     mean = s[0] / s[2]
-    var = torch.clamp(s[1] / s[2] - mean * mean, min=0.0)
+    var = torch.clamp((s[1] - s[2] * mean * mean) / torch.clamp(s[2] - 1.0, min=1.0), min=0.0)
     return mean.to(adv.dtype), var.sqrt().to(adv.dtype), s[2]
 
 
