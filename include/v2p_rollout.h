@@ -218,6 +218,10 @@ int v2p_env_target_index(const v2p_env* e);
 /* diagnostics for tests: contact vertex ids chosen in the last substep, [N,24,4] int32, body*64+vertex or -1 */
 int v2p_env_debug_contacts(v2p_env* e, int32_t* out, void* stream);
 
+/* diagnostics for tests: the wave-slot -> env order used by the last physics launch (`perm`, [N] int32; envs are handed to
+ * waves in descending order of their contact load, see DESIGN.md "pairing") and the load key it was built from (`key`, [N]) */
+int v2p_env_debug_pairing(v2p_env* e, int32_t* perm, int32_t* key, void* stream);
+
 const char* v2p_last_error(void);
 int v2p_abi_version(void);
 

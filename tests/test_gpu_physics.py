@@ -202,3 +202,48 @@ def test_small_and_ragged_env_counts(mlib, n):
     if n > 8:
         assert torch.allclose(rb[0], rb[8], atol=1e-6)
     task.close()
+
+
+def test_env_pairing_is_invisible(mlib, monkeypatch):
+    """Envs are handed to waves in order of their contact load (physics_ll.hip pair_sort_kernel); which env shares a wave with
+    which must not change any env's numbers: paired and unpaired runs agree bit for bit over 6 control steps."""
+    n = 257
+    outs = []
+    for period in ("0", "1"):
+        monkeypatch.setenv("V2P_PAIR_PERIOD", period)
+        task = make_task(n, mlib)
+        g = torch.Generator(device=DEV)
+        g.manual_seed(11)
+        task.reset_with_times(None, torch.rand(n, device=DEV, generator=g) * 0.8)
+        for _ in range(6):
+            a = torch.cat([task._target_dof_pos + 0.3 * torch.randn((n, 69), device=DEV, generator=g), 0.3 * torch.randn((n, 6), device=DEV, generator=g)], dim=1).contiguous()
+            task.step(a)
+        torch.cuda.synchronize()
+        outs.append([N(task._rigid_body_state), N(task._dof_state), N(task._contact_forces), N(task.dof_force_tensor), N(task.rew_buf), N(task.obs_buf),
+                     N(task.debug_contacts())])
+        task.close()
+    assert (outs[0][6] >= 0).any()  # contacts were active
+    for k, (x, y) in enumerate(zip(*outs)):
+        assert np.array_equal(x, y), (k, float(np.abs(x.astype(np.float64) - y).max()), int((x != y).sum()), x.size)
+
+
+@pytest.mark.parametrize("n", [2, 3, 1000, 8195])
+def test_pairing_order_is_a_stable_descending_sort(mlib, n):
+    """pair_sort_kernel: the order for the next launch is the stable descending sort of the keys the last launch wrote."""
+    task = make_task(n, mlib)
+    g = torch.Generator(device=DEV)
+    g.manual_seed(3)
+    task.reset_with_times(None, torch.rand(n, device=DEV, generator=g) * 0.8)
+    a = torch.cat([task._target_dof_pos + 0.5 * torch.randn((n, 69), device=DEV, generator=g), torch.zeros((n, 6), device=DEV)], dim=1).contiguous()
+    task.step(a.clone())
+    task.step(a.clone())
+    perm, key = task.debug_pairing()
+    torch.cuda.synchronize()
+    if n <= 2:  # a single wave: no pairing
+        task.close()
+        return
+    kp = N(key).astype(np.int64)
+    expect = np.argsort(-kp, kind="stable")
+    assert np.array_equal(N(perm).astype(np.int64), expect)
+    assert n < 1000 or len(np.unique(kp)) > 3
+    task.close()

@@ -89,14 +89,19 @@ int v2p_model_create(const v2p_model_desc* d, int device, v2p_model** out) {
             if (off + np > MAX_HULL_VERTS) { set_error("v2p_model_create: padded hull vertices exceed the limit %d", MAX_HULL_VERTS); delete m; return V2P_ERR_UNSUPPORTED; }
             h.hull_offsets[b] = off;
             h.hull_count[b] = n;
-            float r2 = 0.f;
+            float r2 = 0.f, lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
             for (int v = 0; v < np; ++v) {
                 const float* src = d->hull_verts + 3 * (d->hull_offsets[b] + (v < n ? v : n - 1));
-                for (int k = 0; k < 3; ++k) h.hull_verts[off + v][k] = src[k];
+                for (int k = 0; k < 3; ++k) {
+                    h.hull_verts[off + v][k] = src[k];
+                    lo[k] = src[k] < lo[k] ? src[k] : lo[k];
+                    hi[k] = src[k] > hi[k] ? src[k] : hi[k];
+                }
                 float n2 = src[0] * src[0] + src[1] * src[1] + src[2] * src[2];
                 if (n2 > r2) r2 = n2;
             }
             h.bound_radius[b] = sqrtf(r2);
+            for (int k = 0; k < 3; ++k) { h.aabb_c[b][k] = 0.5f * (lo[k] + hi[k]); h.aabb_e[b][k] = 0.5f * (hi[k] - lo[k]) * 1.0001f + 1e-6f; }
             off += np;
         }
         h.hull_offsets[NB] = off;
@@ -281,9 +286,15 @@ int v2p_env_create(const v2p_model* model, const v2p_mlib* mlib, const v2p_sim_c
     if (rc == V2P_OK) rc = check_hip(hipMemset(e->out, 0, sizeof(float) * OUT_SLOTS * N), "hipMemset(out)");
     if (rc == V2P_OK) rc = check_hip(hipMemset(e->ws, 0, sizeof(float) * (size_t)physics_ws_slots() * N), "hipMemset(ws)");
     if (rc == V2P_OK) rc = check_hip(hipMemset(e->contact_ids, 0xff, sizeof(int32_t) * NB * 4 * N), "hipMemset(contact_ids)");
+    e->pair_period = getenv("V2P_PAIR_PERIOD") ? atoi(getenv("V2P_PAIR_PERIOD")) : 1;
+    if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->pair_key, sizeof(int32_t) * N), "hipMalloc(pair_key)");
+    if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->perm, sizeof(int32_t) * N), "hipMalloc(perm)");
+    if (rc == V2P_OK) rc = check_hip(hipMemset(e->pair_key, 0, sizeof(int32_t) * N), "hipMemset(pair_key)");
+    if (rc == V2P_OK) rc = launch_env_pairing(e, nullptr);  // all keys equal -> identity order
+    if (rc == V2P_OK) rc = check_hip(hipDeviceSynchronize(), "hipDeviceSynchronize(env_create)");
     if (rc == V2P_OK && getenv("V2P_PHASE_TIMING")) {
-        rc = check_hip(hipMalloc((void**)&e->prof, sizeof(long long) * 16), "hipMalloc(prof)");
-        if (rc == V2P_OK) rc = check_hip(hipMemset(e->prof, 0, sizeof(long long) * 16), "hipMemset(prof)");
+        rc = check_hip(hipMalloc((void**)&e->prof, sizeof(long long) * 24), "hipMalloc(prof)");
+        if (rc == V2P_OK) rc = check_hip(hipMemset(e->prof, 0, sizeof(long long) * 24), "hipMemset(prof)");
     }
     if (rc != V2P_OK) { v2p_env_destroy(e); return rc; }
     *out = e;
@@ -298,15 +309,17 @@ void v2p_env_destroy(v2p_env* e) {
     if (e->out) (void)hipFree(e->out);
     if (e->ws) (void)hipFree(e->ws);
     if (e->contact_ids) (void)hipFree(e->contact_ids);
+    if (e->pair_key) (void)hipFree(e->pair_key);
+    if (e->perm) (void)hipFree(e->perm);
     if (e->prof) {
-        long long h[16];
+        long long h[24];
         if (hipMemcpy(h, e->prof, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess)
             fprintf(stderr,
                     "[v2p phase cycles, workgroup 0] link-per-lane: counter k = phase k-1 of {pass1, pass2, root+pass3, contacts, lambda, sweep, "
                     "integrate}; env-per-lane: {stage, pass1, pass2, root+pass3, contacts, lambda, sweep, integrate}: "
                     "%lld %lld %lld %lld %lld %lld %lld %lld | block updates %lld touched-sum %lld substeps %lld | "
-                    "sweep: rows %lld up %lld root %lld down %lld\n",
-                    h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11], h[12], h[13], h[14]);
+                    "sweep: rows %lld up %lld contact-rounds %lld down %lld manifold-reductions %lld | contacts: cull %lld rounds %lld points %lld\n",
+                    h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15], h[16], h[17], h[18]);
         (void)hipFree(e->prof);
     }
     delete e;
@@ -327,7 +340,10 @@ int v2p_env_pre_physics(v2p_env* e, float* actions, void* stream) {
 int v2p_env_physics(v2p_env* e, void* stream) {
     if (!e) { set_error("v2p_env_physics: bad argument"); return V2P_ERR_INVALID; }
     DeviceGuard g(e->device);
-    return e->schedule == 0 ? launch_env_physics_ll(e, (hipStream_t)stream) : launch_env_physics(e, (hipStream_t)stream);
+    if (e->schedule != 0) return launch_env_physics(e, (hipStream_t)stream);
+    int rc = launch_env_physics_ll(e, (hipStream_t)stream);
+    if (rc == V2P_OK && env_pairing_on(e)) rc = launch_env_pairing(e, (hipStream_t)stream);  // order for the next launch
+    return rc;
 }
 
 int v2p_env_export(v2p_env* e, void* stream) {
@@ -370,6 +386,14 @@ int v2p_env_debug_contacts(v2p_env* e, int32_t* out, void* stream) {
     DeviceGuard g(e->device);
     return check_hip(hipMemcpyAsync(out, e->contact_ids, sizeof(int32_t) * NB * 4 * (size_t)e->n, hipMemcpyDeviceToDevice, (hipStream_t)stream),
                      "hipMemcpyAsync(contact_ids)");
+}
+
+int v2p_env_debug_pairing(v2p_env* e, int32_t* perm, int32_t* key, void* stream) {
+    if (!e || !perm || !key) { set_error("v2p_env_debug_pairing: bad argument"); return V2P_ERR_INVALID; }
+    DeviceGuard g(e->device);
+    int rc = check_hip(hipMemcpyAsync(perm, e->perm, sizeof(int32_t) * (size_t)e->n, hipMemcpyDeviceToDevice, (hipStream_t)stream), "hipMemcpyAsync(perm)");
+    if (rc == V2P_OK) rc = check_hip(hipMemcpyAsync(key, e->pair_key, sizeof(int32_t) * (size_t)e->n, hipMemcpyDeviceToDevice, (hipStream_t)stream), "hipMemcpyAsync(pair_key)");
+    return rc;
 }
 
 }  // extern "C"

@@ -31,6 +31,8 @@ struct PhysArgs {
     float* __restrict__ x_contact;  // [N,24,3]
     float* __restrict__ x_dof_force;  // [N,69]
     long long* prof;  // optional cycle counters per phase (block 0), NULL = off
+    const int32_t* perm;  // [N] wave slot -> env (envs with similar contact load share a wave), NULL = identity
+    int32_t* pair_key;    // [N] number of touched links in the last substep (input of the next pairing)
     unsigned long long par_pack[2];  // parents[24] and level order[24], 5 bits each, 12 per word: the tree walks of the
     unsigned long long ord_pack[2];  // impulse sweep decode them with scalar ALU ops instead of dependent scalar loads
     int64_t n;

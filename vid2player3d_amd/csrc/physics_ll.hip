@@ -79,21 +79,50 @@ __device__ __forceinline__ Sym3 mask(bool c, const Sym3& a) {
 }
 __device__ __forceinline__ V3 mask(bool c, V3 a) { return V3{c ? a.x : 0.f, c ? a.y : 0.f, c ? a.z : 0.f}; }
 
-#define LLSUB(k) do { if (a.prof) { long long t_ = clock64(); if (blockIdx.x == 0 && lane == 0) atomicAdd((unsigned long long*)&a.prof[k], (unsigned long long)(t_ - tsub)); tsub = t_; } } while (0)
-#define LLPH(k) do { if (a.prof) { long long t_ = clock64(); if (blockIdx.x == 0 && lane == 0) atomicAdd((unsigned long long*)&a.prof[k], (unsigned long long)(t_ - tprev)); tprev = t_; } } while (0)
+// 8-lane group exchanges on the DPP network: lane ^ 1, lane ^ 2 (quad permutes) and lane -> 7 - lane (row_half_mirror)
+__device__ __forceinline__ unsigned grp_xor1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false); }
+__device__ __forceinline__ unsigned grp_xor2(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false); }
+__device__ __forceinline__ unsigned grp_mirror(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false); }
+// (value, index) reductions over a group; index -1 = empty; ties go to the lower index so the result is what a serial scan finds
+template <bool MAX, typename F>
+__device__ __forceinline__ void grp_arg_step(float& v, int& k, F xch) {
+    const float ov = __uint_as_float(xch(__float_as_uint(v)));
+    const int ok = (int)xch((unsigned)k);
+    const bool beats = MAX ? ov > v : ov < v;
+    const bool take = ok >= 0 && (k < 0 || beats || (ov == v && ok < k));
+    v = take ? ov : v;
+    k = take ? ok : k;
+}
+__device__ __forceinline__ void grp_argmin(float& v, int& k) {
+    grp_arg_step<false>(v, k, grp_xor1); grp_arg_step<false>(v, k, grp_xor2); grp_arg_step<false>(v, k, grp_mirror);
+}
+__device__ __forceinline__ void grp_argmax(float& v, int& k) {
+    grp_arg_step<true>(v, k, grp_xor1); grp_arg_step<true>(v, k, grp_xor2); grp_arg_step<true>(v, k, grp_mirror);
+}
 
+#define LLSUB(k) do { if (a.prof) { long long t_ = clock64(); if ((blockIdx.x & 63) == 0 && lane == 0) atomicAdd((unsigned long long*)&a.prof[k], (unsigned long long)(t_ - tsub)); tsub = t_; } } while (0)
+#define LLPH(k) do { if (a.prof) { long long t_ = clock64(); if ((blockIdx.x & 63) == 0 && lane == 0) atomicAdd((unsigned long long*)&a.prof[k], (unsigned long long)(t_ - tprev)); tprev = t_; } } while (0)
+
+#ifndef V2P_LL_WPB
+#define V2P_LL_WPB 1   // waves per workgroup (they share the LDS hull copy)
+#endif
+#ifndef V2P_LL_WPS
+#define V2P_LL_WPS 2   // waves per SIMD the register budget is set for
+#endif
+constexpr int LL_WPB = V2P_LL_WPB;
 template <bool CONTACT>
-__global__ __launch_bounds__(64, 2) void physics_ll_kernel(PhysArgs a) {
+__global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(PhysArgs a) {
     const int64_t N = a.n;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int half = lane >> 5;
     const int lb = lane & (LPE - 1);
     const bool valid = lb < NB;
     const int b = valid ? lb : 0;  // idle lanes shadow link 0 and never commit anything
     const int base = lane & LPE;
-    int64_t e = (int64_t)blockIdx.x * 2 + half;
-    const bool live_env = e < N;
-    if (e >= N) e = N - 1;
+    const int64_t slot = ((int64_t)blockIdx.x * LL_WPB + (threadIdx.x >> 6)) * 2 + half;
+    const bool live_env = slot < N;
+    int64_t e = live_env ? slot : N - 1;
+    if (a.perm) e = a.perm[e];
     ConstModel& M = *(ConstModel*)a.model;
     float* __restrict__ st = a.state;
     const EnvParams& P = a.p;
@@ -108,7 +137,7 @@ __global__ __launch_bounds__(64, 2) void physics_ll_kernel(PhysArgs a) {
     if (CONTACT) {
         for (int bb = 0; bb < NB; ++bb) {
             const int src = M.hull_offsets[bb], dst = M.hull_cofs[bb], n = M.hull_count[bb];
-            for (int i = lane; i < n; i += 64) hv[dst + i] = make_float4(M.hull_verts[src + i][0], M.hull_verts[src + i][1], M.hull_verts[src + i][2], 0.f);
+            for (int i = threadIdx.x; i < n; i += 64 * LL_WPB) hv[dst + i] = make_float4(M.hull_verts[src + i][0], M.hull_verts[src + i][1], M.hull_verts[src + i][2], 0.f);
         }
         __syncthreads();
     }
@@ -117,6 +146,7 @@ __global__ __launch_bounds__(64, 2) void physics_ll_kernel(PhysArgs a) {
     const int par = b ? M.parents[b] : 0;
     const int plane = base + par;
     const ParentPull pp{plane, par == b - 1};
+    const bool firstchild = par == b - 1;  // depth-first order: the first child directly follows its parent
     const int dep = valid ? M.depth[b] : 99;
     const int c0 = M.children[b][0], c1 = M.children[b][1], c2 = M.children[b][2];
     const bool has0 = valid && c0 >= 0, has1 = valid && c1 >= 0, has2 = valid && c2 >= 0;
@@ -141,6 +171,7 @@ __global__ __launch_bounds__(64, 2) void physics_ll_kernel(PhysArgs a) {
 
     long long tprev = a.prof ? clock64() : 0;
     V3 r{0.f, 0.f, 0.f};
+    int ksum = 0, kdep = 0;  // contact load of this env over the launch (pairing key)
 
     for (int sub = 0; sub < P.nsub; ++sub) {
         const bool wrench_on = sub < P.hold_sub;
@@ -336,105 +367,179 @@ __global__ __launch_bounds__(64, 2) void physics_ll_kernel(PhysArgs a) {
             // walks only the candidates.  Hull vertices come from the LDS copy of the model (staged once per launch).
             const float coff = P.contact_offset;
             const int v0 = M.hull_cofs[bo], nv = M.hull_count[bo];
-            const bool near = valid && (x.z - M.bound_radius[bo] < coff);
-            int sel4[4] = {-1, -1, -1, -1};
-            if (__any(near)) {
+            // conservative culling: lowest point of the hull's body-frame bounding box (third row of the link's rotation)
+            const float rz0 = 2.f * (q.x * q.z - q.w * q.y), rz1 = 2.f * (q.y * q.z + q.w * q.x), rz2 = 1.f - 2.f * (q.x * q.x + q.y * q.y);
+            const float zlow = x.z + rz0 * M.aabb_c[bo][0] + rz1 * M.aabb_c[bo][1] + rz2 * M.aabb_c[bo][2] -
+                               (fabsf(rz0) * M.aabb_e[bo][0] + fabsf(rz1) * M.aabb_e[bo][1] + fabsf(rz2) * M.aabb_e[bo][2]);
+            const bool near = valid && (zlow < coff + 1e-4f);
+            int pack = 0x0fffffff;  // four 7-bit vertex slots (127 = none), manifold size in bits 28..30
+            long long tsub = a.prof ? clock64() : 0;
+            const unsigned long long nball = __ballot(near);
+            LLSUB(16);
+            if (nball) {
+                // The hulls of the few links near the ground are scanned by GROUPS of 8 lanes (4 groups per env, 4 near links per
+                // round): lane gl of a group takes vertices gl, gl+8, ... and the group combines with three DPP steps.  Every
+                // selection keeps the serial rule "first index attaining the extreme": per lane indices ascend, across lanes ties
+                // go to the lower index.
+                const unsigned nm = half ? (unsigned)(nball >> 32) : (unsigned)nball;
+                const int nr0 = __popc((unsigned)nball), nr1 = __popc((unsigned)(nball >> 32));
+                const int rounds = ((nr0 > nr1 ? nr0 : nr1) + 3) >> 2;
+                const int myidx = __popc(nm & ((1u << lb) - 1u));  // rank of this link among the near links of its env
+                const int grp = lb >> 3, gl = lb & 7;
+                unsigned remn = nm;
+                if (a.prof && (blockIdx.x & 63) == 0 && lane == 0) atomicAdd((unsigned long long*)&a.prof[13], (unsigned long long)rounds);
+                for (int rd = 0; rd < rounds; ++rd) {
+                    unsigned cb = remn;
+                    if (grp >= 1) cb &= cb - 1;
+                    if (grp >= 2) cb &= cb - 1;
+                    if (grp >= 3) cb &= cb - 1;
+                    const bool gon = cb != 0u;
+                    const int L = gon ? __ffs(cb) - 1 : 0;
+                    remn &= remn - 1; remn &= remn - 1; remn &= remn - 1; remn &= remn - 1;
+                    const int src = base + L;
+                    // the group works in the frame of ITS link: pose pulled from the owner lane (7 values instead of 12)
+                    const M3 RL = q2mat(pull(q, src));
+                    const V3 xL = pull(x, src);
+                    const float r6 = RL.m[6], r7 = RL.m[7], r8 = RL.m[8], xz = xL.z;
+                    const int v0L = __builtin_amdgcn_ds_bpermute(src << 2, v0), nvL = __builtin_amdgcn_ds_bpermute(src << 2, nv);
+                    // ---- one pass over the hull: 8 vertices per lane (all loads in flight at once), ground-plane coordinates kept
+                    // for the manifold reduction; candidates (z < contact_offset) as a bit mask, deepest one tracked
+                    const float r0 = RL.m[0], r1 = RL.m[1], r2 = RL.m[2], xx = xL.x;
+                    const float r3 = RL.m[3], r4 = RL.m[4], r5 = RL.m[5], xy = xL.y;
+                    const unsigned gbit = 1u << gl;
+                    float4 vv[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int i = 8 * k + gl;
+                        vv[k] = hv[v0L + ((gon && i < nvL) ? i : 0)];
+                    }
+                    float px[8], py[8];
+                    unsigned clo = 0u, chi = 0u;
+                    int k0 = -1;
+                    float zmin = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int i = 8 * k + gl;
+                        const bool in = gon && i < nvL;
+                        const float z = xz + r6 * vv[k].x + r7 * vv[k].y + r8 * vv[k].z;
+                        px[k] = xx + r0 * vv[k].x + r1 * vv[k].y + r2 * vv[k].z;
+                        py[k] = xy + r3 * vv[k].x + r4 * vv[k].y + r5 * vv[k].z;
+                        const bool c = in && (z < coff);
+                        const unsigned bit = c ? gbit << (8 * (k & 3)) : 0u;
+                        if (k < 4) clo |= bit; else chi |= bit;
+                        const bool better = c && (k0 < 0 || z < zmin);
+                        k0 = better ? i : k0;
+                        zmin = better ? z : zmin;
+                    }
+                    clo |= grp_xor1(clo); chi |= grp_xor1(chi);
+                    clo |= grp_xor2(clo); chi |= grp_xor2(chi);
+                    clo |= grp_mirror(clo); chi |= grp_mirror(chi);
+                    grp_argmin(zmin, k0);
+                    const unsigned long long cm = ((unsigned long long)chi << 32) | clo;
+                    const int cntg = __popc(clo) + __popc(chi);
+                    unsigned long long t = cm;
+                    int s0 = t ? __ffsll((long long)t) - 1 : -1; t &= t - 1;
+                    int s1 = t ? __ffsll((long long)t) - 1 : -1; t &= t - 1;
+                    int s2 = t ? __ffsll((long long)t) - 1 : -1; t &= t - 1;
+                    int s3 = t ? __ffsll((long long)t) - 1 : -1;
+                    int ns = cntg < 4 ? cntg : 4;
+                    const bool big = gon && cntg > 4;
+                    if (__any(big)) {
+                        if (a.prof && (blockIdx.x & 63) == 0 && lane == 0) atomicAdd((unsigned long long*)&a.prof[15], 1ull);
+                        // manifold reduction: deepest, farthest from it, extreme on either side of that line
+                        const int k0s = k0 < 0 ? 0 : k0;
+                        const float4 u0 = hv[v0L + k0s];
+                        const float p0x = xx + r0 * u0.x + r1 * u0.y + r2 * u0.z;
+                        const float p0y = xy + r3 * u0.x + r4 * u0.y + r5 * u0.z;
+                        const unsigned long long remB = big ? (cm & ~(1ull << k0s)) : 0ull;
+                        const unsigned blo = (unsigned)remB, bhi = (unsigned)(remB >> 32);
+                        int k1 = -1;
+                        float best = -1.f;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const bool on = ((k < 4 ? blo : bhi) & (gbit << (8 * (k & 3)))) != 0u;
+                            const float dx = px[k] - p0x, dy = py[k] - p0y;
+                            const float d2 = dx * dx + dy * dy;
+                            const bool take = on && (d2 > best);
+                            best = take ? d2 : best;
+                            k1 = take ? 8 * k + gl : k1;
+                        }
+                        grp_argmax(best, k1);
+                        const int k1s = k1 < 0 ? 0 : k1;
+                        const float4 u1 = hv[v0L + k1s];
+                        const float ex = xx + r0 * u1.x + r1 * u1.y + r2 * u1.z - p0x;
+                        const float ey = xy + r3 * u1.x + r4 * u1.y + r5 * u1.z - p0y;
+                        const unsigned long long remC = remB & ~(1ull << k1s);
+                        const unsigned elo = (unsigned)remC, ehi = (unsigned)(remC >> 32);
+                        int k2 = -1, k3 = -1;
+                        float amax = 0.f, amin = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const bool on = ((k < 4 ? elo : ehi) & (gbit << (8 * (k & 3)))) != 0u;
+                            const float dx = px[k] - p0x, dy = py[k] - p0y;
+                            const float area = ex * dy - ey * dx;
+                            const bool up = on && area > amax;
+                            const bool dn = on && area < amin;
+                            amax = up ? area : amax; k2 = up ? 8 * k + gl : k2;
+                            amin = dn ? area : amin; k3 = dn ? 8 * k + gl : k3;
+                        }
+                        grp_argmax(amax, k2);
+                        grp_argmin(amin, k3);
+                        if (big) {
+                            s0 = k0; s1 = k1;
+                            s2 = k2 >= 0 ? k2 : k3;
+                            s3 = k2 >= 0 ? k3 : -1;
+                            ns = 2 + (k2 >= 0 ? 1 : 0) + (k3 >= 0 ? 1 : 0);
+                        }
+                    }
+                    const int gpack = (s0 & 0x7f) | ((s1 & 0x7f) << 7) | ((s2 & 0x7f) << 14) | ((s3 & 0x7f) << 21) | (ns << 28);
+                    const int got = __builtin_amdgcn_ds_bpermute((base + ((myidx & 3) << 3)) << 2, gpack);
+                    pack = (near && (myidx >> 2) == rd) ? got : pack;
+                }
+            }
+            LLSUB(17);
+            int sel4[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int sv = (pack >> (7 * c)) & 0x7f;
+                sel4[c] = sv == 0x7f ? -1 : sv;
+            }
+            cnt = (pack >> 28) & 7;
+            if (__any(cnt > 0)) {
                 const M3 R = q2mat(q);
-                const int nvmax = M.max_hull_count;
-                unsigned long long cm = 0ull;
-                int k0 = -1;
-                float zmin = 0.f;
-#pragma unroll 4
-                for (int i = 0; i < nvmax; ++i) {
-                    const float4 hvv = hv[v0 + (i < nv ? i : 0)];
-                    float z = x.z + R.m[6] * hvv.x + R.m[7] * hvv.y + R.m[8] * hvv.z;
-                    bool c = near && (i < nv) && (z < coff);
-                    cm |= (unsigned long long)(c ? 1u : 0u) << i;
-                    bool better = c && (k0 < 0 || z < zmin);
-                    k0 = better ? i : k0;
-                    zmin = better ? z : zmin;
-                }
-                cnt = __popcll(cm);
-                // the first four candidates in index order
-                unsigned long long t = cm;
-                int s0 = t ? __ffsll((long long)t) - 1 : -1; t &= t - 1;
-                int s1 = t ? __ffsll((long long)t) - 1 : -1; t &= t - 1;
-                int s2 = t ? __ffsll((long long)t) - 1 : -1; t &= t - 1;
-                int s3 = t ? __ffsll((long long)t) - 1 : -1;
-                int ns = cnt < 4 ? cnt : 4;
-                if (__any(cnt > 4)) {
-                    // manifold reduction: deepest, farthest from it, extreme on either side of that line
-                    const bool big = cnt > 4;
-                    const float4 u0 = hv[v0 + (k0 < 0 ? 0 : k0)];
-                    float p0x = x.x + R.m[0] * u0.x + R.m[1] * u0.y + R.m[2] * u0.z;
-                    float p0y = x.y + R.m[3] * u0.x + R.m[4] * u0.y + R.m[5] * u0.z;
-                    int k1 = -1;
-                    float best = -1.f;
-                    unsigned long long rem = big ? (cm & ~(1ull << (k0 < 0 ? 0 : k0))) : 0ull;
-                    while (__any(rem != 0ull)) {
-                        const bool on = rem != 0ull;
-                        const int i = on ? __ffsll((long long)rem) - 1 : 0;
-                        rem &= rem - 1;
-                        const float4 uu = hv[v0 + i];
-                        float dx = x.x + R.m[0] * uu.x + R.m[1] * uu.y + R.m[2] * uu.z - p0x;
-                        float dy = x.y + R.m[3] * uu.x + R.m[4] * uu.y + R.m[5] * uu.z - p0y;
-                        float d2 = dx * dx + dy * dy;
-                        bool take = on && (d2 > best);
-                        best = take ? d2 : best;
-                        k1 = take ? i : k1;
-                    }
-                    const float4 u1 = hv[v0 + (k1 < 0 ? 0 : k1)];
-                    float ex = x.x + R.m[0] * u1.x + R.m[1] * u1.y + R.m[2] * u1.z - p0x;
-                    float ey = x.y + R.m[3] * u1.x + R.m[4] * u1.y + R.m[5] * u1.z - p0y;
-                    int k2 = -1, k3 = -1;
-                    float amax = 0.f, amin = 0.f;
-                    rem = big ? (cm & ~(1ull << (k0 < 0 ? 0 : k0)) & ~(1ull << (k1 < 0 ? 0 : k1))) : 0ull;
-                    while (__any(rem != 0ull)) {
-                        const bool on = rem != 0ull;
-                        const int i = on ? __ffsll((long long)rem) - 1 : 0;
-                        rem &= rem - 1;
-                        const float4 uu = hv[v0 + i];
-                        float dx = x.x + R.m[0] * uu.x + R.m[1] * uu.y + R.m[2] * uu.z - p0x;
-                        float dy = x.y + R.m[3] * uu.x + R.m[4] * uu.y + R.m[5] * uu.z - p0y;
-                        float area = ex * dy - ey * dx;
-                        bool up = on && area > amax;
-                        bool dn = on && area < amin;
-                        amax = up ? area : amax; k2 = up ? i : k2;
-                        amin = dn ? area : amin; k3 = dn ? i : k3;
-                    }
-                    if (big) {
-                        s0 = k0; s1 = k1;
-                        s2 = k2 >= 0 ? k2 : k3;
-                        s3 = k2 >= 0 ? k3 : -1;
-                        ns = 2 + (k2 >= 0 ? 1 : 0) + (k3 >= 0 ? 1 : 0);
-                    }
-                }
-                cnt = ns;
-                sel4[0] = s0; sel4[1] = s1; sel4[2] = s2; sel4[3] = s3;
+                const float ih = 1.f / h;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const float4 uu = hv[v0 + (sel4[c] < 0 ? 0 : sel4[c])];
                     cr[c] = mul(R, V3{uu.x, uu.y, uu.z});
                     float dz = x.z + cr[c].z;
-                    cbias[c] = dz >= 0.f ? dz / h : fmaxf(P.erp * dz / h, -P.max_depen);
+                    cbias[c] = dz >= 0.f ? dz * ih : fmaxf(P.erp * dz * ih, -P.max_depen);
                 }
             }
-            if (valid && live_env) {
+            if (last && valid && live_env) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) a.contact_ids[(e * NB + b) * 4 + c] = c < cnt ? b * 64 + sel4[c] : -1;
             }
 
+            LLSUB(18);
             const unsigned long long tb = __ballot(valid && cnt > 0);
             const unsigned m0 = (unsigned)tb, m1 = (unsigned)(tb >> 32);
-            if (a.prof && blockIdx.x == 0 && lane == 0) { atomicAdd((unsigned long long*)&a.prof[9], (unsigned long long)(__popc(m0) + __popc(m1))); atomicAdd((unsigned long long*)&a.prof[10], 1ull); }
+            if (last) {
+                const unsigned mine = half ? m1 : m0;
+                ksum = __popc(mine);
+                kdep = 0;
+                for (unsigned t = mine; t; t &= t - 1) { const int dd = M.depth[__ffs(t) - 1]; kdep = dd > kdep ? dd : kdep; }
+            }
+            if (a.prof && (blockIdx.x & 63) == 0 && lane == 0) { atomicAdd((unsigned long long*)&a.prof[9], (unsigned long long)(__popc(m0) + __popc(m1))); atomicAdd((unsigned long long*)&a.prof[10], 1ull); }
             if ((m0 | m1) && P.n_iter > 0) {
                 // deepest touched link of either env: links below it are never read during the sweep, so Lambda and the
                 // per-update propagation stop there; their velocities catch up once at the end (the propagation is linear)
-                int dneed = 1;
-                for (unsigned t = m0 | m1; t; t &= t - 1) {
-                    const int dd = M.depth[__ffs(t) - 1];
-                    dneed = dd > dneed ? dd : dneed;
-                }
+                // (each env stops at ITS deepest touched link, so its arithmetic does not depend on which env shares the wave)
+                int dn0 = 0, dn1 = 0;
+                for (unsigned t = m0; t; t &= t - 1) { const int dd = M.depth[__ffs(t) - 1]; dn0 = dd > dn0 ? dd : dn0; }
+                for (unsigned t = m1; t; t &= t - 1) { const int dd = M.depth[__ffs(t) - 1]; dn1 = dd > dn1 ? dd : dn1; }
+                const int dneed = dn0 > dn1 ? dn0 : dn1, dmin = dn0 < dn1 ? dn0 : dn1;
+                const bool insweep = dep <= (half ? dn1 : dn0);  // this link moves with every update; the others catch up afterwards
                 LLPH(4);
                 // ======================================================== Lambda_b, root -> leaves by level
                 for (int d = 1; d <= dneed; ++d) {
@@ -511,13 +616,14 @@ __global__ __launch_bounds__(64, 2) void physics_ll_kernel(PhysArgs a) {
                         const bool me = valid && (lb == bsel);
                         const bool onpath = valid && bsel >= 0 && ((desc >> bsel) & 1);  // this link is the touched one or one of its ancestors
                         long long tsub = a.prof ? clock64() : 0;
-                        if (a.prof && blockIdx.x == 0 && lane == 0) atomicAdd((unsigned long long*)&a.prof[8], 1ull);
+                        if (a.prof && (blockIdx.x & 63) == 0 && lane == 0) atomicAdd((unsigned long long*)&a.prof[8], 1ull);
                         V3 un{0.f, 0.f, 0.f}, uf{0.f, 0.f, 0.f};
                         if (me) {
                             V3 wl = w, xl = xd;
 #pragma unroll
                             for (int c = 0; c < 4; ++c) {
                                 const bool active = c < cnt;
+                                if (!__any(active)) break;  // uniform over the (at most two) touched links solved here
                                 V3 rr = cr[c];
                                 float ln = clam[c].x, l1 = clam[c].y, l2 = clam[c].z;
 #pragma unroll
@@ -557,7 +663,7 @@ __global__ __launch_bounds__(64, 2) void physics_ll_kernel(PhysArgs a) {
                             }
                             un = un + mask(has0, from_next(cn));
                             uf = uf + mask(has0, from_next(cf));
-                            if ((multi >> d) & 1) {
+                            if (((multi >> d) & 1) && __any(dep == d && onpath && !firstchild)) {  // path enters its parent through child 1 or 2
                                 un = un + mask(has1, pull(cn, cl1)) + mask(has2, pull(cn, cl2));
                                 uf = uf + mask(has1, pull(cf, cl1)) + mask(has2, pull(cf, cl2));
                             }
@@ -576,7 +682,7 @@ __global__ __launch_bounds__(64, 2) void physics_ll_kernel(PhysArgs a) {
                         for (int d = 1; d <= dneed; ++d) {
                             const bool nc = (nonchain >> d) & 1;
                             V3 pdw = pp(ddw, nc), pdv = pp(ddv, nc);
-                            if (dep == d) {
+                            if (dep == d && insweep) {
                                 V3 av = pdv + cross(pdw, r);
                                 ddw = mul(Di, aug * pdw + du) - mul(E, av);
                                 ddv = av;
@@ -590,10 +696,10 @@ __global__ __launch_bounds__(64, 2) void physics_ll_kernel(PhysArgs a) {
                     }
                 }
                 // links below the deepest touched one: one catch-up pass with the accumulated motion of their parents
-                for (int d = dneed + 1; d <= maxd; ++d) {
+                for (int d = dmin + 1; d <= maxd; ++d) {
                     const bool nc = (nonchain >> d) & 1;
                     V3 pdw = pp(accw, nc), pdv = pp(accv, nc);
-                    if (dep == d) {
+                    if (dep == d && !insweep) {
                         V3 av = pdv + cross(pdw, r);
                         accw = mul(Di, aug * pdw) - mul(E, av);
                         accv = av;
@@ -662,6 +768,9 @@ __global__ __launch_bounds__(64, 2) void physics_ll_kernel(PhysArgs a) {
             xd = pxd + cross(pw, rr);
         }
     }
+    if (lb == 0 && live_env) {
+        a.pair_key[e] = ksum * 8 + (kdep > 7 ? 7 : kdep);  // touched links, then the deepest of them: what the sweep's cost follows
+    }
     if (valid && live_env) {
         if (b == 0) {
             st[SIDX(ST_ROOT_QUAT + 0)] = q.x; st[SIDX(ST_ROOT_QUAT + 1)] = q.y; st[SIDX(ST_ROOT_QUAT + 2)] = q.z; st[SIDX(ST_ROOT_QUAT + 3)] = q.w;
@@ -693,8 +802,90 @@ __global__ __launch_bounds__(64, 2) void physics_ll_kernel(PhysArgs a) {
     }
 }
 
+// ---- pairing: the sweep of a wave costs max(touched links) of its two envs, so envs are handed to waves in descending order of
+// their touched-link count (stable counting sort -> deterministic; heavy waves first also keeps the tail of the launch short).
+// One workgroup, after every physics launch (the load of consecutive control steps is already only loosely correlated: a period
+// of 4 launches loses most of the gain).
+constexpr int PAIR_BINS = 256;
+__global__ __launch_bounds__(1024) void pair_sort_kernel(const int32_t* __restrict__ key, int32_t* __restrict__ perm, int64_t n) {
+    // wave w owns the contiguous env range [w*span, (w+1)*span): count per bin, prefix over (bin, wave), then place in order
+    __shared__ int cnt[16][PAIR_BINS];
+    __shared__ int start[PAIR_BINS];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int64_t span = ((n + 15) / 16 + 63) / 64 * 64;
+    const int64_t lo = wave * span, hi = lo + span < n ? lo + span : n;
+    for (int j = t; j < 16 * PAIR_BINS; j += 1024) (&cnt[0][0])[j] = 0;
+    __syncthreads();
+    auto bin_of = [&](int64_t i) { int k = key[i]; k = k < 0 ? 0 : (k > PAIR_BINS - 1 ? PAIR_BINS - 1 : k); return PAIR_BINS - 1 - k; };
+    auto match = [&](bool on, int k, int& rank, int& total) {  // lanes of this wave holding the same bin, in lane order
+        unsigned long long same = __ballot(on);
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+            const unsigned long long bm = __ballot((k >> bit) & 1);
+            same &= ((k >> bit) & 1) ? bm : ~bm;
+        }
+        rank = __popcll(same & ((1ull << lane) - 1ull));
+        total = __popcll(same);
+    };
+    for (int64_t i0 = lo; i0 < hi; i0 += 512) {  // 8 independent key loads in flight per lane
+        int ks[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int64_t i = i0 + 64 * u + lane; ks[u] = i < hi ? bin_of(i) : -1; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool on = ks[u] >= 0;
+            int rank, total;
+            match(on, on ? ks[u] : 0, rank, total);
+            if (on && rank == 0) cnt[wave][ks[u]] += total;
+        }
+    }
+    __syncthreads();
+    // exclusive prefix over waves inside each bin, bin totals -> start[]
+    if (t < PAIR_BINS) {
+        int acc = 0;
+        for (int w2 = 0; w2 < 16; ++w2) { const int c = cnt[w2][t]; cnt[w2][t] = acc; acc += c; }
+        start[t] = acc;
+    }
+    __syncthreads();
+    if (wave == 0) {  // exclusive scan of the 256 bin totals by one wave (4 bins per lane)
+        int v0 = start[4 * lane], v1 = start[4 * lane + 1], v2 = start[4 * lane + 2], v3 = start[4 * lane + 3];
+        const int mine = v0 + v1 + v2 + v3;
+        int inc = mine;
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+        int ex = inc - mine;
+        start[4 * lane] = ex; start[4 * lane + 1] = ex + v0; start[4 * lane + 2] = ex + v0 + v1; start[4 * lane + 3] = ex + v0 + v1 + v2;
+    }
+    __syncthreads();
+    for (int64_t i0 = lo; i0 < hi; i0 += 512) {
+        int ks[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int64_t i = i0 + 64 * u + lane; ks[u] = i < hi ? bin_of(i) : -1; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool on = ks[u] >= 0;
+            const int k = on ? ks[u] : 0;
+            int rank, total;
+            match(on, k, rank, total);
+            int off = 0;
+            if (on) off = start[k] + cnt[wave][k] + rank;
+            if (on && rank == 0) cnt[wave][k] += total;  // wave-private row: program order within the wave is enough
+            if (on) perm[off] = (int32_t)(i0 + 64 * u + lane);
+        }
+    }
+}
+
+bool env_pairing_on(const v2p_env* env) { return env->pair_period > 0 && env->schedule == 0 && env->p.enable_contact && env->n > 2; }
+
+int launch_env_pairing(v2p_env* env, hipStream_t s) {
+    hipLaunchKernelGGL(pair_sort_kernel, dim3(1), dim3(1024), 0, s, env->pair_key, env->perm, env->n);
+    return check_hip(hipGetLastError(), "pair_sort_kernel");
+}
+
 int launch_env_physics_ll(v2p_env* env, hipStream_t s) {
+    const bool paired = env_pairing_on(env);
     PhysArgs a = {};
+    a.perm = paired ? env->perm : nullptr;
+    a.pair_key = env->pair_key;
     a.model = env->model->dev;
     a.state = env->state;
     a.ctrl = env->ctrl;
@@ -709,12 +900,12 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s) {
     a.prof = env->prof;
     a.n = env->n;
     a.p = env->p;
-    unsigned blocks = (unsigned)((env->n + 1) / 2);
+    unsigned blocks = (unsigned)((env->n + 2 * LL_WPB - 1) / (2 * LL_WPB));
     const size_t lds = env->p.enable_contact ? sizeof(float4) * (size_t)env->model->host.hull_cofs[NB] : 0;
     if (env->p.enable_contact)
-        hipLaunchKernelGGL(physics_ll_kernel<true>, dim3(blocks), dim3(64), lds, s, a);
+        hipLaunchKernelGGL(physics_ll_kernel<true>, dim3(blocks), dim3(64 * LL_WPB), lds, s, a);
     else
-        hipLaunchKernelGGL(physics_ll_kernel<false>, dim3(blocks), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(physics_ll_kernel<false>, dim3(blocks), dim3(64 * LL_WPB), 0, s, a);
     return check_hip(hipGetLastError(), "physics_ll_kernel");
 }
 

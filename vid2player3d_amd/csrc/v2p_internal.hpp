@@ -43,6 +43,7 @@ struct DevModel {
     float kd[NB];
     float arm[NB];
     float bound_radius[NB];  // max |hull vertex| (contact culling)
+    float aabb_c[NB][3], aabb_e[NB][3];  // body-frame bounding box of the hull: centre, half extents (tighter culling)
     int32_t hull_offsets[NB + 1];  // into hull_verts; every body's list is padded to a multiple of HULL_PAD (last vertex repeated)
     int32_t hull_count[NB];        // real vertex count per body
     int32_t hull_cofs[NB + 1];     // offsets of the unpadded lists (LDS copy of the link-per-lane kernel)
@@ -108,6 +109,9 @@ struct v2p_env {
     float* ws;                // SoA [WS_SLOTS][N] physics workspace
     int32_t* contact_ids;     // [N,24,4] debug
     long long* prof;          // [8] phase cycle counters when V2P_PHASE_TIMING is set (device), else NULL
+    int32_t* pair_key;        // [N] touched-link count per env, written by the link-per-lane kernel
+    int32_t* perm;            // [N] wave slot -> env, rebuilt from pair_key after every physics launch
+    int pair_period;          // 0 = pairing off (V2P_PAIR_PERIOD=0), else on
 };
 
 namespace v2p {
@@ -146,6 +150,8 @@ int launch_env_reset(v2p_env* e, const int64_t* env_ids, int64_t n, const float*
 int launch_env_pre(v2p_env* e, float* actions, hipStream_t s);
 int launch_env_physics(v2p_env* e, hipStream_t s);
 int launch_env_physics_ll(v2p_env* e, hipStream_t s);
+bool env_pairing_on(const v2p_env* e);
+int launch_env_pairing(v2p_env* e, hipStream_t s);
 int launch_env_export(v2p_env* e, hipStream_t s);
 int launch_env_post(v2p_env* e, hipStream_t s);
 int launch_env_push_state(v2p_env* e, const int64_t* env_ids, int64_t n, int with_rb, hipStream_t s);

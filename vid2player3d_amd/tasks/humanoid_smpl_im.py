@@ -480,6 +480,13 @@ class HumanoidSMPLIM:
         _lib.check(self._lib.v2p_env_debug_contacts(self._h_env, _lib.ptr(out), self._stream()), "v2p_env_debug_contacts")
         return out
 
+    def debug_pairing(self):
+        """(perm, key): wave-slot -> env order of the last physics launch and the contact-load key of each env after it."""
+        perm = torch.empty((self.num_envs,), dtype=torch.int32, device=self.device)
+        key = torch.empty((self.num_envs,), dtype=torch.int32, device=self.device)
+        _lib.check(self._lib.v2p_env_debug_pairing(self._h_env, _lib.ptr(perm), _lib.ptr(key), self._stream()), "v2p_env_debug_pairing")
+        return perm, key
+
     # ------------------------------------------------------------------ target views
     _SLICES = {"root_pos": (0, 3, None), "root_rot": (3, 7, None), "dof_pos": (7, 76, None), "root_vel": (76, 79, None),
                "root_ang_vel": (79, 82, None), "dof_vel": (82, 151, None), "key_pos": (151, 163, (4, 3)), "rb_pos": (163, 235, (24, 3)),
