@@ -6,8 +6,10 @@
 #include <string.h>
 
 #include <new>
+#include <vector>
 
 #include "v2p_internal.hpp"
+#include "phys_common.hpp"
 
 namespace v2p {
 
@@ -288,9 +290,21 @@ int v2p_env_create(const v2p_model* model, const v2p_mlib* mlib, const v2p_sim_c
     if (rc == V2P_OK) rc = check_hip(hipMemset(e->contact_ids, 0xff, sizeof(int32_t) * NB * 4 * N), "hipMemset(contact_ids)");
     e->pair_period = getenv("V2P_PAIR_PERIOD") ? atoi(getenv("V2P_PAIR_PERIOD")) : 1;
     if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->pair_key, sizeof(int32_t) * N), "hipMalloc(pair_key)");
+    if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->pair_pos, sizeof(int32_t) * N), "hipMalloc(pair_pos)");
     if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->perm, sizeof(int32_t) * N), "hipMalloc(perm)");
+    if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->pair_hist, sizeof(int32_t) * (2 * PAIR_BINS + 1)), "hipMalloc(pair_hist)");
+    if (rc == V2P_OK) {
+        e->pair_start = e->pair_hist + PAIR_BINS;
+        e->pair_done = e->pair_hist + 2 * PAIR_BINS;
+        rc = check_hip(hipMemset(e->pair_hist, 0, sizeof(int32_t) * (2 * PAIR_BINS + 1)), "hipMemset(pair_hist)");
+    }
     if (rc == V2P_OK) rc = check_hip(hipMemset(e->pair_key, 0, sizeof(int32_t) * N), "hipMemset(pair_key)");
-    if (rc == V2P_OK) rc = launch_env_pairing(e, nullptr);  // all keys equal -> identity order
+    if (rc == V2P_OK) {
+        std::vector<int32_t> iota(N);
+        for (size_t i = 0; i < N; ++i) iota[i] = (int32_t)i;
+        rc = check_hip(hipMemcpy(e->perm, iota.data(), sizeof(int32_t) * N, hipMemcpyHostToDevice), "hipMemcpy(perm)");
+        if (rc == V2P_OK) rc = check_hip(hipMemcpy(e->pair_pos, iota.data(), sizeof(int32_t) * N, hipMemcpyHostToDevice), "hipMemcpy(pair_pos)");
+    }
     if (rc == V2P_OK) rc = check_hip(hipDeviceSynchronize(), "hipDeviceSynchronize(env_create)");
     if (rc == V2P_OK && getenv("V2P_PHASE_TIMING")) {
         rc = check_hip(hipMalloc((void**)&e->prof, sizeof(long long) * 24), "hipMalloc(prof)");
@@ -310,6 +324,8 @@ void v2p_env_destroy(v2p_env* e) {
     if (e->ws) (void)hipFree(e->ws);
     if (e->contact_ids) (void)hipFree(e->contact_ids);
     if (e->pair_key) (void)hipFree(e->pair_key);
+    if (e->pair_pos) (void)hipFree(e->pair_pos);
+    if (e->pair_hist) (void)hipFree(e->pair_hist);
     if (e->perm) (void)hipFree(e->perm);
     if (e->prof) {
         long long h[24];
@@ -318,8 +334,8 @@ void v2p_env_destroy(v2p_env* e) {
                     "[v2p phase cycles, workgroup 0] link-per-lane: counter k = phase k-1 of {pass1, pass2, root+pass3, contacts, lambda, sweep, "
                     "integrate}; env-per-lane: {stage, pass1, pass2, root+pass3, contacts, lambda, sweep, integrate}: "
                     "%lld %lld %lld %lld %lld %lld %lld %lld | block updates %lld touched-sum %lld substeps %lld | "
-                    "sweep: rows %lld up %lld contact-rounds %lld down %lld manifold-reductions %lld | contacts: cull %lld rounds %lld points %lld\n",
-                    h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15], h[16], h[17], h[18]);
+                    "sweep: rows %lld up %lld contact-rounds %lld down %lld manifold-reductions %lld | contacts: cull %lld rounds %lld points %lld | null updates %lld\n",
+                    h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15], h[16], h[17], h[18], h[19]);
         (void)hipFree(e->prof);
     }
     delete e;
@@ -341,9 +357,7 @@ int v2p_env_physics(v2p_env* e, void* stream) {
     if (!e) { set_error("v2p_env_physics: bad argument"); return V2P_ERR_INVALID; }
     DeviceGuard g(e->device);
     if (e->schedule != 0) return launch_env_physics(e, (hipStream_t)stream);
-    int rc = launch_env_physics_ll(e, (hipStream_t)stream);
-    if (rc == V2P_OK && env_pairing_on(e)) rc = launch_env_pairing(e, (hipStream_t)stream);  // order for the next launch
-    return rc;
+    return launch_env_physics_ll(e, (hipStream_t)stream);
 }
 
 int v2p_env_export(v2p_env* e, void* stream) {
@@ -391,7 +405,9 @@ int v2p_env_debug_contacts(v2p_env* e, int32_t* out, void* stream) {
 int v2p_env_debug_pairing(v2p_env* e, int32_t* perm, int32_t* key, void* stream) {
     if (!e || !perm || !key) { set_error("v2p_env_debug_pairing: bad argument"); return V2P_ERR_INVALID; }
     DeviceGuard g(e->device);
-    int rc = check_hip(hipMemcpyAsync(perm, e->perm, sizeof(int32_t) * (size_t)e->n, hipMemcpyDeviceToDevice, (hipStream_t)stream), "hipMemcpyAsync(perm)");
+    int rc = V2P_OK;
+    if (env_pairing_on(e) && e->pair_have) rc = launch_env_pairing(e, (hipStream_t)stream);
+    if (rc == V2P_OK) rc = check_hip(hipMemcpyAsync(perm, e->perm, sizeof(int32_t) * (size_t)e->n, hipMemcpyDeviceToDevice, (hipStream_t)stream), "hipMemcpyAsync(perm)");
     if (rc == V2P_OK) rc = check_hip(hipMemcpyAsync(key, e->pair_key, sizeof(int32_t) * (size_t)e->n, hipMemcpyDeviceToDevice, (hipStream_t)stream), "hipMemcpyAsync(pair_key)");
     return rc;
 }

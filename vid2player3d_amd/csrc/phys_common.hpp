@@ -32,12 +32,26 @@ struct PhysArgs {
     float* __restrict__ x_dof_force;  // [N,69]
     long long* prof;  // optional cycle counters per phase (block 0), NULL = off
     const int32_t* perm;  // [N] wave slot -> env (envs with similar contact load share a wave), NULL = identity
-    int32_t* pair_key;    // [N] number of touched links in the last substep (input of the next pairing)
+    int32_t* pair_hist;   // [256] envs per load bin (0 = heaviest), filled by atomics, consumed + cleared by the last workgroup
+    int32_t* pair_start;  // [256] first slot of each bin (exclusive scan of the histogram), written by the last workgroup
+    int32_t* pair_done;   // [1] workgroups that have finished
+    int32_t* pair_pos;    // [N] arrival index of the env inside its bin
+    int32_t* pair_key;    // [N] load key of the env (touched links of the last substep x 8 + depth of the deepest), 0..255
     unsigned long long par_pack[2];  // parents[24] and level order[24], 5 bits each, 12 per word: the tree walks of the
     unsigned long long ord_pack[2];  // impulse sweep decode them with scalar ALU ops instead of dependent scalar loads
     int64_t n;
     EnvParams p;
 };
 
+
+// ---- pairing (see physics_ll.hip): slot of env e in the next launch = first slot of its load bin + its arrival index there
+constexpr int PAIR_BINS = 256;
+struct PairView {
+    const int32_t* key;    // [N]
+    const int32_t* pos;    // [N]
+    const int32_t* start;  // [PAIR_BINS]
+    int32_t* perm;         // [N], NULL = nothing to scatter
+};
+__device__ __forceinline__ void pair_scatter(const PairView& pv, int64_t e) { pv.perm[pv.start[PAIR_BINS - 1 - pv.key[e]] + pv.pos[e]] = (int32_t)e; }
 
 }  // namespace v2p

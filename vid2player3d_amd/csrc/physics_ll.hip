@@ -608,6 +608,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                 // ======================================================== block Gauss-Seidel: k-th touched body of each env at once
                 for (int it = 0; it < P.n_iter; ++it) {
                     unsigned t0 = m0, t1 = m1;
+                    bool moved = false;
                     while (t0 | t1) {
                         const int b0 = t0 ? __ffs(t0) - 1 : -1, b1 = t1 ? __ffs(t1) - 1 : -1;
                         t0 &= t0 - 1;
@@ -649,6 +650,12 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                             }
                         }
                         LLSUB(11);
+                        // an update that changed no impulse (separated or saturated points) moves nothing: skip the propagation
+                        if (!__any(un.x != 0.f || un.y != 0.f || un.z != 0.f || uf.x != 0.f || uf.y != 0.f || uf.z != 0.f)) {
+                            if (a.prof && (blockIdx.x & 63) == 0 && lane == 0) atomicAdd((unsigned long long*)&a.prof[19], 1ull);
+                            continue;
+                        }
+                        moved = true;
                         // ---- net impulse (un, uf) at the touched link: leaf -> root along the path, level by level
                         V3 du{0.f, 0.f, 0.f};
                         for (int d = dneed; d >= 1; --d) {
@@ -694,6 +701,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                         }
                         LLSUB(14);
                     }
+                    if (!moved) break;  // a whole iteration without any change: the remaining ones would repeat it
                 }
                 // links below the deepest touched one: one catch-up pass with the accumulated motion of their parents
                 for (int d = dmin + 1; d <= maxd; ++d) {
@@ -768,8 +776,31 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
             xd = pxd + cross(pw, rr);
         }
     }
-    if (lb == 0 && live_env) {
-        a.pair_key[e] = ksum * 8 + (kdep > 7 ? 7 : kdep);  // touched links, then the deepest of them: what the sweep's cost follows
+    if (a.pair_hist) {
+        // ---- pairing key of this env (touched links, then the deepest of them: what the sweep's cost follows) into its load bin;
+        // the workgroup that finishes last turns the histogram into bin offsets for the scatter that builds the next launch's order
+        if (lb == 0 && live_env) {
+            int key = ksum * 8 + (kdep > 7 ? 7 : kdep);
+            key = key > PAIR_BINS - 1 ? PAIR_BINS - 1 : key;
+            const int pos = atomicAdd(&a.pair_hist[PAIR_BINS - 1 - key], 1);
+            a.pair_key[e] = key;
+            a.pair_pos[e] = pos;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's bin counts are in before its ticket is drawn
+        int ticket = -1;
+        if (lane == 0) ticket = atomicAdd(a.pair_done, 1);
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
+        if (ticket == (int)(gridDim.x * LL_WPB) - 1) {
+            int c[4], mine = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { c[k] = __hip_atomic_load(&a.pair_hist[4 * lane + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); mine += c[k]; }
+            int inc = mine;
+            for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+            int ex = inc - mine;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a.pair_start[4 * lane + k] = ex; ex += c[k]; a.pair_hist[4 * lane + k] = 0; }
+            if (lane == 0) *a.pair_done = 0;
+        }
     }
     if (valid && live_env) {
         if (b == 0) {
@@ -803,89 +834,39 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
 }
 
 // ---- pairing: the sweep of a wave costs max(touched links) of its two envs, so envs are handed to waves in descending order of
-// their touched-link count (stable counting sort -> deterministic; heavy waves first also keeps the tail of the launch short).
-// One workgroup, after every physics launch (the load of consecutive control steps is already only loosely correlated: a period
-// of 4 launches loses most of the gain).
-constexpr int PAIR_BINS = 256;
-__global__ __launch_bounds__(1024) void pair_sort_kernel(const int32_t* __restrict__ key, int32_t* __restrict__ perm, int64_t n) {
-    // wave w owns the contiguous env range [w*span, (w+1)*span): count per bin, prefix over (bin, wave), then place in order
-    __shared__ int cnt[16][PAIR_BINS];
-    __shared__ int start[PAIR_BINS];
-    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-    const int64_t span = ((n + 15) / 16 + 63) / 64 * 64;
-    const int64_t lo = wave * span, hi = lo + span < n ? lo + span : n;
-    for (int j = t; j < 16 * PAIR_BINS; j += 1024) (&cnt[0][0])[j] = 0;
-    __syncthreads();
-    auto bin_of = [&](int64_t i) { int k = key[i]; k = k < 0 ? 0 : (k > PAIR_BINS - 1 ? PAIR_BINS - 1 : k); return PAIR_BINS - 1 - k; };
-    auto match = [&](bool on, int k, int& rank, int& total) {  // lanes of this wave holding the same bin, in lane order
-        unsigned long long same = __ballot(on);
-#pragma unroll
-        for (int bit = 0; bit < 8; ++bit) {
-            const unsigned long long bm = __ballot((k >> bit) & 1);
-            same &= ((k >> bit) & 1) ? bm : ~bm;
-        }
-        rank = __popcll(same & ((1ull << lane) - 1ull));
-        total = __popcll(same);
-    };
-    for (int64_t i0 = lo; i0 < hi; i0 += 512) {  // 8 independent key loads in flight per lane
-        int ks[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const int64_t i = i0 + 64 * u + lane; ks[u] = i < hi ? bin_of(i) : -1; }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const bool on = ks[u] >= 0;
-            int rank, total;
-            match(on, on ? ks[u] : 0, rank, total);
-            if (on && rank == 0) cnt[wave][ks[u]] += total;
-        }
-    }
-    __syncthreads();
-    // exclusive prefix over waves inside each bin, bin totals -> start[]
-    if (t < PAIR_BINS) {
-        int acc = 0;
-        for (int w2 = 0; w2 < 16; ++w2) { const int c = cnt[w2][t]; cnt[w2][t] = acc; acc += c; }
-        start[t] = acc;
-    }
-    __syncthreads();
-    if (wave == 0) {  // exclusive scan of the 256 bin totals by one wave (4 bins per lane)
-        int v0 = start[4 * lane], v1 = start[4 * lane + 1], v2 = start[4 * lane + 2], v3 = start[4 * lane + 3];
-        const int mine = v0 + v1 + v2 + v3;
-        int inc = mine;
-        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
-        int ex = inc - mine;
-        start[4 * lane] = ex; start[4 * lane + 1] = ex + v0; start[4 * lane + 2] = ex + v0 + v1; start[4 * lane + 3] = ex + v0 + v1 + v2;
-    }
-    __syncthreads();
-    for (int64_t i0 = lo; i0 < hi; i0 += 512) {
-        int ks[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const int64_t i = i0 + 64 * u + lane; ks[u] = i < hi ? bin_of(i) : -1; }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const bool on = ks[u] >= 0;
-            const int k = on ? ks[u] : 0;
-            int rank, total;
-            match(on, k, rank, total);
-            int off = 0;
-            if (on) off = start[k] + cnt[wave][k] + rank;
-            if (on && rank == 0) cnt[wave][k] += total;  // wave-private row: program order within the wave is enough
-            if (on) perm[off] = (int32_t)(i0 + 64 * u + lane);
-        }
-    }
+// their contact load (heavy waves first also keeps the tail of the launch short).  A counting sort spread over the kernels that
+// run anyway: every env draws an arrival index in its load bin at the end of the physics kernel (atomics), the workgroup that
+// finishes last scans the 256 bin counts, and the scatter slot = start[bin] + index happens in the next pre-physics kernel (or
+// in the small kernel below when pre-physics is not called between two launches).  The order inside a bin depends on arrival,
+// which is harmless: an env's arithmetic does not depend on the env it shares a wave with (tests: bit-identical results).
+__global__ void pair_scatter_kernel(PairView pv, int64_t n) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) pair_scatter(pv, e);
 }
 
 bool env_pairing_on(const v2p_env* env) { return env->pair_period > 0 && env->schedule == 0 && env->p.enable_contact && env->n > 2; }
 
+PairView env_pair_view(const v2p_env* env) { return PairView{env->pair_key, env->pair_pos, env->pair_start, env->perm}; }
+
 int launch_env_pairing(v2p_env* env, hipStream_t s) {
-    hipLaunchKernelGGL(pair_sort_kernel, dim3(1), dim3(1024), 0, s, env->pair_key, env->perm, env->n);
-    return check_hip(hipGetLastError(), "pair_sort_kernel");
+    hipLaunchKernelGGL(pair_scatter_kernel, dim3((unsigned)((env->n + 255) / 256)), dim3(256), 0, s, env_pair_view(env), env->n);
+    env->pair_have = 0;
+    return check_hip(hipGetLastError(), "pair_scatter_kernel");
 }
 
 int launch_env_physics_ll(v2p_env* env, hipStream_t s) {
     const bool paired = env_pairing_on(env);
+    if (paired && env->pair_have) {  // pre-physics has not consumed the last launch's keys
+        int rc = launch_env_pairing(env, s);
+        if (rc != V2P_OK) return rc;
+    }
     PhysArgs a = {};
     a.perm = paired ? env->perm : nullptr;
     a.pair_key = env->pair_key;
+    a.pair_pos = env->pair_pos;
+    a.pair_hist = paired ? env->pair_hist : nullptr;
+    a.pair_start = env->pair_start;
+    a.pair_done = env->pair_done;
     a.model = env->model->dev;
     a.state = env->state;
     a.ctrl = env->ctrl;
@@ -906,6 +887,7 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s) {
         hipLaunchKernelGGL(physics_ll_kernel<true>, dim3(blocks), dim3(64 * LL_WPB), lds, s, a);
     else
         hipLaunchKernelGGL(physics_ll_kernel<false>, dim3(blocks), dim3(64 * LL_WPB), 0, s, a);
+    env->pair_have = paired ? 1 : 0;
     return check_hip(hipGetLastError(), "physics_ll_kernel");
 }
 

@@ -6,6 +6,7 @@
 #include <math.h>
 
 #include "motion_sample.hpp"
+#include "phys_common.hpp"
 
 namespace v2p {
 
@@ -249,6 +250,7 @@ struct EnvView {
     float* out;
     int64_t n;
     int cur;  // current target buffer
+    PairView pair;  // pre-physics only: scatter of the pairing order for the next physics launch (perm NULL = none)
 };
 
 static EnvView make_view(const v2p_env* e) {
@@ -262,6 +264,7 @@ static EnvView make_view(const v2p_env* e) {
     v.out = e->out;
     v.n = e->n;
     v.cur = e->cur_target;
+    v.pair = PairView{nullptr, nullptr, nullptr, nullptr};
     return v;
 }
 
@@ -375,6 +378,7 @@ __global__ void env_pre_kernel(EnvView v, float* __restrict__ actions) {
     int64_t e = tid / NACT;
     int a = (int)(tid - e * NACT);
     if (e >= v.n) return;
+    if (a == 0 && v.pair.perm) pair_scatter(v.pair, e);
     bool dead = v.b.reset[e] == 1;
     float act = actions[tid];
     if (dead) { act = 0.f; actions[tid] = 0.f; }  // in place on the caller's tensor, like the reference
@@ -397,6 +401,10 @@ __global__ void env_pre_kernel(EnvView v, float* __restrict__ actions) {
 
 int launch_env_pre(v2p_env* env, float* actions, hipStream_t s) {
     EnvView v = make_view(env);
+    if (env_pairing_on(env) && env->pair_have) {  // the wave order of the next physics launch, from the keys the last one left
+        v.pair = env_pair_view(env);
+        env->pair_have = 0;
+    }
     int64_t threads = env->n * NACT;
     unsigned blocks = (unsigned)((threads + 255) / 256);
     hipLaunchKernelGGL(env_pre_kernel, dim3(blocks), dim3(256), 0, s, v, actions);

@@ -109,9 +109,15 @@ struct v2p_env {
     float* ws;                // SoA [WS_SLOTS][N] physics workspace
     int32_t* contact_ids;     // [N,24,4] debug
     long long* prof;          // [8] phase cycle counters when V2P_PHASE_TIMING is set (device), else NULL
-    int32_t* pair_key;        // [N] touched-link count per env, written by the link-per-lane kernel
-    int32_t* perm;            // [N] wave slot -> env, rebuilt from pair_key after every physics launch
+    // pairing (physics_ll.hip): envs are handed to waves in descending order of their contact load
+    int32_t* pair_key;        // [N] load key of each env after the last physics launch (0..255)
+    int32_t* pair_pos;        // [N] arrival index inside its load bin
+    int32_t* pair_hist;       // [256] + pair_start [256] + pair_done [1] (one allocation)
+    int32_t* pair_start;
+    int32_t* pair_done;
+    int32_t* perm;            // [N] wave slot -> env for the next physics launch
     int pair_period;          // 0 = pairing off (V2P_PAIR_PERIOD=0), else on
+    int pair_have;            // the last physics launch left (key, pos, start) that have not been scattered into perm yet
 };
 
 namespace v2p {
@@ -151,7 +157,9 @@ int launch_env_pre(v2p_env* e, float* actions, hipStream_t s);
 int launch_env_physics(v2p_env* e, hipStream_t s);
 int launch_env_physics_ll(v2p_env* e, hipStream_t s);
 bool env_pairing_on(const v2p_env* e);
-int launch_env_pairing(v2p_env* e, hipStream_t s);
+struct PairView;
+PairView env_pair_view(const v2p_env* e);
+int launch_env_pairing(v2p_env* e, hipStream_t s);  // scatter (key, pos, start) -> perm when env_pre_kernel has not done it
 int launch_env_export(v2p_env* e, hipStream_t s);
 int launch_env_post(v2p_env* e, hipStream_t s);
 int launch_env_push_state(v2p_env* e, const int64_t* env_ids, int64_t n, int with_rb, hipStream_t s);
