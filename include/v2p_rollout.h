@@ -184,6 +184,12 @@ typedef struct {
  * array (each env is bound to one clip, humanoid_smpl_im.py:247-254). */
 int v2p_env_create(const v2p_model* model, const v2p_mlib* mlib, const v2p_sim_cfg* cfg, const int64_t* env_motion_id,
                    int64_t num_envs, const v2p_env_buffers* buffers, int device, v2p_env** out);
+/* The same with one body SHAPE per env: the reference builds one humanoid asset per sampled clip from its SMPL betas and
+ * scale (humanoid_smpl_im.py:255-296, _create_smpl_humanoid_xml) and gives env i the asset of its clip.  `shapes` are
+ * models with identical body trees, `env_shape_id` [N] is a HOST array of indices into `shapes` (copied). */
+int v2p_env_create_shapes(const v2p_model* const* shapes, int32_t num_shapes, const int32_t* env_shape_id, const v2p_mlib* mlib,
+                          const v2p_sim_cfg* cfg, const int64_t* env_motion_id, int64_t num_envs, const v2p_env_buffers* buffers,
+                          int device, v2p_env** out);
 void v2p_env_destroy(v2p_env* e);
 
 /* HumanoidSMPL.reset(env_ids) with reference-state init (humanoid_smpl.py:136-173,

@@ -22,9 +22,10 @@ def mlib():
     return MotionLib(synth_tables(seed=5, num_clips=8, min_frames=60, max_frames=120), DEV)
 
 
-def _run_pair(mlib, n, contact, seed, lift=0.0, vel_sigma=0.5, steps=1, hold="first_sim"):
+def _run_pair(mlib, n, contact, seed, lift=0.0, vel_sigma=0.5, steps=1, hold="first_sim", shapes=None):
     rng = np.random.default_rng(seed)
-    task = make_task(n, mlib, enable_contact=contact, residual_force_hold=hold)
+    extra = {} if shapes is None else {"body_model": shapes}
+    task = make_task(n, mlib, enable_contact=contact, residual_force_hold=hold, **extra)
     times = T(rng.uniform(0.1, 1.0, size=n))
     task.reset_with_times(None, times)
     # perturb the reference state so that the drives, Coriolis terms and contacts all have work to do
@@ -40,6 +41,8 @@ def _run_pair(mlib, n, contact, seed, lift=0.0, vel_sigma=0.5, steps=1, hold="fi
     bm = task.body_model
     oracles = []
     for e in range(n):
+        if shapes is not None:
+            bm = shapes[task._env_shape_ids[e]]  # the oracle of env e simulates the body shape of its clip
         o = PhysOracle(bm, default_params(enable_contact=contact), kp=bm.kp.astype(np.float32), kd=bm.kd.astype(np.float32))
         o.set_state(root[e], dpos[e], dvel[e])
         oracles.append(o)
@@ -54,7 +57,7 @@ def _run_pair(mlib, n, contact, seed, lift=0.0, vel_sigma=0.5, steps=1, hold="fi
         torch.cuda.synchronize()
         pd_tar = N(task._pd_target)
         # wrench from the numpy oracle of pre_physics on the same inputs
-        _, pd_ref, _, force, torque = O.pre_physics(act, N(task.reset_buf), dpos_before, rb0[:, 0, 3:7], bm.kp.astype(np.float32))
+        _, pd_ref, _, force, torque = O.pre_physics(act, N(task.reset_buf), dpos_before, rb0[:, 0, 3:7], task.body_model.kp.astype(np.float32))
         close(pd_tar, pd_ref, 1e-6, "pd target")
         res = {"root": [], "dpos": [], "dvel": [], "rb": [], "cf": [], "df": [], "ids": []}
         for e in range(n):
@@ -259,3 +262,32 @@ def test_pairing_order_is_a_descending_permutation(mlib, n):
     task.step(a.clone())
     check()
     task.close()
+
+
+def test_per_env_body_shapes_match_oracle():
+    """One body shape per clip (the reference builds one asset per clip from its betas / scale, humanoid_smpl_im.py:255-296):
+    eight uniformly scaled variants of the body, env i simulates the shape of its clip; every env against its own oracle."""
+    from vid2player3d_amd import synth
+    from vid2player3d_amd.model import load_baked_model
+    from vid2player3d_amd.motion_lib import MotionLib
+
+    base = load_baked_model()
+    shapes = [base.scaled(s) for s in (0.85, 0.9, 0.95, 1.0, 1.05, 1.1, 1.15, 1.2)]
+    assert abs(shapes[0].total_mass / base.total_mass - 0.85 ** 3) < 1e-9
+    clips = synth.make_clips(5, 8, 60, 120)
+    lib = MotionLib.from_clips(clips, shapes, DEV)
+    for contact, lift, seed in ((False, 0.0, 41), (True, -0.05, 42)):
+        (got, ref), = _run_pair(lib, 48, contact, seed, lift=lift, shapes=shapes)
+        if contact:
+            same = np.all(got["ids"] == ref["ids"], axis=(1, 2))
+            assert same.mean() > 0.9 and (ref["ids"] >= 0).any(axis=(1, 2)).mean() > 0.8
+            got, ref = {k: v[same] for k, v in got.items()}, {k: v[same] for k, v in ref.items()}
+            close(got["cf"], ref["cf"], TOL_FORCE, "contact force")
+        _compare(got, ref, "shapes contact=%s" % contact)
+    # the shapes really differ: pelvis height of the rest pose scales with the body
+    t = make_task(16, lib, body_model=shapes)
+    h = N(t.smpl_rest_joints)[:, :, :].copy()
+    assert not np.allclose(h[0], h[7])
+    with pytest.raises(RuntimeError):
+        t.set_schedule("env_per_lane")  # the cross-check kernel is single-shape
+    t.close()

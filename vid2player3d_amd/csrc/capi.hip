@@ -67,11 +67,11 @@ int v2p_model_create(const v2p_model_desc* d, int device, v2p_model** out) {
         h.parents[b] = p;
         h.depth[b] = b == 0 ? 0 : h.depth[p] + 1;
         if (h.depth[b] >= MAX_DEPTH) { set_error("v2p_model_create: tree depth exceeds %d", MAX_DEPTH); delete m; return V2P_ERR_UNSUPPORTED; }
-        for (int k = 0; k < 3; ++k) { h.local_pos[b][k] = d->local_pos[3 * b + k]; h.com[b][k] = d->com[3 * b + k]; }
-        h.mass[b] = d->mass[b];
+        for (int k = 0; k < 3; ++k) { h.shape.local_pos[b][k] = d->local_pos[3 * b + k]; h.shape.com[b][k] = d->com[3 * b + k]; }
+        h.shape.mass[b] = d->mass[b];
         const float* I = d->inertia + 9 * b;
-        h.inertia[b][0] = I[0]; h.inertia[b][1] = 0.5f * (I[1] + I[3]); h.inertia[b][2] = 0.5f * (I[2] + I[6]);
-        h.inertia[b][3] = I[4]; h.inertia[b][4] = 0.5f * (I[5] + I[7]); h.inertia[b][5] = I[8];
+        h.shape.inertia[b][0] = I[0]; h.shape.inertia[b][1] = 0.5f * (I[1] + I[3]); h.shape.inertia[b][2] = 0.5f * (I[2] + I[6]);
+        h.shape.inertia[b][3] = I[4]; h.shape.inertia[b][4] = 0.5f * (I[5] + I[7]); h.shape.inertia[b][5] = I[8];
         if (b > 0) {
             const float *kp = d->kp + 3 * (b - 1), *kd = d->kd + 3 * (b - 1), *ar = d->armature + 3 * (b - 1);
             if (kp[0] != kp[1] || kp[0] != kp[2] || kd[0] != kd[1] || kd[0] != kd[2] || ar[0] != ar[1] || ar[0] != ar[2]) {
@@ -79,7 +79,7 @@ int v2p_model_create(const v2p_model_desc* d, int device, v2p_model** out) {
                 delete m;
                 return V2P_ERR_UNSUPPORTED;
             }
-            h.kp[b] = kp[0]; h.kd[b] = kd[0]; h.arm[b] = ar[0];
+            h.shape.kp[b] = kp[0]; h.shape.kd[b] = kd[0]; h.shape.arm[b] = ar[0];
         }
     }
     {
@@ -89,26 +89,26 @@ int v2p_model_create(const v2p_model_desc* d, int device, v2p_model** out) {
             int np = (n + HULL_PAD - 1) / HULL_PAD * HULL_PAD;
             if (n < 1 || n > 64) { set_error("v2p_model_create: body %d has %d hull vertices (1..64 supported)", b, n); delete m; return V2P_ERR_UNSUPPORTED; }
             if (off + np > MAX_HULL_VERTS) { set_error("v2p_model_create: padded hull vertices exceed the limit %d", MAX_HULL_VERTS); delete m; return V2P_ERR_UNSUPPORTED; }
-            h.hull_offsets[b] = off;
-            h.hull_count[b] = n;
+            h.shape.hull_offsets[b] = off;
+            h.shape.hull_count[b] = n;
             float r2 = 0.f, lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
             for (int v = 0; v < np; ++v) {
                 const float* src = d->hull_verts + 3 * (d->hull_offsets[b] + (v < n ? v : n - 1));
                 for (int k = 0; k < 3; ++k) {
-                    h.hull_verts[off + v][k] = src[k];
+                    h.shape.hull_verts[off + v][k] = src[k];
                     lo[k] = src[k] < lo[k] ? src[k] : lo[k];
                     hi[k] = src[k] > hi[k] ? src[k] : hi[k];
                 }
                 float n2 = src[0] * src[0] + src[1] * src[1] + src[2] * src[2];
                 if (n2 > r2) r2 = n2;
             }
-            h.bound_radius[b] = sqrtf(r2);
-            for (int k = 0; k < 3; ++k) { h.aabb_c[b][k] = 0.5f * (lo[k] + hi[k]); h.aabb_e[b][k] = 0.5f * (hi[k] - lo[k]) * 1.0001f + 1e-6f; }
+            h.shape.bound_radius[b] = sqrtf(r2);
+            for (int k = 0; k < 3; ++k) { h.shape.aabb_c[b][k] = 0.5f * (lo[k] + hi[k]); h.shape.aabb_e[b][k] = 0.5f * (hi[k] - lo[k]) * 1.0001f + 1e-6f; }
             off += np;
         }
-        h.hull_offsets[NB] = off;
-        h.hull_cofs[0] = 0;
-        for (int b = 0; b < NB; ++b) h.hull_cofs[b + 1] = h.hull_cofs[b] + h.hull_count[b];
+        h.shape.hull_offsets[NB] = off;
+        h.shape.hull_cofs[0] = 0;
+        for (int b = 0; b < NB; ++b) h.shape.hull_cofs[b + 1] = h.shape.hull_cofs[b] + h.shape.hull_count[b];
     }
     {
         int k = 0;
@@ -126,7 +126,7 @@ int v2p_model_create(const v2p_model_desc* d, int device, v2p_model** out) {
             for (int k = 0; k < 3; ++k) h.children[b][k] = -1;
             h.anc_mask[b] = 1 << b;
             if (h.depth[b] > h.max_depth) h.max_depth = h.depth[b];
-            if (h.hull_count[b] > h.max_hull_count) h.max_hull_count = h.hull_count[b];
+            if (h.shape.hull_count[b] > h.max_hull_count) h.max_hull_count = h.shape.hull_count[b];
         }
         for (int b = 1; b < NB; ++b) {
             int p = h.parents[b];
@@ -232,8 +232,22 @@ int v2p_gae(int64_t horizon, int64_t n, const float* fdones, const float* values
     return launch_gae(horizon, n, fdones, values, rewards, next_values, gamma, tau, advs, (hipStream_t)stream);
 }
 
-int v2p_env_create(const v2p_model* model, const v2p_mlib* mlib, const v2p_sim_cfg* c, const int64_t* env_motion_id, int64_t n,
-                   const v2p_env_buffers* b, int device, v2p_env** out) {
+static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, const int32_t* env_shape_id, const v2p_mlib* mlib,
+                           const v2p_sim_cfg* c, const int64_t* env_motion_id, int64_t n, const v2p_env_buffers* b, int device, v2p_env** out) {
+    if (!shapes || num_shapes < 1 || !shapes[0]) { set_error("v2p_env_create: bad argument"); return V2P_ERR_INVALID; }
+    const v2p_model* model = shapes[0];
+    for (int32_t k = 1; k < num_shapes; ++k) {
+        if (!shapes[k] || shapes[k]->device != device) { set_error("v2p_env_create_shapes: shape %d is null or lives on another device", k); return V2P_ERR_INVALID; }
+        if (memcmp(shapes[k]->host.parents, model->host.parents, sizeof(model->host.parents))) {
+            set_error("v2p_env_create_shapes: shape %d has a different body tree", k);
+            return V2P_ERR_UNSUPPORTED;
+        }
+    }
+    if (num_shapes > 1) {
+        if (!env_shape_id) { set_error("v2p_env_create_shapes: env_shape_id is null"); return V2P_ERR_INVALID; }
+        for (int64_t i = 0; i < n; ++i)
+            if (env_shape_id[i] < 0 || env_shape_id[i] >= num_shapes) { set_error("v2p_env_create_shapes: env %lld has shape id %d", (long long)i, env_shape_id[i]); return V2P_ERR_INVALID; }
+    }
     if (!model || !mlib || !c || !env_motion_id || !b || !out || n <= 0) { set_error("v2p_env_create: bad argument"); return V2P_ERR_INVALID; }
     if (model->device != device || mlib->device != device) { set_error("v2p_env_create: model/motion-lib live on another device"); return V2P_ERR_INVALID; }
     const void* req[] = {b->root_states, b->dof_state, b->rb_state, b->contact_force, b->dof_force, b->pd_target, b->obs, b->rew,
@@ -274,7 +288,8 @@ int v2p_env_create(const v2p_model* model, const v2p_mlib* mlib, const v2p_sim_c
     memcpy(p.term_heights, c->term_heights, sizeof(p.term_heights));
     memcpy(p.body_pos_weights, c->body_pos_weights, sizeof(p.body_pos_weights));
     memcpy(p.reward_specs, c->reward_specs, sizeof(p.reward_specs));
-    for (int b = 0; b < NB; ++b) p.aug[b] = b ? model->host.arm[b] + p.h * model->host.kd[b] + p.h * p.h * model->host.kp[b] : 0.f;
+    for (int b = 0; b < NB; ++b) p.aug[b] = b ? model->host.shape.arm[b] + p.h * model->host.shape.kd[b] + p.h * p.h * model->host.shape.kp[b] : 0.f;
+    e->num_shapes = num_shapes;
     DeviceGuard g(device);
     if (!g.ok) { set_error("v2p_env_create: cannot select device %d", device); delete e; return V2P_ERR_HIP; }
     size_t N = (size_t)n;
@@ -288,6 +303,21 @@ int v2p_env_create(const v2p_model* model, const v2p_mlib* mlib, const v2p_sim_c
     if (rc == V2P_OK) rc = check_hip(hipMemset(e->out, 0, sizeof(float) * OUT_SLOTS * N), "hipMemset(out)");
     if (rc == V2P_OK) rc = check_hip(hipMemset(e->ws, 0, sizeof(float) * (size_t)physics_ws_slots() * N), "hipMemset(ws)");
     if (rc == V2P_OK) rc = check_hip(hipMemset(e->contact_ids, 0xff, sizeof(int32_t) * NB * 4 * N), "hipMemset(contact_ids)");
+    if (rc == V2P_OK && num_shapes > 1) {
+        // per-env body shapes: the numeric tables of every shape + each shape's joint-diagonal augmentation, indexed by env_shape
+        std::vector<float> aug((size_t)num_shapes * NB, 0.f);
+        rc = check_hip(hipMalloc((void**)&e->shapes_dev, sizeof(DevShape) * (size_t)num_shapes), "hipMalloc(shapes)");
+        for (int32_t k = 0; k < num_shapes && rc == V2P_OK; ++k) {
+            const DevShape& sh = shapes[k]->host.shape;
+            rc = check_hip(hipMemcpy(e->shapes_dev + k, &sh, sizeof(DevShape), hipMemcpyHostToDevice), "hipMemcpy(shape)");
+            for (int bb = 1; bb < NB; ++bb) aug[(size_t)k * NB + bb] = sh.arm[bb] + p.h * sh.kd[bb] + p.h * p.h * sh.kp[bb];
+        }
+        if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->shape_aug_dev, sizeof(float) * aug.size()), "hipMalloc(shape_aug)");
+        if (rc == V2P_OK) rc = check_hip(hipMemcpy(e->shape_aug_dev, aug.data(), sizeof(float) * aug.size(), hipMemcpyHostToDevice), "hipMemcpy(shape_aug)");
+        if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->env_shape_dev, sizeof(int32_t) * N), "hipMalloc(env_shape)");
+        if (rc == V2P_OK) rc = check_hip(hipMemcpy(e->env_shape_dev, env_shape_id, sizeof(int32_t) * N, hipMemcpyHostToDevice), "hipMemcpy(env_shape)");
+        if (rc == V2P_OK) e->schedule = 0;  // the env-per-lane cross-check kernel is single-shape
+    }
     e->pair_period = getenv("V2P_PAIR_PERIOD") ? atoi(getenv("V2P_PAIR_PERIOD")) : 1;
     if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->pair_key, sizeof(int32_t) * N), "hipMalloc(pair_key)");
     if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->pair_pos, sizeof(int32_t) * N), "hipMalloc(pair_pos)");
@@ -315,6 +345,16 @@ int v2p_env_create(const v2p_model* model, const v2p_mlib* mlib, const v2p_sim_c
     return V2P_OK;
 }
 
+int v2p_env_create(const v2p_model* model, const v2p_mlib* mlib, const v2p_sim_cfg* c, const int64_t* env_motion_id, int64_t n,
+                   const v2p_env_buffers* b, int device, v2p_env** out) {
+    return env_create_impl(&model, 1, nullptr, mlib, c, env_motion_id, n, b, device, out);
+}
+
+int v2p_env_create_shapes(const v2p_model* const* shapes, int32_t num_shapes, const int32_t* env_shape_id, const v2p_mlib* mlib,
+                          const v2p_sim_cfg* c, const int64_t* env_motion_id, int64_t n, const v2p_env_buffers* b, int device, v2p_env** out) {
+    return env_create_impl(shapes, num_shapes, env_shape_id, mlib, c, env_motion_id, n, b, device, out);
+}
+
 void v2p_env_destroy(v2p_env* e) {
     if (!e) return;
     DeviceGuard g(e->device);
@@ -323,6 +363,9 @@ void v2p_env_destroy(v2p_env* e) {
     if (e->out) (void)hipFree(e->out);
     if (e->ws) (void)hipFree(e->ws);
     if (e->contact_ids) (void)hipFree(e->contact_ids);
+    if (e->shapes_dev) (void)hipFree(e->shapes_dev);
+    if (e->shape_aug_dev) (void)hipFree(e->shape_aug_dev);
+    if (e->env_shape_dev) (void)hipFree(e->env_shape_dev);
     if (e->pair_key) (void)hipFree(e->pair_key);
     if (e->pair_pos) (void)hipFree(e->pair_pos);
     if (e->pair_hist) (void)hipFree(e->pair_hist);
@@ -389,6 +432,7 @@ int v2p_env_push_state(v2p_env* e, const int64_t* env_ids, int64_t n, int with_r
 
 int v2p_env_set_schedule(v2p_env* e, int schedule) {
     if (!e || (schedule != 0 && schedule != 1)) { set_error("v2p_env_set_schedule: bad argument"); return V2P_ERR_INVALID; }
+    if (schedule == 1 && e->num_shapes > 1) { set_error("v2p_env_set_schedule: the env-per-lane kernel handles single-shape batches only"); return V2P_ERR_UNSUPPORTED; }
     e->schedule = schedule;
     return V2P_OK;
 }

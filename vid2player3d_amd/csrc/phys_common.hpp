@@ -31,6 +31,9 @@ struct PhysArgs {
     float* __restrict__ x_contact;  // [N,24,3]
     float* __restrict__ x_dof_force;  // [N,69]
     long long* prof;  // optional cycle counters per phase (block 0), NULL = off
+    const DevShape* shapes;    // [num_shapes] per-env body shapes (multi-shape batches only)
+    const int32_t* env_shape;  // [N] shape of each env
+    const float* shape_aug;    // [num_shapes][24] joint-diagonal augmentation of each shape
     const int32_t* perm;  // [N] wave slot -> env (envs with similar contact load share a wave), NULL = identity
     int32_t* pair_hist;   // [256] envs per load bin (0 = heaviest), filled by atomics, consumed + cleared by the last workgroup
     int32_t* pair_start;  // [256] first slot of each bin (exclusive scan of the histogram), written by the last workgroup

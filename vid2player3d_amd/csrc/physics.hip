@@ -163,7 +163,7 @@ __global__ __launch_bounds__(L) void physics_kernel(PhysArgs a) {
                 V3 xp = xyz(SG(par, 1)), wp = xyz(pg2), xdp{pg2.w, pg3.x, pg3.y};
                 q = qnormalize(qmul(qp, jq));
                 M3 Rp = q2mat(qp);
-                r = mul(Rp, V3{M.local_pos[b][0], M.local_pos[b][1], M.local_pos[b][2]});
+                r = mul(Rp, V3{M.shape.local_pos[b][0], M.shape.local_pos[b][1], M.shape.local_pos[b][2]});
                 x = xp + r;
                 M3 Rb = q2mat(q);
                 V3 wrel = mul(Rb, wt);
@@ -174,14 +174,14 @@ __global__ __launch_bounds__(L) void physics_kernel(PhysArgs a) {
                 zv = cross(wp, wpr);
                 // implicit PD drive: kp (q_tar - q) - (kd + h kp) wrel, q = exp-map of the joint quaternion
                 V3 qe = quat_to_expmap_stable(jq);
-                float kp = M.kp[b], kdh = M.kd[b] + h * M.kp[b];
+                float kp = M.shape.kp[b], kdh = M.shape.kd[b] + h * M.shape.kp[b];
                 tau = mul(Rb, kp * (tar - qe) - kdh * wt);
             }
             M3 R = q2mat(q);
             // body inertia at its origin, world axes
-            const float m = M.mass[b];
-            V3 d = mul(R, V3{M.com[b][0], M.com[b][1], M.com[b][2]});
-            Sym3 Ib{M.inertia[b][0], M.inertia[b][1], M.inertia[b][2], M.inertia[b][3], M.inertia[b][4], M.inertia[b][5]};
+            const float m = M.shape.mass[b];
+            V3 d = mul(R, V3{M.shape.com[b][0], M.shape.com[b][1], M.shape.com[b][2]});
+            Sym3 Ib{M.shape.inertia[b][0], M.shape.inertia[b][1], M.shape.inertia[b][2], M.shape.inertia[b][3], M.shape.inertia[b][4], M.shape.inertia[b][5]};
             V3 c0 = mul(Ib, V3{R.m[0], R.m[1], R.m[2]});  // Ic = R Ib R^T
             V3 c1 = mul(Ib, V3{R.m[3], R.m[4], R.m[5]});
             V3 c2 = mul(Ib, V3{R.m[6], R.m[7], R.m[8]});
@@ -354,17 +354,17 @@ __global__ __launch_bounds__(L) void physics_kernel(PhysArgs a) {
             for (int b = 0; b < NB; ++b) {
                 V3 x = xyz(SG(b, 1));
                 int cnt = 0;
-                bool near = x.z - M.bound_radius[b] < coff;
+                bool near = x.z - M.shape.bound_radius[b] < coff;
                 if (__any(near)) {
                     M3 R = q2mat(ld_q(b));
-                    const int v0 = M.hull_offsets[b], nv = M.hull_count[b];
+                    const int v0 = M.shape.hull_offsets[b], nv = M.shape.hull_count[b];
                     int f0 = -1, f1 = -1, f2 = -1, f3 = -1, k0 = -1;
                     float zmin = 0.f;
                     // vertex lists are padded to a multiple of HULL_PAD: 8 vertices = 24 consecutive floats per batch of scalar loads
                     for (int vb = 0; vb < nv; vb += HULL_PAD) {
                         float hv[3 * HULL_PAD];
 #pragma unroll
-                        for (int k = 0; k < 3 * HULL_PAD; ++k) hv[k] = (&M.hull_verts[v0 + vb][0])[k];
+                        for (int k = 0; k < 3 * HULL_PAD; ++k) hv[k] = (&M.shape.hull_verts[v0 + vb][0])[k];
 #pragma unroll
                         for (int j = 0; j < HULL_PAD; ++j) {
                             const int i = vb + j;
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(L) void physics_kernel(PhysArgs a) {
                     if (__any(cnt > 4)) {
                         // manifold reduction: deepest, farthest from it, extreme on either side of that line
                         int kk0 = k0 < 0 ? 0 : k0;
-                        V3 u0{M.hull_verts[v0 + kk0][0], M.hull_verts[v0 + kk0][1], M.hull_verts[v0 + kk0][2]};
+                        V3 u0{M.shape.hull_verts[v0 + kk0][0], M.shape.hull_verts[v0 + kk0][1], M.shape.hull_verts[v0 + kk0][2]};
                         float p0x = x.x + R.m[0] * u0.x + R.m[1] * u0.y + R.m[2] * u0.z;
                         float p0y = x.y + R.m[3] * u0.x + R.m[4] * u0.y + R.m[5] * u0.z;
                         int k1 = -1;
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(L) void physics_kernel(PhysArgs a) {
                         for (int vb = 0; vb < nv; vb += HULL_PAD) {
                             float hv[3 * HULL_PAD];
 #pragma unroll
-                            for (int k = 0; k < 3 * HULL_PAD; ++k) hv[k] = (&M.hull_verts[v0 + vb][0])[k];
+                            for (int k = 0; k < 3 * HULL_PAD; ++k) hv[k] = (&M.shape.hull_verts[v0 + vb][0])[k];
 #pragma unroll
                             for (int j = 0; j < HULL_PAD; ++j) {
                                 const int i = vb + j;
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(L) void physics_kernel(PhysArgs a) {
                             }
                         }
                         int kk1 = k1 < 0 ? 0 : k1;
-                        V3 u1{M.hull_verts[v0 + kk1][0], M.hull_verts[v0 + kk1][1], M.hull_verts[v0 + kk1][2]};
+                        V3 u1{M.shape.hull_verts[v0 + kk1][0], M.shape.hull_verts[v0 + kk1][1], M.shape.hull_verts[v0 + kk1][2]};
                         float ex = x.x + R.m[0] * u1.x + R.m[1] * u1.y + R.m[2] * u1.z - p0x;
                         float ey = x.y + R.m[3] * u1.x + R.m[4] * u1.y + R.m[5] * u1.z - p0y;
                         int k2 = -1, k3 = -1;
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(L) void physics_kernel(PhysArgs a) {
                         for (int vb = 0; vb < nv; vb += HULL_PAD) {
                             float hv[3 * HULL_PAD];
 #pragma unroll
-                            for (int k = 0; k < 3 * HULL_PAD; ++k) hv[k] = (&M.hull_verts[v0 + vb][0])[k];
+                            for (int k = 0; k < 3 * HULL_PAD; ++k) hv[k] = (&M.shape.hull_verts[v0 + vb][0])[k];
 #pragma unroll
                             for (int j = 0; j < HULL_PAD; ++j) {
                                 const int i = vb + j;
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(L) void physics_kernel(PhysArgs a) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         int vi = sel[c] < 0 ? 0 : sel[c];
-                        V3 rr = mul(R, V3{M.hull_verts[v0 + vi][0], M.hull_verts[v0 + vi][1], M.hull_verts[v0 + vi][2]});
+                        V3 rr = mul(R, V3{M.shape.hull_verts[v0 + vi][0], M.shape.hull_verts[v0 + vi][1], M.shape.hull_verts[v0 + vi][2]});
                         G(b, GCR + 3 * c) = rr.x; G(b, GCR + 3 * c + 1) = rr.y; G(b, GCR + 3 * c + 2) = rr.z;
                         float d = x.z + rr.z;
                         G(b, GCB + c) = d >= 0.f ? d / h : fmaxf(P.erp * d / h, -P.max_depen);
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(L) void physics_kernel(PhysArgs a) {
                 V3 qe = quat_to_expmap_stable(jq);
                 const int cb = CT_PD + 3 * (b - 1);
                 V3 tar{a.ctrl[CIDX(cb + 0)], a.ctrl[CIDX(cb + 1)], a.ctrl[CIDX(cb + 2)]};
-                V3 tf = M.kp[b] * (tar - qe - h * wt) - M.kd[b] * wt;
+                V3 tf = M.shape.kp[b] * (tar - qe - h * wt) - M.shape.kd[b] * wt;
                 const int ob = OUT_DOF_FORCE + 3 * (b - 1);
                 a.out[OIDX(ob + 0)] = tf.x; a.out[OIDX(ob + 1)] = tf.y; a.out[OIDX(ob + 2)] = tf.z;
             }
@@ -734,7 +734,7 @@ __global__ __launch_bounds__(L) void physics_kernel(PhysArgs a) {
             Q4 qp = ld_q(par);
             V3 xp = xyz(SG(par, 1)), wp = xyz(pg2), xdp{pg2.w, pg3.x, pg3.y};
             q = qnormalize(qmul(qp, jq));
-            V3 r = mul(q2mat(qp), V3{M.local_pos[b][0], M.local_pos[b][1], M.local_pos[b][2]});
+            V3 r = mul(q2mat(qp), V3{M.shape.local_pos[b][0], M.shape.local_pos[b][1], M.shape.local_pos[b][2]});
             x = xp + r;
             w = wp + mul(q2mat(q), wt);
             xd = xdp + cross(wp, r);

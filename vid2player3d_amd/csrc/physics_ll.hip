@@ -110,7 +110,7 @@ __device__ __forceinline__ void grp_argmax(float& v, int& k) {
 #define V2P_LL_WPS 2   // waves per SIMD the register budget is set for
 #endif
 constexpr int LL_WPB = V2P_LL_WPB;
-template <bool CONTACT>
+template <bool CONTACT, bool MULTI>
 __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(PhysArgs a) {
     const int64_t N = a.n;
     const int lane = threadIdx.x & 63;
@@ -124,6 +124,9 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
     int64_t e = live_env ? slot : N - 1;
     if (a.perm) e = a.perm[e];
     ConstModel& M = *(ConstModel*)a.model;
+    // numeric data of this env's body shape: the model's own shape, or (MULTI) one of the batch's shapes, per env
+    const int sid = MULTI ? a.env_shape[e] : 0;
+    ConstShape* S = MULTI ? (ConstShape*)(a.shapes + sid) : &M.shape;
     float* __restrict__ st = a.state;
     const EnvParams& P = a.p;
     const float h = P.h;
@@ -134,10 +137,15 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
     // ---- hull vertices of the (lane-uniform) body model -> LDS, padded to float4: per-lane gathers in contact generation
     // (unpadded copy, dynamic size: 1182 x 16 B = 18.5 KB lets 8 workgroups = 2 waves per SIMD share a CU's 160 KB)
     extern __shared__ float4 hv[];
-    if (CONTACT) {
+    // hull vertex `idx` of this env's shape: LDS copy (indices = unpadded offsets) or, with per-env shapes, the shape's own table
+    auto hullv = [&](int idx) -> float4 {
+        if (MULTI) return make_float4(S->hull_verts[idx][0], S->hull_verts[idx][1], S->hull_verts[idx][2], 0.f);
+        return hv[idx];
+    };
+    if (CONTACT && !MULTI) {
         for (int bb = 0; bb < NB; ++bb) {
-            const int src = M.hull_offsets[bb], dst = M.hull_cofs[bb], n = M.hull_count[bb];
-            for (int i = threadIdx.x; i < n; i += 64 * LL_WPB) hv[dst + i] = make_float4(M.hull_verts[src + i][0], M.hull_verts[src + i][1], M.hull_verts[src + i][2], 0.f);
+            const int src = S->hull_offsets[bb], dst = S->hull_cofs[bb], n = S->hull_count[bb];
+            for (int i = threadIdx.x; i < n; i += 64 * LL_WPB) hv[dst + i] = make_float4(S->hull_verts[src + i][0], S->hull_verts[src + i][1], S->hull_verts[src + i][2], 0.f);
         }
         __syncthreads();
     }
@@ -151,7 +159,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
     const int c0 = M.children[b][0], c1 = M.children[b][1], c2 = M.children[b][2];
     const bool has0 = valid && c0 >= 0, has1 = valid && c1 >= 0, has2 = valid && c2 >= 0;
     const int cl1 = has1 ? base + c1 : lane, cl2 = has2 ? base + c2 : lane;
-    const float aug = P.aug[b];
+    const float aug = MULTI ? a.shape_aug[sid * NB + b] : P.aug[b];
     const int desc = M.desc_mask[b];  // links of the subtree rooted here (self included)
 
     // ---- state: the root lane carries the root pose/velocity, every other lane its joint
@@ -181,8 +189,8 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
         // kernel; the opaque index keeps the compiler from hoisting the loads back out of the substep loop
         int bo = b;
         asm volatile("" : "+v"(bo));
-        const V3 lpos{M.local_pos[bo][0], M.local_pos[bo][1], M.local_pos[bo][2]};
-        const float kp = M.kp[bo], kd = M.kd[bo];
+        const V3 lpos{S->local_pos[bo][0], S->local_pos[bo][1], S->local_pos[bo][2]};
+        const float kp = S->kp[bo], kd = S->kd[bo];
         // ================================================================ pass 1: kinematics, root -> leaves by level
         V3 zw{0.f, 0.f, 0.f}, zv{0.f, 0.f, 0.f};
         for (int d = 1; d <= maxd; ++d) {
@@ -204,9 +212,9 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
         // ---- per link, all lanes at once: joint torque, body inertia at its origin (world axes), bias force
         // mass properties are needed once per substep: reload them (L1/K$ hits) instead of pinning 10 registers for the
         // whole kernel; the opaque index keeps the loads from being hoisted back out of the loop
-        const float mass = M.mass[bo];
-        const V3 com{M.com[bo][0], M.com[bo][1], M.com[bo][2]};
-        const Sym3 Ib{M.inertia[bo][0], M.inertia[bo][1], M.inertia[bo][2], M.inertia[bo][3], M.inertia[bo][4], M.inertia[bo][5]};
+        const float mass = S->mass[bo];
+        const V3 com{S->com[bo][0], S->com[bo][1], S->com[bo][2]};
+        const Sym3 Ib{S->inertia[bo][0], S->inertia[bo][1], S->inertia[bo][2], S->inertia[bo][3], S->inertia[bo][4], S->inertia[bo][5]};
         V3 tau{0.f, 0.f, 0.f};
         Sym3 A;
         M3 B;
@@ -366,11 +374,11 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
             // pass A marks the candidate vertices (z < contact_offset) in a per-lane 64-bit mask; the manifold reduction then
             // walks only the candidates.  Hull vertices come from the LDS copy of the model (staged once per launch).
             const float coff = P.contact_offset;
-            const int v0 = M.hull_cofs[bo], nv = M.hull_count[bo];
+            const int v0 = MULTI ? S->hull_offsets[bo] : S->hull_cofs[bo], nv = S->hull_count[bo];
             // conservative culling: lowest point of the hull's body-frame bounding box (third row of the link's rotation)
             const float rz0 = 2.f * (q.x * q.z - q.w * q.y), rz1 = 2.f * (q.y * q.z + q.w * q.x), rz2 = 1.f - 2.f * (q.x * q.x + q.y * q.y);
-            const float zlow = x.z + rz0 * M.aabb_c[bo][0] + rz1 * M.aabb_c[bo][1] + rz2 * M.aabb_c[bo][2] -
-                               (fabsf(rz0) * M.aabb_e[bo][0] + fabsf(rz1) * M.aabb_e[bo][1] + fabsf(rz2) * M.aabb_e[bo][2]);
+            const float zlow = x.z + rz0 * S->aabb_c[bo][0] + rz1 * S->aabb_c[bo][1] + rz2 * S->aabb_c[bo][2] -
+                               (fabsf(rz0) * S->aabb_e[bo][0] + fabsf(rz1) * S->aabb_e[bo][1] + fabsf(rz2) * S->aabb_e[bo][2]);
             const bool near = valid && (zlow < coff + 1e-4f);
             int pack = 0x0fffffff;  // four 7-bit vertex slots (127 = none), manifold size in bits 28..30
             long long tsub = a.prof ? clock64() : 0;
@@ -411,7 +419,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
                         const int i = 8 * k + gl;
-                        vv[k] = hv[v0L + ((gon && i < nvL) ? i : 0)];
+                        vv[k] = hullv(v0L + ((gon && i < nvL) ? i : 0));
                     }
                     float px[8], py[8];
                     unsigned clo = 0u, chi = 0u;
@@ -448,7 +456,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                         if (a.prof && (blockIdx.x & 63) == 0 && lane == 0) atomicAdd((unsigned long long*)&a.prof[15], 1ull);
                         // manifold reduction: deepest, farthest from it, extreme on either side of that line
                         const int k0s = k0 < 0 ? 0 : k0;
-                        const float4 u0 = hv[v0L + k0s];
+                        const float4 u0 = hullv(v0L + k0s);
                         const float p0x = xx + r0 * u0.x + r1 * u0.y + r2 * u0.z;
                         const float p0y = xy + r3 * u0.x + r4 * u0.y + r5 * u0.z;
                         const unsigned long long remB = big ? (cm & ~(1ull << k0s)) : 0ull;
@@ -466,7 +474,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                         }
                         grp_argmax(best, k1);
                         const int k1s = k1 < 0 ? 0 : k1;
-                        const float4 u1 = hv[v0L + k1s];
+                        const float4 u1 = hullv(v0L + k1s);
                         const float ex = xx + r0 * u1.x + r1 * u1.y + r2 * u1.z - p0x;
                         const float ey = xy + r3 * u1.x + r4 * u1.y + r5 * u1.z - p0y;
                         const unsigned long long remC = remB & ~(1ull << k1s);
@@ -510,7 +518,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                 const float ih = 1.f / h;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const float4 uu = hv[v0 + (sel4[c] < 0 ? 0 : sel4[c])];
+                    const float4 uu = hullv(v0 + (sel4[c] < 0 ? 0 : sel4[c]));
                     cr[c] = mul(R, V3{uu.x, uu.y, uu.z});
                     float dz = x.z + cr[c].z;
                     cbias[c] = dz >= 0.f ? dz * ih : fmaxf(P.erp * dz * ih, -P.max_depen);
@@ -763,7 +771,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
 
     LLPH(7);
     // ==================================================================== final kinematics -> state, rigid-body state, dof_pos
-    const V3 lpos{M.local_pos[b][0], M.local_pos[b][1], M.local_pos[b][2]};
+    const V3 lpos{S->local_pos[b][0], S->local_pos[b][1], S->local_pos[b][2]};
     for (int d = 1; d <= maxd; ++d) {
         const bool nc = (nonchain >> d) & 1;
         Q4 pq = pp(q, nc);
@@ -882,11 +890,19 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s) {
     a.n = env->n;
     a.p = env->p;
     unsigned blocks = (unsigned)((env->n + 2 * LL_WPB - 1) / (2 * LL_WPB));
-    const size_t lds = env->p.enable_contact ? sizeof(float4) * (size_t)env->model->host.hull_cofs[NB] : 0;
-    if (env->p.enable_contact)
-        hipLaunchKernelGGL(physics_ll_kernel<true>, dim3(blocks), dim3(64 * LL_WPB), lds, s, a);
-    else
-        hipLaunchKernelGGL(physics_ll_kernel<false>, dim3(blocks), dim3(64 * LL_WPB), 0, s, a);
+    const size_t lds = env->p.enable_contact ? sizeof(float4) * (size_t)env->model->host.shape.hull_cofs[NB] : 0;
+    a.shapes = env->shapes_dev;
+    a.env_shape = env->env_shape_dev;
+    a.shape_aug = env->shape_aug_dev;
+    const bool multi = env->num_shapes > 1;  // per-env shapes: hull vertices come from the shape tables instead of the LDS copy
+    const dim3 grid(blocks), block(64 * LL_WPB);
+    if (env->p.enable_contact) {
+        if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((physics_ll_kernel<true, false>), grid, block, lds, s, a);
+    } else {
+        if (multi) hipLaunchKernelGGL((physics_ll_kernel<false, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((physics_ll_kernel<false, false>), grid, block, 0, s, a);
+    }
     env->pair_have = paired ? 1 : 0;
     return check_hip(hipGetLastError(), "physics_ll_kernel");
 }

@@ -22,7 +22,25 @@ constexpr int MAX_BRANCH = 3;  // links with more than one child (root + chest f
 constexpr int MS_ROOT_POS = 0, MS_ROOT_ROT = 3, MS_DOF_POS = 7, MS_ROOT_VEL = 76, MS_ROOT_ANG_VEL = 79, MS_DOF_VEL = 82, MS_KEY_POS = 151,
               MS_RB_POS = 163, MS_RB_ROT = 235;
 
-// Body model as the kernels see it: uniform across lanes, read through scalar loads.
+// Numeric data of one body SHAPE (the reference builds one asset per clip from its SMPL betas, humanoid_smpl_im.py:279-296):
+// every env points at one of these; the tree itself is the same for all shapes.
+struct DevShape {
+    float local_pos[NB][3];
+    float mass[NB];
+    float com[NB][3];
+    float inertia[NB][6];  // xx xy xz yy yz zz about COM, body axes
+    float kp[NB];          // per joint (isotropic over its 3 axes), index = body id, [0] unused
+    float kd[NB];
+    float arm[NB];
+    float bound_radius[NB];  // max |hull vertex| (contact culling, env-per-lane kernel)
+    float aabb_c[NB][3], aabb_e[NB][3];  // body-frame bounding box of the hull: centre, half extents (tighter culling)
+    int32_t hull_offsets[NB + 1];  // into hull_verts; every body's list is padded to a multiple of HULL_PAD (last vertex repeated)
+    int32_t hull_count[NB];        // real vertex count per body
+    int32_t hull_cofs[NB + 1];     // offsets of the unpadded lists (LDS copy of the link-per-lane kernel)
+    float hull_verts[MAX_HULL_VERTS][3];
+};
+
+// Body model as the kernels see it: the tree (uniform across lanes, scalar loads) + the shape of a single-shape batch.
 struct DevModel {
     int32_t parents[NB];
     int32_t depth[NB];
@@ -35,24 +53,13 @@ struct DevModel {
     int32_t max_hull_count;
     int32_t nonchain_levels;     // bit d set when some link at depth d does not directly follow its parent (parent != link - 1)
     int32_t lam_slot[NB];  // index into the saved-Lambda register sets for branching links (root = 0), -1 otherwise
-    float local_pos[NB][3];
-    float mass[NB];
-    float com[NB][3];
-    float inertia[NB][6];  // xx xy xz yy yz zz about COM, body axes
-    float kp[NB];          // per joint (isotropic over its 3 axes), index = body id, [0] unused
-    float kd[NB];
-    float arm[NB];
-    float bound_radius[NB];  // max |hull vertex| (contact culling)
-    float aabb_c[NB][3], aabb_e[NB][3];  // body-frame bounding box of the hull: centre, half extents (tighter culling)
-    int32_t hull_offsets[NB + 1];  // into hull_verts; every body's list is padded to a multiple of HULL_PAD (last vertex repeated)
-    int32_t hull_count[NB];        // real vertex count per body
-    int32_t hull_cofs[NB + 1];     // offsets of the unpadded lists (LDS copy of the link-per-lane kernel)
-    float hull_verts[MAX_HULL_VERTS][3];
+    DevShape shape;
 };
 
 // the model is immutable while kernels run: reading it through the constant address space keeps every
 // access a scalar load that the compiler may hoist and batch (stores to the workspace cannot clobber it)
 typedef const DevModel __attribute__((address_space(4))) ConstModel;
+typedef const DevShape __attribute__((address_space(4))) ConstShape;
 
 struct DevTables {
     v2p_motion_tables t;
@@ -94,7 +101,11 @@ struct EnvParams {
 }  // namespace v2p
 
 struct v2p_env {
-    const v2p_model* model;
+    const v2p_model* model;   // shape 0 (the tree tables of every shape are identical)
+    int num_shapes;           // > 1: per-env body shapes
+    v2p::DevShape* shapes_dev;   // [num_shapes] (multi-shape only)
+    int32_t* env_shape_dev;      // [N]
+    float* shape_aug_dev;        // [num_shapes][24]
     const v2p_mlib* mlib;
     v2p::EnvParams p;
     v2p_env_buffers buf;

@@ -165,6 +165,18 @@ class BodyModel:
         self.dof_body_ids = list(range(1, self.num_bodies))
         self.dof_offsets = list(range(0, self.num_dof + 1, 3))
 
+    def scaled(self, scale, **kw):
+        """The same body uniformly scaled (the reference's per-clip `_motion_body_scales`, humanoid_smpl_im.py:255): lengths x s,
+        masses x s^3, inertias x s^5; the gains follow the total mass like every asset's do (humanoid_smpl_im.py:376-385)."""
+        s = float(scale)
+        blob = dict(self.blob)
+        blob["local_pos"] = self.blob["local_pos"] * s
+        blob["com"] = self.blob["com"] * s
+        blob["hull_verts"] = self.blob["hull_verts"] * s
+        blob["mass"] = self.blob["mass"] * s ** 3
+        blob["inertia"] = self.blob["inertia"] * s ** 5
+        return BodyModel(blob, **kw)
+
     def body_index(self, name):
         return self.body_names.index(name)
 

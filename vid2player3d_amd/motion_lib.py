@@ -50,6 +50,8 @@ class MotionLib:
     @classmethod
     def from_clips(cls, clips, body_model, device, **kw):
         """Synthetic / converted clips -> tables (motion_tables.py) -> device."""
+        if isinstance(body_model, (list, tuple)):  # one body shape per clip
+            return cls(mt.build_tables(clips, body_model[0].parents, np.stack([m.local_pos for m in body_model])), device, **kw)
         return cls(mt.build_tables(clips, body_model.parents, body_model.local_pos), device, **kw)
 
     def generate_length_starts(self):

@@ -108,7 +108,9 @@ def clip_to_tables(clip, parents, local_pos):
 
 def build_tables(clips, parents, local_pos):
     """All clips -> flat float32 tables + per-clip vectors (motion_lib.py:78-99, 370-384)."""
-    per = [clip_to_tables(c, parents, local_pos) for c in clips]
+    # local_pos [24,3] for one skeleton, or [C,24,3]: one skeleton per clip (each clip of the reference carries its own SMPL shape)
+    lp = np.asarray(local_pos)
+    per = [clip_to_tables(c, parents, lp[i] if lp.ndim == 3 else lp) for i, c in enumerate(clips)]
     out = {k: np.concatenate([p[k] for p in per], axis=0).astype(np.float32) for k in TABLE_KEYS}
     nf = np.array([p["num_frames"] for p in per], dtype=np.int64)
     out["motion_num_frames"] = nf

@@ -129,7 +129,13 @@ class HumanoidSMPLIM:
         self.record_pd_torque = bool(env.get("record_pd_torque", False))
 
         # ---- body model (replaces Robot.load_from_skeleton + gym.load_asset, :231-298)
+        # `body_model`: one BodyModel for every env, or a list of them = one body shape per clip of the motion library (the
+        # reference builds one asset per sampled clip from its betas/scale, :255-296); `motion_shape_ids` [num_motions] maps
+        # clips to list entries when several clips share a shape (default: clip i -> shape i)
         bm = env.get("body_model")
+        self.body_shapes = list(bm) if isinstance(bm, (list, tuple)) else None
+        if self.body_shapes is not None:
+            bm = self.body_shapes[0]
         self.body_model = bm if isinstance(bm, BodyModel) else load_baked_model(
             default_humanoid_mass=env.get("default_humanoid_mass", 90.0), kp_scale=self.kp_scale, kd_scale=self.kd_scale)
         self.body_names = list(self.body_model.body_names)
@@ -175,6 +181,8 @@ class HumanoidSMPLIM:
             ids = self._motion_lib.sample_motions(self.num_envs, weights_from_lenth=env.get("motion_weights_from_length", False))
         if "motion_id" in env:
             ids[:] = env["motion_id"]
+        if "motion_ids" in env:  # explicit clip of every env (tests)
+            ids = torch.as_tensor(np.asarray(env["motion_ids"]), dtype=torch.long)
         self._reset_ref_motion_ids = ids.to(self.device).contiguous()
         self._reset_ref_motion_bodies = self._motion_lib._motion_bodies[self._reset_ref_motion_ids].to(self.device)
 
@@ -187,15 +195,32 @@ class HumanoidSMPLIM:
         for val, bodies in env.get("body_pos_weights", dict()).items():
             for body in bodies:
                 self.body_pos_weights[self.body_names.index(body)] = val
-        self.stiffness = torch.tensor(self.body_model.kp, dtype=torch.float32, device=self.device)
-        self.damping = torch.tensor(self.body_model.kd, dtype=torch.float32, device=self.device)
+        # per-env shape (index into body_shapes) = shape of the env's clip
+        self._env_shape_ids = None
+        if self.body_shapes is not None and len(self.body_shapes) > 1:
+            m2s = np.asarray(env.get("motion_shape_ids", np.arange(self._motion_lib.num_motions())), dtype=np.int64)
+            if len(m2s) != self._motion_lib.num_motions() or m2s.min() < 0 or m2s.max() >= len(self.body_shapes):
+                raise ValueError("motion_shape_ids must map each of the %d clips to one of the %d body shapes" % (self._motion_lib.num_motions(), len(self.body_shapes)))
+            self._env_shape_ids = m2s[self._reset_ref_motion_ids.cpu().numpy()].astype(np.int32)
+            self.humanoid_masses = np.array([self.body_shapes[k].total_mass for k in self._env_shape_ids])
+        last = self.body_model if self._env_shape_ids is None else self.body_shapes[self._env_shape_ids[-1]]
+        # (the reference keeps the gains of the LAST env it built, :382-383)
+        self.stiffness = torch.tensor(last.kp, dtype=torch.float32, device=self.device)
+        self.damping = torch.tensor(last.kd, dtype=torch.float32, device=self.device)
 
         # agent back-channels (:325-327); joints in MJCF body order (the SMPL-order table needs the licensed SMPL model)
-        rest = np.zeros((self.num_bodies, 3))
-        for b in range(self.num_bodies):
-            p = self.body_model.parents[b]
-            rest[b] = self.body_model.local_pos[b] + (rest[p] if p >= 0 else 0.0)
-        self.smpl_rest_joints = torch.tensor(rest, dtype=torch.float32, device=self.device).unsqueeze(0).repeat(self.num_envs, 1, 1)
+        def rest_joints(m):
+            rest = np.zeros((self.num_bodies, 3))
+            for b in range(self.num_bodies):
+                p = m.parents[b]
+                rest[b] = m.local_pos[b] + (rest[p] if p >= 0 else 0.0)
+            return rest
+
+        if self._env_shape_ids is None:
+            self.smpl_rest_joints = torch.tensor(rest_joints(self.body_model), dtype=torch.float32, device=self.device).unsqueeze(0).repeat(self.num_envs, 1, 1)
+        else:
+            per_shape = np.stack([rest_joints(m) for m in self.body_shapes])
+            self.smpl_rest_joints = torch.tensor(per_shape[self._env_shape_ids], dtype=torch.float32, device=self.device)
         self.smpl_parents = torch.tensor(self.body_model.parents, dtype=torch.long, device=self.device)
         ch = self.body_model.children_lists()
         self.smpl_children = torch.tensor([(c[0] if c else -1) for c in ch], dtype=torch.long, device=self.device)
@@ -216,7 +241,8 @@ class HumanoidSMPLIM:
             spec = dict(env["synthetic_motions"])
             clips = synth.make_clips(spec.get("seed", 7), spec.get("num_clips", 64), spec.get("min_frames", 90), spec.get("max_frames", 300),
                                      spec.get("speed", 1.0))
-            return MotionLib.from_clips(clips, self.body_model, self.device)
+            per_clip = self.body_shapes is not None and len(self.body_shapes) == len(clips) and "motion_shape_ids" not in env
+            return MotionLib.from_clips(clips, self.body_shapes if per_clip else self.body_model, self.device)
         path = env.get("motion_file")
         if path and os.path.isfile(path) and path.endswith(".npz"):
             with np.load(path) as z:
@@ -283,11 +309,16 @@ class HumanoidSMPLIM:
             keep.append(a)
             return a.ctypes.data_as(_lib.c_i32)
 
-        d = _lib.ModelDesc(num_bodies=bm.num_bodies, parents=iarr(bm.parents), local_pos=farr(bm.local_pos), mass=farr(bm.mass),
-                           com=farr(bm.com), inertia=farr(bm.inertia), kp=farr(bm.kp), kd=farr(bm.kd), armature=farr(bm.armature),
-                           hull_offsets=iarr(bm.hull_offsets), hull_verts=farr(bm.hull_verts))
-        self._h_model = C.c_void_p()
-        _lib.check(lib.v2p_model_create(C.byref(d), self.device_id, C.byref(self._h_model)), "v2p_model_create")
+        def create_model(m):
+            d = _lib.ModelDesc(num_bodies=m.num_bodies, parents=iarr(m.parents), local_pos=farr(m.local_pos), mass=farr(m.mass),
+                               com=farr(m.com), inertia=farr(m.inertia), kp=farr(m.kp), kd=farr(m.kd), armature=farr(m.armature),
+                               hull_offsets=iarr(m.hull_offsets), hull_verts=farr(m.hull_verts))
+            h = C.c_void_p()
+            _lib.check(lib.v2p_model_create(C.byref(d), self.device_id, C.byref(h)), "v2p_model_create")
+            return h
+
+        self._h_models = [create_model(m) for m in (self.body_shapes if self._env_shape_ids is not None else [bm])]
+        self._h_model = self._h_models[0]
         c = _lib.SimCfg()
         c.sim_dt = sp.dt
         c.substeps = sp.substeps
@@ -339,8 +370,14 @@ class HumanoidSMPLIM:
         b.context_feat = self.context_feat.data_ptr()
         b.context_mask = self._context_mask_u8.data_ptr()
         self._h_env = C.c_void_p()
-        _lib.check(lib.v2p_env_create(self._h_model, self._motion_lib.handle(), C.byref(c), _lib.ptr(self._reset_ref_motion_ids),
-                                      self.num_envs, C.byref(b), self.device_id, C.byref(self._h_env)), "v2p_env_create")
+        if self._env_shape_ids is None:
+            _lib.check(lib.v2p_env_create(self._h_model, self._motion_lib.handle(), C.byref(c), _lib.ptr(self._reset_ref_motion_ids),
+                                          self.num_envs, C.byref(b), self.device_id, C.byref(self._h_env)), "v2p_env_create")
+        else:
+            hs = (C.c_void_p * len(self._h_models))(*[h.value for h in self._h_models])
+            _lib.check(lib.v2p_env_create_shapes(hs, len(self._h_models), iarr(self._env_shape_ids), self._motion_lib.handle(), C.byref(c),
+                                                 _lib.ptr(self._reset_ref_motion_ids), self.num_envs, C.byref(b), self.device_id,
+                                                 C.byref(self._h_env)), "v2p_env_create_shapes")
         self._lib = lib
         self._cur = 0
 
@@ -348,9 +385,10 @@ class HumanoidSMPLIM:
         if getattr(self, "_h_env", None):
             self._lib.v2p_env_destroy(self._h_env)
             self._h_env = None
-        if getattr(self, "_h_model", None):
-            self._lib.v2p_model_destroy(self._h_model)
-            self._h_model = None
+        for h in getattr(self, "_h_models", None) or []:
+            self._lib.v2p_model_destroy(h)
+        self._h_models = []
+        self._h_model = None
 
     def __del__(self):
         try:
