@@ -203,3 +203,28 @@ def test_termination_head_height_is_configurable(mlib):
         task.close()
     assert res["amass"][1].all() and res["amass"][0].all()
     assert not res["djokovic"][1].any() and not res["djokovic"][0].any()
+
+
+def test_legacy_pth_motion_file_drives_the_task():
+    """cfg['env']['motion_file'] = the reference's directory of pickled MotionLib parts: loaded without the reference's classes,
+    sampled on the GPU, equal to the reference's own get_motion_state on the merged library."""
+    import os
+
+    from tests.conftest import GOLDEN
+    from vid2player3d_amd.tasks import HumanoidSMPLIM, default_cfg
+
+    cfg = default_cfg(6, motion_file=os.path.join(GOLDEN, "legacy_mlib"))
+    cfg["env"]["sample_first_motions"] = True
+    task = HumanoidSMPLIM(cfg, device_type="cuda", device_id=0)
+    assert task._motion_lib.num_motions() == 3
+    with np.load(os.path.join(GOLDEN, "legacy_mlib_expected.npz")) as z:
+        exp = {k: z[k] for k in z.files}
+    res = task._motion_lib.get_motion_state(T(exp["state_ids"], torch.long), T(exp["state_times"]), return_rigid_body=True, adjust_height=True,
+                                            ground_tolerance=0.0)
+    for name, r in zip(O.MOTION_STATE_NAMES, res):
+        close(N(r), exp["state_" + name], 5e-6, name)
+    task.reset()
+    task.step(torch.zeros((6, 75), device=DEV))
+    torch.cuda.synchronize()
+    assert torch.isfinite(task.obs_buf).all()
+    task.close()

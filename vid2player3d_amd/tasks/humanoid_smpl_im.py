@@ -247,8 +247,13 @@ class HumanoidSMPLIM:
         if path and os.path.isfile(path) and path.endswith(".npz"):
             with np.load(path) as z:
                 return MotionLib({k: z[k] for k in z.files}, self.device)
-        raise RuntimeError("no motion library: pass cfg['env']['motion_lib'] (MotionLib), 'synthetic_motions' or a flat .npz 'motion_file' "
-                           "(pickled reference MotionLib .pth files need the reference's classes to unpickle)")
+        if path and (os.path.isdir(path) or (os.path.isfile(path) and path.endswith(".pth"))):
+            # the reference's pickled MotionLib parts (humanoid_smpl_im.py:420-440), through the restricted unpickler
+            from ..legacy_motion_lib import load_legacy_motion_lib
+
+            return load_legacy_motion_lib(path, self.device, env.get("motion_file_range"))
+        raise RuntimeError("no motion library: pass cfg['env']['motion_lib'] (MotionLib), 'synthetic_motions', a flat .npz 'motion_file' or the "
+                           "reference's .pth file / directory of mlib_part_*.pth")
 
     def _allocate_buffers(self):
         n, dev = self.num_envs, self.device
