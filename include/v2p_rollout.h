@@ -123,6 +123,15 @@ int v2p_obs_imitation(int64_t n, const float* body_pos, const float* body_rot, c
 /* ... with RunningNorm.forward in eval mode fused when norm_mean/norm_std are given: clamp((x-mean)/(std+1e-8), +-clip)
  * (models/running_norm.py:32-43). */
 
+/* The same features straight from what the policy network is handed (models/im_network_builder.py:150-189, preprocess_input +
+ * compute_humanoid_obs): `obs` rows [rows,461] as the task packs them (humanoid_smpl_im.py:198) and the context frames
+ * [envs,ctx_frames,378] (humanoid_smpl_im.py:202, body_pos | body_rot | dof_pos | ...).  rows = envs * steps; row env*steps + k is
+ * paired with context frame first_frame + k: rollout (eval) = steps 1, first_frame = context_padding + t; training minibatches
+ * (flatten=True) = steps T, first_frame = context_padding.  No split / view / cat of the inputs is materialised. */
+int v2p_obs_imitation_packed(int64_t rows, int64_t steps, const float* obs /*[rows,461]*/, const float* context_feat /*[rows/steps,ctx_frames,378]*/,
+                             int64_t ctx_frames, int64_t first_frame, const float* norm_mean /*nullable*/, const float* norm_std /*nullable*/,
+                             float norm_clip, float* out /*[rows,734]*/, void* stream);
+
 /* GAE reverse scan of the PPO rollout, CommonAgent.discount_values (learning/common_agent.py:423-435):
  * fdones [T,N], values / rewards / next_values / advs [T,N,1] (device). */
 int v2p_gae(int64_t horizon, int64_t n, const float* fdones, const float* values, const float* rewards, const float* next_values,

@@ -228,3 +228,49 @@ def test_legacy_pth_motion_file_drives_the_task():
     torch.cuda.synchronize()
     assert torch.isfinite(task.obs_buf).all()
     task.close()
+
+
+def _packed_inputs(g, rows, pad=8, length=32, t=5):
+    """The golden 734-d inputs packed the way the network receives them: 461-d obs rows + 48 context frames per env."""
+    obs = np.concatenate([g["body_pos"][:rows].reshape(rows, 72), g["body_rot"][:rows].reshape(rows, 96), g["dof_pos"][:rows], g["dof_vel"][:rows],
+                          g["body_vel"][:rows].reshape(rows, 72), g["body_ang_vel"][:rows].reshape(rows, 72), g["obs734_motion_bodies"][:rows]], axis=1)
+    assert obs.shape[1] == 461
+    frame = np.concatenate([g["tgt_pos"][:rows].reshape(rows, 72), g["tgt_rot"][:rows].reshape(rows, 96), g["tgt_dof_pos"][:rows],
+                            np.zeros((rows, 141), np.float32)], axis=1)
+    return obs.astype(np.float32), frame.astype(np.float32)
+
+
+def test_obs_imitation_from_packed_obs_and_context(golden_task_ops):
+    """learning.ImitationObs = preprocess_input + compute_humanoid_obs + running_obs of the reference network, on the packed inputs."""
+    from vid2player3d_amd.learning import ImitationObs
+
+    g = golden_task_ops
+    n = g["obs734"].shape[0]
+    obs, frame = _packed_inputs(g, n)
+    rng = np.random.default_rng(0)
+    # rollout flavour: env e, step t=5 -> context frame pad + 5; the other frames hold garbage
+    ctx = rng.normal(size=(n, 48, 378)).astype(np.float32)
+    ctx[:, 8 + 5] = frame
+    enc = ImitationObs(context_padding=8)
+    close(N(enc.rollout(T(obs), T(ctx), 5)), g["obs734"], 5e-6, "packed rollout")
+    enc = ImitationObs(8, T(g["rn_mean"]), T(g["rn_std"]), 5.0)
+    close(N(enc.rollout(T(obs), T(ctx), 5)), g["obs734_normed"], 2e-5, "packed rollout normalised")
+    # training flavour: n = envs * steps rows, row e*steps + k pairs with frame pad + k of env e
+    steps = 4
+    envs = n // steps
+    rows = envs * steps
+    ctx = rng.normal(size=(envs, 48, 378)).astype(np.float32)
+    ctx[:, 8:8 + steps] = frame[:rows].reshape(envs, steps, 378)
+    out = ImitationObs(8).training(T(obs[:rows].reshape(envs, steps, 461)), T(ctx))
+    close(N(out), g["obs734"][:rows], 5e-6, "packed training")
+    with pytest.raises(RuntimeError):
+        ImitationObs(8).rollout(T(obs), T(ctx[:, :, :100]), 0)
+
+
+def test_discount_values_wrapper(golden_task_ops):
+    from vid2player3d_amd.learning import discount_values
+
+    g = golden_task_ops
+    adv = discount_values(None, None, T(g["gae_fdones"]), T(g["gae_values"]), T(g["gae_rewards"]), T(g["gae_next_values"]), float(g["gae_gamma"]),
+                          float(g["gae_tau"]))
+    close(N(adv), g["gae_advs"], 2e-6, "discount_values")

@@ -76,6 +76,7 @@ def load():
         "v2p_reward": [C.c_int64] + [vp] * 8 + [c_f, c_f, vp, vp, vp],
         "v2p_reset_flags": [C.c_int64, vp, vp, c_f, vp, vp, C.c_float, C.c_int, vp, vp, vp],
         "v2p_obs_imitation": [C.c_int64] + [vp] * 10 + [vp, vp, C.c_float, vp, vp],
+        "v2p_obs_imitation_packed": [C.c_int64, C.c_int64, vp, vp, C.c_int64, C.c_int64, vp, vp, C.c_float, vp, vp],
         "v2p_gae": [C.c_int64, C.c_int64, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp],
         "v2p_env_create": [vp, vp, C.POINTER(SimCfg), vp, C.c_int64, C.POINTER(EnvBuffers), C.c_int, C.POINTER(vp)],
         "v2p_env_create_shapes": [C.POINTER(vp), C.c_int32, c_i32, vp, C.POINTER(SimCfg), vp, C.c_int64, C.POINTER(EnvBuffers), C.c_int, C.POINTER(vp)],
@@ -105,7 +106,7 @@ def load():
 
 EXPORTED_SYMBOLS = (
     "v2p_model_create", "v2p_model_destroy", "v2p_mlib_create", "v2p_mlib_destroy", "v2p_motion_state", "v2p_reward", "v2p_reset_flags",
-    "v2p_obs_imitation", "v2p_gae", "v2p_env_create", "v2p_env_create_shapes", "v2p_env_destroy", "v2p_env_reset", "v2p_env_step", "v2p_env_pre_physics", "v2p_env_physics", "v2p_env_export",
+    "v2p_obs_imitation", "v2p_obs_imitation_packed", "v2p_gae", "v2p_env_create", "v2p_env_create_shapes", "v2p_env_destroy", "v2p_env_reset", "v2p_env_step", "v2p_env_pre_physics", "v2p_env_physics", "v2p_env_export",
     "v2p_env_post_physics", "v2p_env_push_state", "v2p_env_target_index", "v2p_env_set_schedule", "v2p_env_debug_contacts", "v2p_env_debug_pairing", "v2p_last_error", "v2p_abi_version",
 )
 

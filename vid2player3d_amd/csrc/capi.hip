@@ -226,6 +226,16 @@ int v2p_obs_imitation(int64_t n, const float* body_pos, const float* body_rot, c
                                 motion_bodies, norm_mean, norm_std, norm_clip, obs, (hipStream_t)stream);
 }
 
+int v2p_obs_imitation_packed(int64_t rows, int64_t steps, const float* obs, const float* context_feat, int64_t ctx_frames, int64_t first_frame,
+                             const float* norm_mean, const float* norm_std, float norm_clip, float* out, void* stream) {
+    if (rows < 0 || steps < 1 || rows % steps || !obs || !context_feat || !out || first_frame < 0 || first_frame + steps > ctx_frames ||
+        ((norm_mean == nullptr) != (norm_std == nullptr))) {
+        set_error("v2p_obs_imitation_packed: bad argument");
+        return V2P_ERR_INVALID;
+    }
+    return launch_obs_imitation_packed(rows, steps, obs, context_feat, ctx_frames, first_frame, norm_mean, norm_std, norm_clip, out, (hipStream_t)stream);
+}
+
 int v2p_gae(int64_t horizon, int64_t n, const float* fdones, const float* values, const float* rewards, const float* next_values, float gamma,
             float tau, float* advs, void* stream) {
     if (horizon < 0 || n < 0) { set_error("v2p_gae: bad argument"); return V2P_ERR_INVALID; }

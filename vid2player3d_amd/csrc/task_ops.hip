@@ -139,24 +139,33 @@ int launch_reset_flags(int64_t n, const int64_t* progress, const float* rb_pos, 
 // layout: root_h 1 | local_body_pos 69 | local_body_rot 144 | local_vel 72 | local_ang_vel 72 | dof_vel 69 |
 //         rel_root_h 1 | rel_root_rot 6 | rel_2d_pos 2 | rel_heading 2 | rel_dof 69 | rel_body_pos 72 | rel_body_rot 144 | motion_bodies 11
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(EB_BLOCK) void obs_imitation_kernel(int64_t n, const float* __restrict__ body_pos, const float* __restrict__ body_rot,
-                                                                 const float* __restrict__ tgt_pos, const float* __restrict__ tgt_rot,
-                                                                 const float* __restrict__ dof_pos, const float* __restrict__ dof_vel,
-                                                                 const float* __restrict__ tgt_dof_pos, const float* __restrict__ body_vel,
-                                                                 const float* __restrict__ body_ang_vel, const float* __restrict__ motion_bodies,
-                                                                 const float* __restrict__ nmean, const float* __restrict__ nstd, float nclip,
-                                                                 float* __restrict__ obs) {
+// Row r of the inputs: element pointers + row strides (floats), so that the same kernel reads either nine separate contiguous
+// tensors or the packed 461-d observation row + the 378-d context frame the network is handed (im_network_builder.py:150-189).
+struct ObsImSrc {
+    const float *body_pos, *body_rot, *dof_pos, *dof_vel, *body_vel, *body_ang_vel, *motion_bodies;  // per row
+    int64_t s_body_pos, s_body_rot, s_dof_pos, s_dof_vel, s_body_vel, s_body_ang_vel, s_motion_bodies;
+    const float *tgt_pos, *tgt_rot, *tgt_dof_pos;  // per row, or (steps > 1 / context) per (env, frame)
+    int64_t s_tgt_pos, s_tgt_rot, s_tgt_dof_pos;   // stride between FRAMES of the target
+    int64_t steps, ctx_frames, first_frame;         // row r = env * steps + k reads target frame env * ctx_frames + first_frame + k
+};
+
+__global__ __launch_bounds__(EB_BLOCK) void obs_imitation_kernel(int64_t n, ObsImSrc in, const float* __restrict__ nmean,
+                                                                 const float* __restrict__ nstd, float nclip, float* __restrict__ obs) {
     int le = threadIdx.x / NB, j = threadIdx.x % NB;
     int64_t e = (int64_t)blockIdx.x * ENVS_PER_BLOCK + le;
     if (e >= n) return;
+    const int64_t tf = (e / in.steps) * in.ctx_frames + in.first_frame + e % in.steps;  // target frame of this row
+    const float* body_pos = in.body_pos + e * in.s_body_pos;
+    const float* body_rot = in.body_rot + e * in.s_body_rot;
+    const float* tgt_pos = in.tgt_pos + tf * in.s_tgt_pos;
+    const float* tgt_rot = in.tgt_rot + tf * in.s_tgt_rot;
     float* o = obs + e * 734;
-    V3 root_pos = ld3(body_pos + e * NB * 3);
-    Q4 root_rot = ref_remove_base_rot(ld4(body_rot + e * NB * 4));
+    V3 root_pos = ld3(body_pos);
+    Q4 root_rot = ref_remove_base_rot(ld4(body_rot));
     float heading = ref_calc_heading(root_rot);
     Q4 hinv = ref_heading_quat(-heading);
-    int64_t bj = e * NB + j;
-    V3 p = ld3(body_pos + bj * 3);
-    Q4 q = ld4(body_rot + bj * 4);
+    V3 p = ld3(body_pos + j * 3);
+    Q4 q = ld4(body_rot + j * 4);
     V3 lp = ref_quat_rotate(hinv, p - root_pos);
     if (j > 0) st3(o + 1 + 3 * (j - 1), lp);
     V3 tn, nm;
@@ -164,18 +173,18 @@ __global__ __launch_bounds__(EB_BLOCK) void obs_imitation_kernel(int64_t n, cons
     else ref_quat_to_tan_norm(qmul(hinv, q), tn, nm);
     st3(o + 70 + 6 * j, tn);
     st3(o + 70 + 6 * j + 3, nm);
-    st3(o + 214 + 3 * j, ref_quat_rotate(hinv, ld3(body_vel + bj * 3)));
-    st3(o + 286 + 3 * j, ref_quat_rotate(hinv, ld3(body_ang_vel + bj * 3)));
-    V3 tp = ld3(tgt_pos + bj * 3);
-    Q4 tq = ld4(tgt_rot + bj * 4);
+    st3(o + 214 + 3 * j, ref_quat_rotate(hinv, ld3(in.body_vel + e * in.s_body_vel + j * 3)));
+    st3(o + 286 + 3 * j, ref_quat_rotate(hinv, ld3(in.body_ang_vel + e * in.s_body_ang_vel + j * 3)));
+    V3 tp = ld3(tgt_pos + j * 3);
+    Q4 tq = ld4(tgt_rot + j * 4);
     st3(o + 507 + 3 * j, ref_quat_rotate(hinv, tp - p));
     ref_quat_to_tan_norm(qmul(qconj(q), tq), tn, nm);
     st3(o + 579 + 6 * j, tn);
     st3(o + 579 + 6 * j + 3, nm);
     if (j > 0) {
-        int64_t dj = e * NDOF + 3 * (j - 1);
-        st3(o + 358 + 3 * (j - 1), ld3(dof_vel + dj));
-        st3(o + 438 + 3 * (j - 1), ld3(tgt_dof_pos + dj) - ld3(dof_pos + dj));
+        const int dj = 3 * (j - 1);
+        st3(o + 358 + dj, ld3(in.dof_vel + e * in.s_dof_vel + dj));
+        st3(o + 438 + dj, ld3(in.tgt_dof_pos + tf * in.s_tgt_dof_pos + dj) - ld3(in.dof_pos + e * in.s_dof_pos + dj));
     } else {
         o[0] = root_pos.z;
         V3 t_root_pos = tp;
@@ -189,7 +198,7 @@ __global__ __launch_bounds__(EB_BLOCK) void obs_imitation_kernel(int64_t n, cons
         float dh = ref_calc_heading(t_root_rot) - heading;
         o[436] = cosf(dh); o[437] = sinf(dh);
     }
-    if (j < 11) o[723 + j] = motion_bodies[e * 11 + j];
+    if (j < 11) o[723 + j] = in.motion_bodies[e * in.s_motion_bodies + j];
     if (nmean) {
         // RunningNorm (eval) fused: the row was just written by this workgroup's 24 threads of env e
         __syncthreads();
@@ -200,15 +209,29 @@ __global__ __launch_bounds__(EB_BLOCK) void obs_imitation_kernel(int64_t n, cons
     }
 }
 
+static int launch_obs_imitation_src(int64_t n, const ObsImSrc& in, const float* nmean, const float* nstd, float nclip, float* obs, hipStream_t s) {
+    if (n <= 0) return V2P_OK;
+    unsigned blocks = (unsigned)((n + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK);
+    hipLaunchKernelGGL(obs_imitation_kernel, dim3(blocks), dim3(EB_BLOCK), 0, s, n, in, nmean, nstd, nclip, obs);
+    return check_hip(hipGetLastError(), "obs_imitation_kernel");
+}
+
 int launch_obs_imitation(int64_t n, const float* body_pos, const float* body_rot, const float* tgt_pos, const float* tgt_rot,
                          const float* dof_pos, const float* dof_vel, const float* tgt_dof_pos, const float* body_vel,
                          const float* body_ang_vel, const float* motion_bodies, const float* nmean, const float* nstd, float nclip, float* obs,
                          hipStream_t s) {
-    if (n <= 0) return V2P_OK;
-    unsigned blocks = (unsigned)((n + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK);
-    hipLaunchKernelGGL(obs_imitation_kernel, dim3(blocks), dim3(EB_BLOCK), 0, s, n, body_pos, body_rot, tgt_pos, tgt_rot, dof_pos, dof_vel,
-                       tgt_dof_pos, body_vel, body_ang_vel, motion_bodies, nmean, nstd, nclip, obs);
-    return check_hip(hipGetLastError(), "obs_imitation_kernel");
+    ObsImSrc in = {body_pos, body_rot, dof_pos, dof_vel, body_vel, body_ang_vel, motion_bodies, NB * 3, NB * 4, NDOF, NDOF, NB * 3, NB * 3, 11,
+                   tgt_pos, tgt_rot, tgt_dof_pos, NB * 3, NB * 4, NDOF, 1, 1, 0};
+    return launch_obs_imitation_src(n, in, nmean, nstd, nclip, obs, s);
+}
+
+// the network's own inputs: obs rows [rows,461] in the order of humanoid_smpl_im.py:198 and context frames [envs,ctx_frames,378] in the
+// order of :202 (body_pos 72 | body_rot 96 | dof_pos 69 | ...); rows = envs * steps, row env*steps+k pairs with frame first_frame+k
+int launch_obs_imitation_packed(int64_t rows, int64_t steps, const float* obs461, const float* context_feat, int64_t ctx_frames, int64_t first_frame,
+                                const float* nmean, const float* nstd, float nclip, float* obs, hipStream_t s) {
+    ObsImSrc in = {obs461, obs461 + 72, obs461 + 168, obs461 + 237, obs461 + 306, obs461 + 378, obs461 + 450, NOBS, NOBS, NOBS, NOBS, NOBS, NOBS, NOBS,
+                   context_feat, context_feat + 72, context_feat + 168, V2P_CONTEXT_DIM, V2P_CONTEXT_DIM, V2P_CONTEXT_DIM, steps, ctx_frames, first_frame};
+    return launch_obs_imitation_src(rows, in, nmean, nstd, nclip, obs, s);
 }
 
 // ------------------------------------------------------------------------------------------

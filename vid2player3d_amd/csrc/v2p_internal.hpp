@@ -161,6 +161,8 @@ int launch_obs_imitation(int64_t n, const float* body_pos, const float* body_rot
                          const float* dof_pos, const float* dof_vel, const float* tgt_dof_pos, const float* body_vel,
                          const float* body_ang_vel, const float* motion_bodies, const float* nmean, const float* nstd, float nclip, float* obs,
                          hipStream_t s);
+int launch_obs_imitation_packed(int64_t rows, int64_t steps, const float* obs461, const float* context_feat, int64_t ctx_frames, int64_t first_frame,
+                                const float* nmean, const float* nstd, float nclip, float* obs, hipStream_t s);
 int launch_gae(int64_t horizon, int64_t n, const float* fdones, const float* values, const float* rewards, const float* next_values, float gamma,
                float tau, float* advs, hipStream_t s);
 int launch_env_reset(v2p_env* e, const int64_t* env_ids, int64_t n, const float* motion_times, hipStream_t s);

@@ -1,0 +1,83 @@
+"""Host-side mirrors of the two learner-side ops that sit right after the env boundary, with the reference's
+argument meaning, forwarding to the HIP library (no CPU path):
+
+  * `ImitationObs` — `ImitatorBuilder.Network.preprocess_input` + `compute_humanoid_obs` + `running_obs`
+    (models/im_network_builder.py:150-189, env/tasks/humanoid_smpl_im.py:773-850, models/running_norm.py:32-43): the 734-d
+    in-network observation computed straight from the packed 461-d obs rows and the context frames, RunningNorm (eval) fused.
+  * `discount_values` — `CommonAgent.discount_values` (learning/common_agent.py:423-435), the GAE reverse scan.
+"""
+import torch
+
+from . import _lib
+
+OBS_IMITATION_DIM = 734
+
+
+def _chk(t, shape_tail, name):
+    if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda or tuple(t.shape[-len(shape_tail):]) != tuple(shape_tail):
+        raise RuntimeError("%s must be a contiguous float32 CUDA tensor [..., %s]" % (name, ", ".join(map(str, shape_tail))))
+
+
+class ImitationObs:
+    """context_padding as in cfg (amass_im.yaml: 8).  `mean` / `std` [734] are the buffers of the policy's RunningNorm
+    (`Network.running_obs.mean/.std`; None = raw features, like `use_running_obs=False`), `clip` its clamp (5.0)."""
+
+    def __init__(self, context_padding=8, mean=None, std=None, clip=5.0):
+        self.context_padding = int(context_padding)
+        self.clip = float(clip)
+        self.set_running_stats(mean, std)
+        self._lib = _lib.load()
+
+    @classmethod
+    def from_running_norm(cls, running_norm, context_padding=8):
+        """running_norm: the reference's models.running_norm.RunningNorm in eval mode (or anything with .mean .std .clip)."""
+        return cls(context_padding, running_norm.mean, running_norm.std, running_norm.clip)
+
+    def set_running_stats(self, mean, std):
+        if (mean is None) != (std is None):
+            raise ValueError("mean and std go together")
+        self._mean = None if mean is None else mean.detach().float().contiguous()
+        self._std = None if std is None else std.detach().float().contiguous()
+
+    def _run(self, obs, context_feat, steps, first_frame):
+        rows = obs.shape[0]
+        out = torch.empty((rows, OBS_IMITATION_DIM), dtype=torch.float32, device=obs.device)
+        stream = torch.cuda.current_stream(obs.device).cuda_stream
+        _lib.check(self._lib.v2p_obs_imitation_packed(rows, steps, _lib.ptr(obs), _lib.ptr(context_feat), context_feat.shape[1], first_frame,
+                                                      _lib.ptr(self._mean), _lib.ptr(self._std), self.clip, _lib.ptr(out), stream),
+                   "v2p_obs_imitation_packed")
+        return out
+
+    def rollout(self, obs, context_feat, t):
+        """eval / rollout flavour (flatten=False): obs [N,461], context_feat [N,L,378], step t of the epoch -> [N,734]."""
+        _chk(obs, (_lib.NUM_OBS,), "obs")
+        _chk(context_feat, (378,), "context_feat")
+        return self._run(obs, context_feat, 1, self.context_padding + int(t))
+
+    def training(self, obs, context_feat):
+        """training flavour (flatten=True): obs [N,T,461] (or [N*T,461]), context_feat [N,L,378] -> [N*T,734]."""
+        _chk(obs, (_lib.NUM_OBS,), "obs")
+        _chk(context_feat, (378,), "context_feat")
+        n = context_feat.shape[0]
+        flat = obs.reshape(-1, _lib.NUM_OBS)
+        if flat.shape[0] % n:
+            raise RuntimeError("obs rows %d are not a multiple of the %d envs of context_feat" % (flat.shape[0], n))
+        return self._run(flat, context_feat, flat.shape[0] // n, self.context_padding)
+
+
+def discount_values(fdones, last_extrinsic_values, mb_fdones, mb_extrinsic_values, mb_rewards, mb_next_values, gamma, tau):
+    """CommonAgent.discount_values (learning/common_agent.py:423-435): same arguments (the first two are unused there as well);
+    mb_* are [T,N] / [T,N,1] float32 CUDA tensors; returns mb_advs like mb_rewards."""
+    for name, t in (("mb_fdones", mb_fdones), ("mb_extrinsic_values", mb_extrinsic_values), ("mb_rewards", mb_rewards), ("mb_next_values", mb_next_values)):
+        if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
+            raise RuntimeError("%s must be a contiguous float32 CUDA tensor" % name)
+    horizon = mb_rewards.shape[0]
+    n = mb_rewards[0].numel()
+    if mb_fdones.numel() != horizon * n or mb_extrinsic_values.numel() != horizon * n or mb_next_values.numel() != horizon * n:
+        raise RuntimeError("discount_values: tensors disagree on [T,N]")
+    advs = torch.empty_like(mb_rewards)
+    lib = _lib.load()
+    stream = torch.cuda.current_stream(mb_rewards.device).cuda_stream
+    _lib.check(lib.v2p_gae(horizon, n, _lib.ptr(mb_fdones), _lib.ptr(mb_extrinsic_values), _lib.ptr(mb_rewards), _lib.ptr(mb_next_values),
+                           float(gamma), float(tau), _lib.ptr(advs), stream), "v2p_gae")
+    return advs
