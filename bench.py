@@ -123,7 +123,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the rollout engine has no CPU path")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("V2P_BENCH_FORCE_DIST"):  # (the env var runs the collective path on a single GPU: CI of the N>1 code)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))

@@ -290,7 +290,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                 cf = paf;
             }
             // parents (depth d-1) pull their children's contributions; contributions of lanes that are not at depth d are zero
-            {
+            if ((nonchain >> d) & 1) {
                 A = A + mask(has0, from_next(cA));
                 C = C + mask(has0, from_next(cC));
                 M3 t = from_next(cB);
@@ -298,6 +298,16 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                 for (int i = 0; i < 9; ++i) B.m[i] += has0 ? t.m[i] : 0.f;
                 pn = pn + mask(has0, from_next(cn));
                 pf = pf + mask(has0, from_next(cf));
+            } else {
+                // every link of this level directly follows its parent: whatever the next lane contributes is this lane's child's
+                // (lanes at other depths contribute zeros), so the shifted values are added unmasked (DPP operand of the add)
+                A = A + from_next(cA);
+                C = C + from_next(cC);
+                M3 t = from_next(cB);
+#pragma unroll
+                for (int i = 0; i < 9; ++i) B.m[i] += t.m[i];
+                pn = pn + from_next(cn);
+                pf = pf + from_next(cf);
             }
             if ((multi >> d) & 1) {
 #pragma unroll 1
@@ -612,7 +622,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                 }
 
                 LLPH(5);
-                V3 accw{0.f, 0.f, 0.f}, accv{0.f, 0.f, 0.f};  // total delta-velocity of this link over the whole sweep
+                const V3 w0 = w, xd0 = xd;  // the sweep's total delta-velocity of a link = its velocity now - these
                 // ======================================================== block Gauss-Seidel: k-th touched body of each env at once
                 for (int it = 0; it < P.n_iter; ++it) {
                     unsigned t0 = m0, t1 = m1;
@@ -665,19 +675,23 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                         }
                         moved = true;
                         // ---- net impulse (un, uf) at the touched link: leaf -> root along the path, level by level
-                        V3 du{0.f, 0.f, 0.f};
+                        // (after its own level a path link's un is final: it is the joint-space impulse the way down needs)
                         for (int d = dneed; d >= 1; --d) {
                             if (!__any(onpath && dep == d)) continue;  // nothing to hand up from this level
                             V3 cn{0.f, 0.f, 0.f}, cf{0.f, 0.f, 0.f};
                             if (dep == d && onpath) {
-                                du = un;
                                 V3 na = aug * mul(Di, un);
                                 V3 fa = uf - V3{dot(col(E, 0), un), dot(col(E, 1), un), dot(col(E, 2), un)};
                                 cn = na + cross(r, fa);
                                 cf = fa;
                             }
-                            un = un + mask(has0, from_next(cn));
-                            uf = uf + mask(has0, from_next(cf));
+                            if ((nonchain >> d) & 1) {
+                                un = un + mask(has0, from_next(cn));
+                                uf = uf + mask(has0, from_next(cf));
+                            } else {
+                                un = un + from_next(cn);
+                                uf = uf + from_next(cf);
+                            }
                             if (((multi >> d) & 1) && __any(dep == d && onpath && !firstchild)) {  // path enters its parent through child 1 or 2
                                 un = un + mask(has1, pull(cn, cl1)) + mask(has2, pull(cn, cl2));
                                 uf = uf + mask(has1, pull(cf, cl1)) + mask(has2, pull(cf, cl2));
@@ -691,20 +705,16 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                             ddv = V3{dot(col(Lam.B, 0), un), dot(col(Lam.B, 1), un), dot(col(Lam.B, 2), un)} + mul(Lam.C, uf);
                             w = w + ddw;
                             xd = xd + ddv;
-                            accw = accw + ddw;
-                            accv = accv + ddv;
                         }
                         for (int d = 1; d <= dneed; ++d) {
                             const bool nc = (nonchain >> d) & 1;
                             V3 pdw = pp(ddw, nc), pdv = pp(ddv, nc);
                             if (dep == d && insweep) {
                                 V3 av = pdv + cross(pdw, r);
-                                ddw = mul(Di, aug * pdw + du) - mul(E, av);
+                                ddw = mul(Di, aug * pdw + un) - mul(E, av);
                                 ddv = av;
                                 w = w + ddw;
                                 xd = xd + ddv;
-                                accw = accw + ddw;
-                                accv = accv + ddv;
                             }
                         }
                         LLSUB(14);
@@ -712,6 +722,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                     if (!moved) break;  // a whole iteration without any change: the remaining ones would repeat it
                 }
                 // links below the deepest touched one: one catch-up pass with the accumulated motion of their parents
+                V3 accw = w - w0, accv = xd - xd0;
                 for (int d = dmin + 1; d <= maxd; ++d) {
                     const bool nc = (nonchain >> d) & 1;
                     V3 pdw = pp(accw, nc), pdv = pp(accv, nc);
