@@ -1,8 +1,10 @@
 #!/bin/bash
-# VALU utilisation of the physics kernel: SQ counters in separate passes (no tracing domains besides the kernel trace)
+# SQ counters of the physics kernel in separate passes (kernel trace only); GROUPS overrides the counter groups ("a b|c d")
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; cd /tmp; export TMPDIR=/tmp
+DEF="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES|SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_THREAD_CYCLES_VALU|SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_TRANS_F32|SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM"
+IFS='|' read -ra GR <<< "${GROUPS_:-$DEF}"
 i=0
-for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_THREAD_CYCLES_VALU" "SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_TRANS_F32" "SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM"; do
+for grp in "${GR[@]}"; do
 i=$((i+1)); rm -rf $O/pmc_valu_$i
 timeout 600 rocprofv3 --pmc $grp --kernel-trace -d $O/pmc_valu_$i -o pmc -- python $R/bench.py --steps 16 --warmup 0 --no-cpu-baseline > $O/pmc_valu_$i.log 2>&1
 done

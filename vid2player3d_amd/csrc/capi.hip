@@ -346,6 +346,10 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
         if (rc == V2P_OK) rc = check_hip(hipMemcpy(e->pair_pos, iota.data(), sizeof(int32_t) * N, hipMemcpyHostToDevice), "hipMemcpy(pair_pos)");
     }
     if (rc == V2P_OK) rc = check_hip(hipDeviceSynchronize(), "hipDeviceSynchronize(env_create)");
+    if (rc == V2P_OK && getenv("V2P_WAVE_TIMES")) {
+        rc = check_hip(hipMalloc((void**)&e->wave_times, sizeof(long long) * 4 * (N / 2 + 1)), "hipMalloc(wave_times)");
+        if (rc == V2P_OK) rc = check_hip(hipMemset(e->wave_times, 0, sizeof(long long) * 4 * (N / 2 + 1)), "hipMemset(wave_times)");
+    }
     if (rc == V2P_OK && getenv("V2P_PHASE_TIMING")) {
         rc = check_hip(hipMalloc((void**)&e->prof, sizeof(long long) * 24), "hipMalloc(prof)");
         if (rc == V2P_OK) rc = check_hip(hipMemset(e->prof, 0, sizeof(long long) * 24), "hipMemset(prof)");
@@ -380,6 +384,14 @@ void v2p_env_destroy(v2p_env* e) {
     if (e->pair_pos) (void)hipFree(e->pair_pos);
     if (e->pair_hist) (void)hipFree(e->pair_hist);
     if (e->perm) (void)hipFree(e->perm);
+    if (e->wave_times) {
+        const size_t nw = (size_t)(e->n + 1) / 2;
+        std::vector<long long> h(nw * 4);
+        FILE* f = fopen(getenv("V2P_WAVE_TIMES") ? getenv("V2P_WAVE_TIMES") : "wave_times.bin", "wb");
+        if (f && hipMemcpy(h.data(), e->wave_times, sizeof(long long) * h.size(), hipMemcpyDeviceToHost) == hipSuccess) fwrite(h.data(), sizeof(long long), h.size(), f);
+        if (f) fclose(f);
+        (void)hipFree(e->wave_times);
+    }
     if (e->prof) {
         long long h[24];
         if (hipMemcpy(h, e->prof, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess)

@@ -31,6 +31,7 @@ struct PhysArgs {
     float* __restrict__ x_contact;  // [N,24,3]
     float* __restrict__ x_dof_force;  // [N,69]
     long long* prof;  // optional cycle counters per phase (block 0), NULL = off
+    long long* wave_times;  // optional [waves][4]: wall-clock start, end (100 MHz), slot key, hw id of every wave of the launch
     const DevShape* shapes;    // [num_shapes] per-env body shapes (multi-shape batches only)
     const int32_t* env_shape;  // [N] shape of each env
     const float* shape_aug;    // [num_shapes][24] joint-diagonal augmentation of each shape

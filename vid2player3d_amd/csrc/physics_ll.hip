@@ -178,6 +178,9 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
     }
 
     long long tprev = a.prof ? clock64() : 0;
+    const long long wt0 = a.wave_times ? wall_clock64() : 0;
+    const int key_pred = a.wave_times ? a.pair_key[e] : 0;  // what the launch order was built from (diagnostics)
+    int tsum = 0, tmaxs = 0;
     V3 r{0.f, 0.f, 0.f};
     int ksum = 0, kdep = 0;  // contact load of this env over the launch (pairing key)
 
@@ -542,6 +545,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
             LLSUB(18);
             const unsigned long long tb = __ballot(valid && cnt > 0);
             const unsigned m0 = (unsigned)tb, m1 = (unsigned)(tb >> 32);
+            if (a.wave_times) { const int tt = __popc(half ? m1 : m0); tsum += tt; tmaxs = tt > tmaxs ? tt : tmaxs; }
             if (last) {
                 const unsigned mine = half ? m1 : m0;
                 ksum = __popc(mine);
@@ -795,6 +799,11 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
             xd = pxd + cross(pw, rr);
         }
     }
+    if (a.wave_times && lane == 0) {
+        long long* wt = a.wave_times + ((int64_t)blockIdx.x * LL_WPB + (threadIdx.x >> 6)) * 4;
+        wt[0] = wt0; wt[1] = wall_clock64(); wt[2] = ksum * 8 + kdep + 1024 * (long long)tsum + 1048576ll * tmaxs + 1073741824ll * key_pred;
+        unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); wt[3] = hw;
+    }
     if (a.pair_hist) {
         // ---- pairing key of this env (touched links, then the deepest of them: what the sweep's cost follows) into its load bin;
         // the workgroup that finishes last turns the histogram into bin offsets for the scatter that builds the next launch's order
@@ -898,6 +907,7 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s) {
     a.x_contact = env->buf.contact_force;
     a.x_dof_force = env->buf.dof_force;
     a.prof = env->prof;
+    a.wave_times = env->wave_times;
     a.n = env->n;
     a.p = env->p;
     unsigned blocks = (unsigned)((env->n + 2 * LL_WPB - 1) / (2 * LL_WPB));

@@ -120,6 +120,7 @@ struct v2p_env {
     float* ws;                // SoA [WS_SLOTS][N] physics workspace
     int32_t* contact_ids;     // [N,24,4] debug
     long long* prof;          // [8] phase cycle counters when V2P_PHASE_TIMING is set (device), else NULL
+    long long* wave_times;    // [waves][4] per-wave wall-clock stamps of the last launch when V2P_WAVE_TIMES=<file> is set
     // pairing (physics_ll.hip): envs are handed to waves in descending order of their contact load
     int32_t* pair_key;        // [N] load key of each env after the last physics launch (0..255)
     int32_t* pair_pos;        // [N] arrival index inside its load bin
