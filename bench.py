@@ -186,6 +186,17 @@ def main():
     if rank == 0:
         value = world * n * args.steps / elapsed
         achieved = ALGO_BYTES_PER_ENV_STEP * n / (phys_ms * 1e-3) / 1e9
+        valu = None  # VALU-side view of the same kernel from the committed SQ counter passes (tools/valu_probe.sh): the binding resource
+        vc = os.path.join(REPO, "profiles", "r01e_valu_counters.json")
+        if os.path.exists(vc):
+            try:
+                c = json.load(open(vc))
+                valu = {"valu_insts_per_wave": c["SQ_INSTS_VALU"]["avg"] / c["SQ_WAVES"]["avg"],
+                        "wave_time_issuing_valu": c["SQ_ACTIVE_INST_VALU"]["avg"] / c["SQ_WAVE_CYCLES"]["avg"],
+                        "lanes_active_per_valu_op": c["SQ_THREAD_CYCLES_VALU"]["avg"] / c["SQ_ACTIVE_INST_VALU"]["avg"],
+                        "source": "profiles/r01e_valu_counters.json (rocprofv3 --pmc, 8192 envs)"}
+            except Exception:
+                valu = None
         traffic = None
         pmc = os.path.join(REPO, "profiles", "pmc_summary.json")
         if os.path.exists(pmc):
@@ -205,7 +216,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "physics_ll_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": phys_ms,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n,
-                         "note": "latency/VALU bound, not HBM bound: see DESIGN.md"},
+                         "note": "latency/VALU bound, not HBM bound: see DESIGN.md", "valu": valu},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
