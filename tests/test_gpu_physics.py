@@ -291,3 +291,39 @@ def test_per_env_body_shapes_match_oracle():
     with pytest.raises(RuntimeError):
         t.set_schedule("env_per_lane")  # the cross-check kernel is single-shape
     t.close()
+
+
+def test_fused_step_equals_staged_step(mlib):
+    """v2p_env_step (pre-physics inside the physics kernel) against pre_physics + physics + post_physics as separate kernels:
+    same masks, same targets, same state to float32 rounding; dead envs get their action rows zeroed in place by both."""
+    n = 96
+    outs = []
+    for fused in (False, True):
+        task = make_task(n, mlib)
+        g = torch.Generator(device=DEV)
+        g.manual_seed(23)
+        task.reset_with_times(None, torch.rand(n, device=DEV, generator=g) * 0.8)
+        task.reset_buf[::5] = 1  # some dead envs
+        acts = []
+        for _ in range(3):
+            a = torch.cat([task._target_dof_pos + 0.2 * torch.randn((n, 69), device=DEV, generator=g), 0.5 * torch.randn((n, 6), device=DEV, generator=g)], dim=1).contiguous()
+            if fused:
+                task.step_fused(a)
+            else:
+                task.pre_physics_step(a)
+                task._physics_step()
+                task.post_physics_step()
+            acts.append(N(a))
+        torch.cuda.synchronize()
+        outs.append({"acts": np.stack(acts), "pd": N(task._pd_target), "rb": N(task._rigid_body_state), "dof": N(task._dof_state), "obs": N(task.obs_buf),
+                     "rew": N(task.rew_buf), "reset": N(task.reset_buf), "ids": N(task.debug_contacts())})
+        task.close()
+    a, b = outs
+    assert np.array_equal(a["acts"], b["acts"]) and (a["acts"][:, ::5] == 0).all() and (a["acts"][:, 1] != 0).any()
+    assert np.array_equal(a["reset"], b["reset"])
+    close(a["pd"], b["pd"], 1e-6, "pd target")
+    same = np.all(a["ids"] == b["ids"], axis=(1, 2))
+    assert same.mean() > 0.97
+    close(a["rb"].reshape(n, 24, 13)[same], b["rb"].reshape(n, 24, 13)[same], 2e-4, "rb state")
+    close(a["dof"].reshape(n, 69, 2)[same], b["dof"].reshape(n, 69, 2)[same], 5e-4, "dof state")
+    close(a["rew"][same], b["rew"][same], 1e-4, "reward")

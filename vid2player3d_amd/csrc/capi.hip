@@ -439,6 +439,13 @@ int v2p_env_post_physics(v2p_env* e, void* stream) {
 }
 
 int v2p_env_step(v2p_env* e, float* actions, void* stream) {
+    if (e && actions && e->schedule == 0) {
+        // link-per-lane schedule: pre-physics runs in the physics kernel's prologue (lane = link owns its joint's action components)
+        DeviceGuard g(e->device);
+        int rc = launch_env_physics_ll(e, (hipStream_t)stream, actions);
+        if (rc == V2P_OK) rc = launch_env_post(e, (hipStream_t)stream);
+        return rc;
+    }
     int rc = v2p_env_pre_physics(e, actions, stream);
     if (rc == V2P_OK) rc = v2p_env_physics(e, stream);
     if (rc == V2P_OK) rc = v2p_env_export(e, stream);

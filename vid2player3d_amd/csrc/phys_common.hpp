@@ -20,7 +20,7 @@ constexpr int WS_SLOTS = LINK_SLOTS * NB;
 struct PhysArgs {
     const DevModel* __restrict__ model;
     float* __restrict__ state;
-    const float* __restrict__ ctrl;
+    float* ctrl;  // [N][75] PD targets + root wrench (written by pre-physics: its own kernel, or this kernel's prologue when `actions` is set)
     float* __restrict__ out;
     float* __restrict__ ws;
     int32_t* __restrict__ contact_ids;
@@ -30,6 +30,10 @@ struct PhysArgs {
     float* __restrict__ x_rb;       // [N,24,13]
     float* __restrict__ x_contact;  // [N,24,3]
     float* __restrict__ x_dof_force;  // [N,69]
+    // fused pre-physics (v2p_env_step, link-per-lane schedule): the caller's actions [N,75] (masked in place), reset flags, exposed PD targets
+    float* actions;
+    const int64_t* reset;
+    float* pd_target;
     long long* prof;  // optional cycle counters per phase (block 0), NULL = off
     long long* wave_times;  // optional [waves][4]: wall-clock start, end (100 MHz), slot key, hw id of every wave of the launch
     const DevShape* shapes;    // [num_shapes] per-env body shapes (multi-shape batches only)

@@ -166,7 +166,37 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
         const int jb = ST_JQUAT + 4 * (b - 1), vb = ST_VEL + 6 + 3 * (b - 1), cb = CT_PD + 3 * (b - 1);
         jq = Q4{st[SIDX(jb + 0)], st[SIDX(jb + 1)], st[SIDX(jb + 2)], st[SIDX(jb + 3)]};
         wt = V3{st[SIDX(vb + 0)], st[SIDX(vb + 1)], st[SIDX(vb + 2)]};
-        tar = V3{a.ctrl[CIDX(cb + 0)], a.ctrl[CIDX(cb + 1)], a.ctrl[CIDX(cb + 2)]};
+        if (!a.actions) tar = V3{a.ctrl[CIDX(cb + 0)], a.ctrl[CIDX(cb + 1)], a.ctrl[CIDX(cb + 2)]};
+    }
+    if (a.actions && valid && live_env) {
+        // ---- pre-physics fused in (humanoid_smpl_im.py:125-157, 391-396; same arithmetic as env_pre_kernel): lane b owns the three
+        // action components of its joint, the root lane the residual wrench; dead envs are masked in place on the caller's tensor
+        const bool dead = a.reset[e] == 1;
+        if (b != 0) {
+            float* ap = a.actions + e * NACT + 3 * (b - 1);
+            V3 act{ap[0], ap[1], ap[2]};
+            if (dead) { act = V3{0.f, 0.f, 0.f}; ap[0] = 0.f; ap[1] = 0.f; ap[2] = 0.f; }
+            const float* qd = a.x_dof + (e * NDOF + 3 * (b - 1)) * 2;
+            const float lim = P.pd_tar_lim;
+            tar = V3{fmaxf(fminf(act.x, qd[0] + lim), qd[0] - lim), fmaxf(fminf(act.y, qd[2] + lim), qd[2] - lim), fmaxf(fminf(act.z, qd[4] + lim), qd[4] - lim)};
+            float* pt = a.pd_target + e * NDOF + 3 * (b - 1);
+            pt[0] = tar.x; pt[1] = tar.y; pt[2] = tar.z;
+            const int cb = CT_PD + 3 * (b - 1);
+            a.ctrl[CIDX(cb + 0)] = tar.x; a.ctrl[CIDX(cb + 1)] = tar.y; a.ctrl[CIDX(cb + 2)] = tar.z;
+        } else {
+            float* ap = a.actions + e * NACT + NDOF;
+            V3 af{ap[0], ap[1], ap[2]}, at{ap[3], ap[4], ap[5]};
+            if (dead) {
+                af = at = V3{0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 6; ++k) ap[k] = 0.f;
+            }
+            const float* rq4 = a.x_rb + e * NB * 13 + 3;
+            const Q4 hq = ref_heading_quat(ref_calc_heading(ref_remove_base_rot(Q4{rq4[0], rq4[1], rq4[2], rq4[3]})));
+            const V3 F = ref_quat_rotate(hq, P.res_force_scale * af), Tq = ref_quat_rotate(hq, P.res_torque_scale * at);
+            a.ctrl[CIDX(CT_FORCE + 0)] = F.x; a.ctrl[CIDX(CT_FORCE + 1)] = F.y; a.ctrl[CIDX(CT_FORCE + 2)] = F.z;
+            a.ctrl[CIDX(CT_TORQUE + 0)] = Tq.x; a.ctrl[CIDX(CT_TORQUE + 1)] = Tq.y; a.ctrl[CIDX(CT_TORQUE + 2)] = Tq.z;
+        }
     }
 
     long long tprev = a.prof ? clock64() : 0;
@@ -885,7 +915,7 @@ int launch_env_pairing(v2p_env* env, hipStream_t s) {
     return check_hip(hipGetLastError(), "pair_scatter_kernel");
 }
 
-int launch_env_physics_ll(v2p_env* env, hipStream_t s) {
+int launch_env_physics_ll(v2p_env* env, hipStream_t s, float* actions) {
     const bool paired = env_pairing_on(env);
     if (paired && env->pair_have) {  // pre-physics has not consumed the last launch's keys
         int rc = launch_env_pairing(env, s);
@@ -901,6 +931,9 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s) {
     a.model = env->model->dev;
     a.state = env->state;
     a.ctrl = env->ctrl;
+    a.actions = actions;  // non-null: pre-physics runs in this kernel's prologue
+    a.reset = env->buf.reset;
+    a.pd_target = env->buf.pd_target;
     a.out = env->out;
     a.ws = env->ws;
     a.contact_ids = env->contact_ids;

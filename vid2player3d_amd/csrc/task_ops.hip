@@ -511,6 +511,7 @@ __global__ __launch_bounds__(EB_BLOCK) void env_post_kernel(EnvView v) {
     RewardPartial r{0.f, 0.f, 0.f, 0.f};
     float t_new = 0.f;
     int64_t mid = 0;
+    if (live && j == 0 && v.pair.perm) pair_scatter(v.pair, e);  // wave order of the next physics launch (see physics_ll.hip)
     if (live) {
         mid = v.motion_id[e];
         t_new = v.b.cur_time[e] + v.p.dt;  // _cur_ref_motion_times += dt
@@ -563,6 +564,10 @@ __global__ __launch_bounds__(EB_BLOCK) void env_post_kernel(EnvView v) {
 int launch_env_post(v2p_env* env, hipStream_t s) {
     EnvView v = make_view(env);
     unsigned blocks = (unsigned)((env->n + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK);
+    if (env_pairing_on(env) && env->pair_have) {
+        v.pair = env_pair_view(env);
+        env->pair_have = 0;
+    }
     hipLaunchKernelGGL(env_post_kernel, dim3(blocks), dim3(EB_BLOCK), 0, s, v);
     int rc = check_hip(hipGetLastError(), "env_post_kernel");
     if (rc == V2P_OK) env->cur_target = 1 - env->cur_target;

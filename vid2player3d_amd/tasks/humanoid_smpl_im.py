@@ -471,9 +471,13 @@ class HumanoidSMPLIM:
     def step(self, actions):
         """BaseTask.step (base_task.py:147-165).  `actions` [N,75] fp32 on this device; rows of envs whose
         reset flag is set are zeroed in place like the reference does (humanoid_smpl_im.py:126)."""
-        self.pre_physics_step(actions)
-        self._physics_step()
-        self.post_physics_step()
+        if self.record_pd_torque or type(self).pre_physics_step is not HumanoidSMPLIM.pre_physics_step or \
+                type(self)._physics_step is not HumanoidSMPLIM._physics_step or type(self).post_physics_step is not HumanoidSMPLIM.post_physics_step:
+            self.pre_physics_step(actions)  # a subclass hooks a stage (or the PD torque is being logged): run the stages one by one
+            self._physics_step()
+            self.post_physics_step()
+        else:
+            self.step_fused(actions)  # one C call: pre-physics inside the physics kernel, then post-physics
 
     def _check_actions(self, actions):
         if actions.dtype != torch.float32 or not actions.is_contiguous() or str(actions.device) != self.device or tuple(actions.shape) != (self.num_envs, self.num_actions):
