@@ -649,50 +649,94 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
 
                 LLPH(5);
                 const V3 w0 = w, xd0 = xd;  // the sweep's total delta-velocity of a link = its velocity now - these
+                // touched links whose parent is the touched link right before them (ascending): they continue a group (below)
+                unsigned chain0 = 0u, chain1 = 0u;
+                {
+                    int prev = -1;
+                    for (unsigned t = m0; t; t &= t - 1) {
+                        const int nn = __ffs(t) - 1;
+                        if ((int)((a.par_pack[nn / 12] >> (5 * (nn % 12))) & 31ull) == prev) chain0 |= 1u << nn;
+                        prev = nn;
+                    }
+                    prev = -1;
+                    for (unsigned t = m1; t; t &= t - 1) {
+                        const int nn = __ffs(t) - 1;
+                        if ((int)((a.par_pack[nn / 12] >> (5 * (nn % 12))) & 31ull) == prev) chain1 |= 1u << nn;
+                        prev = nn;
+                    }
+                }
                 // ======================================================== block Gauss-Seidel: k-th touched body of each env at once
                 for (int it = 0; it < P.n_iter; ++it) {
                     unsigned t0 = m0, t1 = m1;
                     bool moved = false;
                     while (t0 | t1) {
-                        const int b0 = t0 ? __ffs(t0) - 1 : -1, b1 = t1 ? __ffs(t1) - 1 : -1;
+                        // ---- one GROUP per env: a touched link and, while the next touched link (ascending order) is a child of the
+                        // one just solved, that child too.  Inside a group a link sees its parent's impulses through the parent's own
+                        // response (Lambda_parent x impulse, propagated over one joint), and the leaf->root->leaves propagation runs
+                        // ONCE for the whole chain (a limb lying on the ground, ankle + toe of a standing foot) - linear, so the
+                        // sequence of row updates is exactly the one of solving the links one by one.
+                        int b0 = t0 ? __ffs(t0) - 1 : -1, b1 = t1 ? __ffs(t1) - 1 : -1;
                         t0 &= t0 - 1;
                         t1 &= t1 - 1;
-                        const int bsel = half ? b1 : b0;
-                        const bool me = valid && (lb == bsel);
-                        const bool onpath = valid && bsel >= 0 && ((desc >> bsel) & 1);  // this link is the touched one or one of its ancestors
+                        int last0 = b0, last1 = b1;
                         long long tsub = a.prof ? clock64() : 0;
                         if (a.prof && (blockIdx.x & 63) == 0 && lane == 0) atomicAdd((unsigned long long*)&a.prof[8], 1ull);
                         V3 un{0.f, 0.f, 0.f}, uf{0.f, 0.f, 0.f};
-                        if (me) {
-                            V3 wl = w, xl = xd;
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) {
-                                const bool active = c < cnt;
-                                if (!__any(active)) break;  // uniform over the (at most two) touched links solved here
-                                V3 rr = cr[c];
-                                float ln = clam[c].x, l1 = clam[c].y, l2 = clam[c].z;
-#pragma unroll
-                                for (int ax = 0; ax < 3; ++ax) {
-                                    V3 dir = ax == 0 ? V3{0.f, 0.f, 1.f} : (ax == 1 ? V3{1.f, 0.f, 0.f} : V3{0.f, 1.f, 0.f});
-                                    V3 jn = cross(rr, dir);
-                                    V3 yw = mul(Lam.A, jn) + mul(Lam.B, dir);
-                                    V3 yv = V3{dot(col(Lam.B, 0), jn), dot(col(Lam.B, 1), jn), dot(col(Lam.B, 2), jn)} + mul(Lam.C, dir);
-                                    float wii = dot(jn, yw) + dot(dir, yv);
-                                    float rel = dot(jn, wl) + dot(dir, xl) + (ax == 0 ? cbias[c] : 0.f);
-                                    float old = ax == 0 ? ln : (ax == 1 ? l1 : l2);
-                                    float nl = old - rel * __builtin_amdgcn_rcpf(wii);
-                                    if (ax == 0) nl = fmaxf(nl, 0.f);
-                                    else { float lim = P.mu * ln; nl = fminf(fmaxf(nl, -lim), lim); }
-                                    float dl = active ? nl - old : 0.f;
-                                    if (ax == 0) ln += dl; else if (ax == 1) l1 += dl; else l2 += dl;
-                                    wl = wl + dl * yw;
-                                    xl = xl + dl * yv;
-                                    un = un + dl * jn;
-                                    uf = uf + dl * dir;
+                        V3 Dw{0.f, 0.f, 0.f}, Dv{0.f, 0.f, 0.f};  // velocity change of the link just solved due to the group's impulses so far
+                        for (int step = 0;; ++step) {
+                            const int bsel = half ? b1 : b0;
+                            const bool me = valid && (lb == bsel);
+                            V3 tw{0.f, 0.f, 0.f}, tv{0.f, 0.f, 0.f};
+                            if (step > 0) {
+                                const V3 pdw = pp(Dw, true), pdv = pp(Dv, true);
+                                if (me) {
+                                    tv = pdv + cross(pdw, r);
+                                    tw = mul(Di, aug * pdw) - mul(E, tv);
                                 }
-                                clam[c] = V3{ln, l1, l2};
                             }
+                            if (me) {
+                                V3 wl = w + tw, xl = xd + tv;
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) {
+                                    const bool active = c < cnt;
+                                    if (!__any(active)) break;  // uniform over the (at most two) touched links solved here
+                                    V3 rr = cr[c];
+                                    float ln = clam[c].x, l1 = clam[c].y, l2 = clam[c].z;
+#pragma unroll
+                                    for (int ax = 0; ax < 3; ++ax) {
+                                        V3 dir = ax == 0 ? V3{0.f, 0.f, 1.f} : (ax == 1 ? V3{1.f, 0.f, 0.f} : V3{0.f, 1.f, 0.f});
+                                        V3 jn = cross(rr, dir);
+                                        V3 yw = mul(Lam.A, jn) + mul(Lam.B, dir);
+                                        V3 yv = V3{dot(col(Lam.B, 0), jn), dot(col(Lam.B, 1), jn), dot(col(Lam.B, 2), jn)} + mul(Lam.C, dir);
+                                        float wii = dot(jn, yw) + dot(dir, yv);
+                                        float rel = dot(jn, wl) + dot(dir, xl) + (ax == 0 ? cbias[c] : 0.f);
+                                        float old = ax == 0 ? ln : (ax == 1 ? l1 : l2);
+                                        float nl = old - rel * __builtin_amdgcn_rcpf(wii);
+                                        if (ax == 0) nl = fmaxf(nl, 0.f);
+                                        else { float lim = P.mu * ln; nl = fminf(fmaxf(nl, -lim), lim); }
+                                        float dl = active ? nl - old : 0.f;
+                                        if (ax == 0) ln += dl; else if (ax == 1) l1 += dl; else l2 += dl;
+                                        wl = wl + dl * yw;
+                                        xl = xl + dl * yv;
+                                        un = un + dl * jn;
+                                        uf = uf + dl * dir;
+                                    }
+                                    clam[c] = V3{ln, l1, l2};
+                                }
+                                Dw = wl - w;  // = tw + Lambda (un, uf): what this link's child (if it is next) starts from
+                                Dv = xl - xd;
+                            }
+                            // does the chain go on?  (next touched link of the env, ascending, is a child of the one just solved)
+                            const int n0 = t0 ? __ffs(t0) - 1 : -1, n1 = t1 ? __ffs(t1) - 1 : -1;
+                            const bool c0 = b0 >= 0 && n0 >= 0 && ((chain0 >> n0) & 1u), c1 = b1 >= 0 && n1 >= 0 && ((chain1 >> n1) & 1u);
+                            if (!(c0 || c1)) break;
+                            b0 = c0 ? n0 : -1;
+                            b1 = c1 ? n1 : -1;
+                            if (c0) { t0 &= t0 - 1; last0 = n0; }
+                            if (c1) { t1 &= t1 - 1; last1 = n1; }
                         }
+                        const int blast = half ? last1 : last0;
+                        const bool onpath = valid && blast >= 0 && ((desc >> blast) & 1);  // the group's deepest link or one of its ancestors
                         LLSUB(11);
                         // an update that changed no impulse (separated or saturated points) moves nothing: skip the propagation
                         if (!__any(un.x != 0.f || un.y != 0.f || un.z != 0.f || uf.x != 0.f || uf.y != 0.f || uf.z != 0.f)) {
@@ -932,6 +976,11 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s, float* actions) {
     a.state = env->state;
     a.ctrl = env->ctrl;
     a.actions = actions;  // non-null: pre-physics runs in this kernel's prologue
+    a.par_pack[0] = a.par_pack[1] = 0ull;
+    for (int i = 0; i < NB; ++i) {
+        const int par = env->model->host.parents[i] < 0 ? 0 : env->model->host.parents[i];
+        a.par_pack[i / 12] |= (unsigned long long)par << (5 * (i % 12));
+    }
     a.reset = env->buf.reset;
     a.pd_target = env->buf.pd_target;
     a.out = env->out;
