@@ -37,11 +37,14 @@ HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: 8 TB/s spec
 HORIZON = 32
 
 
-def build_task(num_envs, device_id, seed, contact=True, per_clip_shapes=False):
+def build_task(num_envs, device_id, seed, contact=True, per_clip_shapes=False, djokovic=False):
     from vid2player3d_amd.tasks import HumanoidSMPLIM, default_cfg
 
     cfg = default_cfg(num_envs, synthetic_motions={"seed": 7, "num_clips": 64, "min_frames": 90, "max_frames": 300},
                       enable_contact=contact)
+    if djokovic:  # BASELINE config 4 = cfg/djokovic_im.yaml: same task class, head termination height -0.5, faster (tennis-like) clips
+        cfg["env"]["terminationHeadHeight"] = -0.5
+        cfg["env"]["synthetic_motions"]["speed"] = 2.0
     if per_clip_shapes:  # one body shape per clip like the reference's per-clip SMPL assets: 64 uniformly scaled bodies, 0.85 .. 1.15
         from vid2player3d_amd.model import load_baked_model
 
@@ -109,6 +112,7 @@ def main():
     ap.add_argument("--num-envs", type=int, default=8192, help="envs per GPU")
     ap.add_argument("--no-contact", action="store_true", help="BASELINE config 2 (PD only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--djokovic", action="store_true", help="BASELINE config 4 (djokovic_im.yaml: terminationHeadHeight -0.5, faster clips)")
     ap.add_argument("--per-clip-shapes", action="store_true", help="one body shape per clip (64 scaled bodies) instead of one shape for all envs")
     args = ap.parse_args()
 
@@ -134,7 +138,7 @@ def main():
     if dist is not None:
         dist.barrier()
     n = args.num_envs
-    task = build_task(n, local_rank, seed=7 + rank, contact=not args.no_contact, per_clip_shapes=args.per_clip_shapes)  # per-rank seed like run.py:37
+    task = build_task(n, local_rank, seed=7 + rank, contact=not args.no_contact, per_clip_shapes=args.per_clip_shapes, djokovic=args.djokovic)  # per-rank seed like run.py:37
     dev = task.device
     gen = torch.Generator(device=dev)
     gen.manual_seed(7 + rank)
@@ -210,7 +214,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "amass_im num_envs=%d per GPU, %s, imitation reward, per-epoch reset+context every %d steps, 64 synthetic clips%s"
                                    % (n, "PD control only (no contact solve)" if args.no_contact else "full contact PGS (4 substeps x 4 iterations)", HORIZON,
-                                      ", one body shape per clip" if args.per_clip_shapes else ""),
+                                      (", one body shape per clip" if args.per_clip_shapes else "") + (", djokovic_im variant" if args.djokovic else "")),
                        "num_envs_per_gpu": n, "global_envs": world * n, "parallelism": "env-sharded x%d, no data-path collective" % world,
                        "alive_fraction_at_end": alive},
             "roofline": {"bound": "hbm", "kernel": "physics_ll_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
