@@ -22,7 +22,8 @@ def mlib():
     return MotionLib(synth_tables(seed=5, num_clips=8, min_frames=60, max_frames=120), DEV)
 
 
-def _run_pair(mlib, n, contact, seed, lift=0.0, vel_sigma=0.5, steps=1, hold="first_sim", shapes=None):
+def _run_pair(mlib, n, contact, seed, lift=0.0, vel_sigma=0.5, steps=1, hold="first_sim", shapes=None, subset=None):
+    """subset: env indices that get an oracle (all by default); the returned arrays are restricted to them."""
     rng = np.random.default_rng(seed)
     extra = {} if shapes is None else {"body_model": shapes}
     task = make_task(n, mlib, enable_contact=contact, residual_force_hold=hold, **extra)
@@ -39,8 +40,9 @@ def _run_pair(mlib, n, contact, seed, lift=0.0, vel_sigma=0.5, steps=1, hold="fi
     task._dof_vel[:] = T(dvel)
     task._reset_env_tensors(None)
     bm = task.body_model
+    ids_o = list(range(n)) if subset is None else [int(i) for i in subset]
     oracles = []
-    for e in range(n):
+    for e in ids_o:
         if shapes is not None:
             bm = shapes[task._env_shape_ids[e]]  # the oracle of env e simulates the body shape of its clip
         o = PhysOracle(bm, default_params(enable_contact=contact), kp=bm.kp.astype(np.float32), kd=bm.kd.astype(np.float32))
@@ -60,15 +62,16 @@ def _run_pair(mlib, n, contact, seed, lift=0.0, vel_sigma=0.5, steps=1, hold="fi
         _, pd_ref, _, force, torque = O.pre_physics(act, N(task.reset_buf), dpos_before, rb0[:, 0, 3:7], task.body_model.kp.astype(np.float32))
         close(pd_tar, pd_ref, 1e-6, "pd target")
         res = {"root": [], "dpos": [], "dvel": [], "rb": [], "cf": [], "df": [], "ids": []}
-        for e in range(n):
-            cf, df, ids = oracles[e].step(pd_target=pd_tar[e], ext_force=force[e], ext_torque=torque[e], nsub=4, hold=2 if hold == "first_sim" else 4)
-            r, p, v, rb = oracles[e].get_state()
+        for k, e in enumerate(ids_o):
+            cf, df, ids = oracles[k].step(pd_target=pd_tar[e], ext_force=force[e], ext_torque=torque[e], nsub=4, hold=2 if hold == "first_sim" else 4)
+            r, p, v, rb = oracles[k].get_state()
             for k, x in zip(("root", "dpos", "dvel", "rb", "cf", "df", "ids"), (r, p, v, rb, cf, df, ids)):
                 res[k].append(x)
         res = {k: np.stack(v) for k, v in res.items()}
         got = {"root": N(task._humanoid_root_states), "dpos": N(task._dof_pos), "dvel": N(task._dof_vel),
                "rb": N(task._rigid_body_state).reshape(n, 24, 13), "cf": N(task._contact_forces), "df": N(task.dof_force_tensor),
                "ids": N(task.debug_contacts())}
+        got = {k: v[ids_o] for k, v in got.items()}
         out.append((got, res))
         task.post_physics_step()
     task.close()
@@ -327,3 +330,15 @@ def test_fused_step_equals_staged_step(mlib):
     close(a["rb"].reshape(n, 24, 13)[same], b["rb"].reshape(n, 24, 13)[same], 2e-4, "rb state")
     close(a["dof"].reshape(n, 69, 2)[same], b["dof"].reshape(n, 69, 2)[same], 5e-4, "dof state")
     close(a["rew"][same], b["rew"][same], 1e-4, "reward")
+
+
+def test_full_size_sample_matches_oracle(mlib):
+    """8192 envs on the GPU (4096 waves, paired by contact load), 40 of them - first, last, and a spread in between - against
+    their own float64 oracles: indexing, pairing and the tail of the launch at the BASELINE size."""
+    n = 8192
+    subset = sorted(set([0, 1, 2, n - 1, n - 2] + list(np.random.default_rng(8).integers(0, n, size=35))))
+    (got, ref), = _run_pair(mlib, n, contact=True, seed=6, lift=0.0, subset=subset)
+    same = np.all(got["ids"] == ref["ids"], axis=(1, 2))
+    assert same.mean() > 0.85, "contact sets differ in %d of %d envs" % ((~same).sum(), len(same))
+    sel = {k: v[same] for k, v in got.items()}, {k: v[same] for k, v in ref.items()}
+    _compare(sel[0], sel[1], "8192-env sample")
