@@ -54,10 +54,18 @@ def build_task(num_envs, device_id, seed, contact=True, per_clip_shapes=False, d
     return HumanoidSMPLIM(cfg, device_type="cuda", device_id=device_id)
 
 
+_ACT_MASK = {}
+
+
 def make_actions(task, noise):
-    a = noise.clone()
-    a[:, :69] += task._target_dof_pos
-    return a
+    """Stand-in policy: a = [target_dof_pos + noise, noise] (sigma 0.17), one elementwise kernel: the 75 columns starting at the
+    target's dof_pos (dof_pos 69 | root_vel 3 | root_ang_vel 3 of the packed target row) times a [1]*69 + [0]*6 mask."""
+    dev = noise.device
+    if dev not in _ACT_MASK:
+        _ACT_MASK[dev] = torch.cat([torch.ones(69, device=dev), torch.zeros(6, device=dev)])
+    tgt = task._target_dof_pos  # [N,69] view into the current packed target [N,331]
+    tgt75 = torch.as_strided(tgt, (tgt.shape[0], 75), (tgt.stride(0), 1), tgt.storage_offset())
+    return torch.addcmul(noise, tgt75, _ACT_MASK[dev])
 
 
 def cpu_baseline(num_envs_sample=None, max_steps=100000, budget_s=12.0):
