@@ -15,4 +15,8 @@ rm -rf $O/prof $O/pmc_fetch $O/pmc_write && mkdir -p $O/prof
 # HBM traffic counters, each in its own pass (TCC slots: FETCH_SIZE 3, WRITE_SIZE 2)
 (cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch -o pmc -- python $R/bench.py --steps 32 --warmup 0 --no-cpu-baseline > $O/pmc_fetch.log 2>&1)
 (cd /tmp && timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write -o pmc -- python $R/bench.py --steps 32 --warmup 0 --no-cpu-baseline > $O/pmc_write.log 2>&1)
-tail -3 $O/pytest_gpu.log; tail -2 $O/smoke.log; tail -1 $O/bench.log | cut -c1-1500; tail -1 $O/bench_cfg2.log | cut -c1-300; ls $O/pmc_fetch $O/pmc_write 2>&1 | head
+# summaries on the box (the raw rocprofv3 databases exceed what is merged back)
+python $R/tools/rocprof_summary.py $O/prof/stats_results.db > $O/rocprof_stats.txt 2>&1
+python $R/tools/pmc_summary.py $O/pmc_fetch/pmc_results.db $O/pmc_write/pmc_results.db $O/pmc_summary.json > /dev/null 2>&1
+rm -rf $O/prof $O/pmc_fetch $O/pmc_write
+tail -3 $O/pytest_gpu.log; tail -2 $O/smoke.log; tail -1 $O/bench.log | cut -c1-1500; tail -1 $O/bench_cfg2.log | cut -c1-300; head -8 $O/rocprof_stats.txt
