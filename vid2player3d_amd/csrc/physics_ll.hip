@@ -702,6 +702,11 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                                     if (!__any(active)) break;  // uniform over the (at most two) touched links solved here
                                     V3 rr = cr[c];
                                     float ln = clam[c].x, l1 = clam[c].y, l2 = clam[c].z;
+                                    // a point without normal impulse (hence without friction impulses: they are clamped to mu x normal)
+                                    // that is separating stays as it is: its three rows would change nothing
+                                    // (masked per lane as well, so that an env's numbers do not depend on what its wave partner does)
+                                    const bool act = active && !(ln == 0.f && rr.y * wl.x - rr.x * wl.y + xl.z + cbias[c] >= 0.f);
+                                    if (!__any(act)) continue;
 #pragma unroll
                                     for (int ax = 0; ax < 3; ++ax) {
                                         V3 dir = ax == 0 ? V3{0.f, 0.f, 1.f} : (ax == 1 ? V3{1.f, 0.f, 0.f} : V3{0.f, 1.f, 0.f});
@@ -714,7 +719,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                                         float nl = old - rel * __builtin_amdgcn_rcpf(wii);
                                         if (ax == 0) nl = fmaxf(nl, 0.f);
                                         else { float lim = P.mu * ln; nl = fminf(fmaxf(nl, -lim), lim); }
-                                        float dl = active ? nl - old : 0.f;
+                                        float dl = act ? nl - old : 0.f;
                                         if (ax == 0) ln += dl; else if (ax == 1) l1 += dl; else l2 += dl;
                                         wl = wl + dl * yw;
                                         xl = xl + dl * yv;
