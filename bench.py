@@ -37,11 +37,13 @@ HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: 8 TB/s spec
 HORIZON = 32
 
 
-def build_task(num_envs, device_id, seed, contact=True, per_clip_shapes=False, djokovic=False):
+def build_task(num_envs, device_id, seed, contact=True, per_clip_shapes=False, djokovic=False, freeze=False):
     from vid2player3d_amd.tasks import HumanoidSMPLIM, default_cfg
 
     cfg = default_cfg(num_envs, synthetic_motions={"seed": 7, "num_clips": 64, "min_frames": 90, "max_frames": 300},
                       enable_contact=contact)
+    if freeze:  # NOT the reference's behaviour (it keeps simulating terminated envs as ragdolls): reported separately, never as `value` of the default run
+        cfg["env"]["freeze_terminated_envs"] = True
     if djokovic:  # BASELINE config 4 = cfg/djokovic_im.yaml: same task class, head termination height -0.5, faster (tennis-like) clips
         cfg["env"]["terminationHeadHeight"] = -0.5
         cfg["env"]["synthetic_motions"]["speed"] = 2.0
@@ -120,6 +122,7 @@ def main():
     ap.add_argument("--num-envs", type=int, default=8192, help="envs per GPU")
     ap.add_argument("--no-contact", action="store_true", help="BASELINE config 2 (PD only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--freeze-terminated", action="store_true", help="opt-in engine feature: terminated envs are not simulated until the epoch reset (not reference behaviour)")
     ap.add_argument("--djokovic", action="store_true", help="BASELINE config 4 (djokovic_im.yaml: terminationHeadHeight -0.5, faster clips)")
     ap.add_argument("--per-clip-shapes", action="store_true", help="one body shape per clip (64 scaled bodies) instead of one shape for all envs")
     args = ap.parse_args()
@@ -146,7 +149,7 @@ def main():
     if dist is not None:
         dist.barrier()
     n = args.num_envs
-    task = build_task(n, local_rank, seed=7 + rank, contact=not args.no_contact, per_clip_shapes=args.per_clip_shapes, djokovic=args.djokovic)  # per-rank seed like run.py:37
+    task = build_task(n, local_rank, seed=7 + rank, contact=not args.no_contact, per_clip_shapes=args.per_clip_shapes, djokovic=args.djokovic, freeze=args.freeze_terminated)  # per-rank seed like run.py:37
     dev = task.device
     gen = torch.Generator(device=dev)
     gen.manual_seed(7 + rank)
@@ -222,7 +225,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "amass_im num_envs=%d per GPU, %s, imitation reward, per-epoch reset+context every %d steps, 64 synthetic clips%s"
                                    % (n, "PD control only (no contact solve)" if args.no_contact else "full contact PGS (4 substeps x 4 iterations)", HORIZON,
-                                      (", one body shape per clip" if args.per_clip_shapes else "") + (", djokovic_im variant" if args.djokovic else "")),
+                                      (", one body shape per clip" if args.per_clip_shapes else "") + (", djokovic_im variant" if args.djokovic else "") + (", TERMINATED ENVS FROZEN (not reference behaviour)" if args.freeze_terminated else "")),
                        "num_envs_per_gpu": n, "global_envs": world * n, "parallelism": "env-sharded x%d, no data-path collective" % world,
                        "alive_fraction_at_end": alive},
             "roofline": {"bound": "hbm", "kernel": "physics_ll_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

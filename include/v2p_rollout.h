@@ -34,7 +34,7 @@ extern "C" {
 #define V2P_NUM_OBS 461
 #define V2P_MOTION_STATE_DIM 331  /* root_pos3 root_rot4 dof_pos69 root_vel3 root_ang_vel3 dof_vel69 key_pos12 rb_pos72 rb_rot96 */
 #define V2P_CONTEXT_DIM 378       /* body_pos72 body_rot96 dof_pos69 body_pos_gt72 dof_pos_gt69 (humanoid_smpl_im.py:202) */
-#define V2P_ABI_VERSION 1
+#define V2P_ABI_VERSION 2
 
 typedef enum {
     V2P_OK = 0,
@@ -164,6 +164,9 @@ typedef struct {
     float term_heights[24];     /* per body; contact bodies get -inf (humanoid_smpl_im.py:217-224, 956-987) */
     float body_pos_weights[24]; /* humanoid_smpl_im.py:109-115 */
     float reward_specs[8];      /* k_dof,k_vel,k_pos,k_rot,w_dof,w_vel,w_pos,w_rot (humanoid_smpl_im.py:682) */
+    int32_t freeze_terminated_envs; /* 0 (reference behaviour): envs whose reset flag is set keep being simulated as ragdolls until the
+                                     * epoch reset, although nothing downstream reads them (zero reward, masked by `dones` in
+                                     * im_agent.py:392-414).  1: their physics state is frozen instead (link-per-lane schedule). */
 } v2p_sim_cfg;
 
 /* Caller-owned DEVICE buffers the engine reads/writes; these are the tensors the reference

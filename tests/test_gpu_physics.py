@@ -342,3 +342,39 @@ def test_full_size_sample_matches_oracle(mlib):
     assert same.mean() > 0.85, "contact sets differ in %d of %d envs" % ((~same).sum(), len(same))
     sel = {k: v[same] for k, v in got.items()}, {k: v[same] for k, v in ref.items()}
     _compare(sel[0], sel[1], "8192-env sample")
+
+
+def test_freeze_terminated_envs_option(mlib):
+    """cfg['env']['freeze_terminated_envs'] (opt-in, not the reference's behaviour): envs whose reset flag is set stop moving, every
+    other env's numbers are bit-identical to the default engine's (and so are rewards / reset flags, which never read dead envs)."""
+    n = 200
+    STEPS = 40
+    outs = []
+    for freeze in (False, True):
+        task = make_task(n, mlib, freeze_terminated_envs=freeze)
+        g = torch.Generator(device=DEV)
+        g.manual_seed(31)
+        task.reset_with_times(None, torch.rand(n, device=DEV, generator=g) * 0.5)
+        snaps = []
+        for k in range(STEPS):
+            a = torch.cat([task._target_dof_pos + 1.0 * torch.randn((n, 69), device=DEV, generator=g), 2.0 * torch.randn((n, 6), device=DEV, generator=g)], dim=1).contiguous()
+            task.step(a)
+            snaps.append((N(task.reset_buf).copy(), N(task._rigid_body_state).reshape(n, 24, 13).copy(), N(task.rew_buf).copy(), N(task._dof_state).copy()))
+        torch.cuda.synchronize()
+        outs.append(snaps)
+        task.close()
+    ref, frz = outs
+    died = 0
+    for k in range(STEPS):
+        assert np.array_equal(ref[k][0], frz[k][0])  # same envs terminate at the same steps
+        assert np.array_equal(ref[k][2], frz[k][2])  # same rewards
+        alive_before = (ref[k - 1][0] == 0) if k else np.ones(n, bool)  # simulated in step k by both engines
+        assert np.array_equal(ref[k][1][alive_before], frz[k][1][alive_before])
+        assert np.array_equal(ref[k][3].reshape(n, -1)[alive_before], frz[k][3].reshape(n, -1)[alive_before])
+        if k:
+            dead = ref[k - 1][0] == 1
+            died = max(died, int(dead.sum()))
+            assert np.array_equal(frz[k][1][dead], frz[k - 1][1][dead])  # frozen
+            if dead.any():
+                assert not np.array_equal(ref[k][1][dead], ref[k - 1][1][dead])  # the default keeps simulating them
+    assert died > 10

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "libv2p_rollout.so")
 
 NUM_BODIES, NUM_DOF, NUM_ACTIONS, NUM_OBS = 24, 69, 75, 461
 MOTION_STATE_DIM, CONTEXT_DIM = 331, 378
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_f = C.POINTER(C.c_float)
 c_i32 = C.POINTER(C.c_int32)
@@ -39,7 +39,7 @@ class SimCfg(C.Structure):
                 ("residual_force_scale", C.c_float), ("residual_torque_scale", C.c_float), ("ground_tolerance", C.c_float),
                 ("max_episode_length", C.c_float), ("enable_early_termination", C.c_int32), ("context_length", C.c_int32),
                 ("context_padding", C.c_int32), ("term_heights", C.c_float * 24), ("body_pos_weights", C.c_float * 24),
-                ("reward_specs", C.c_float * 8)]
+                ("reward_specs", C.c_float * 8), ("freeze_terminated_envs", C.c_int32)]
 
 
 class EnvBuffers(C.Structure):

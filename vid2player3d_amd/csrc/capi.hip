@@ -293,6 +293,7 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
     p.pd_tar_lim = c->pd_tar_lim; p.res_force_scale = c->residual_force_scale; p.res_torque_scale = c->residual_torque_scale;
     p.ground_tolerance = c->ground_tolerance; p.max_episode_length = c->max_episode_length;
     p.enable_early_termination = c->enable_early_termination;
+    p.freeze_terminated = c->freeze_terminated_envs;
     p.context_length = c->context_length; p.context_padding = c->context_padding;
     p.dt = (float)c->control_freq_inv * c->sim_dt;
     memcpy(p.term_heights, c->term_heights, sizeof(p.term_heights));

@@ -153,6 +153,10 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
     const int cl1 = has1 ? base + c1 : lane, cl2 = has2 ? base + c2 : lane;
     const float aug = MULTI ? a.shape_aug[sid * NB + b] : P.aug[b];
     const int desc = M.desc_mask[b];  // links of the subtree rooted here (self included)
+    // opt-in (v2p_sim_cfg.freeze_terminated_envs): an env whose reset flag is set keeps its state; a wave whose two envs are frozen
+    // skips the substeps altogether (frozen envs sort to the end of the launch order, so they share waves)
+    const bool frozen = P.freeze_terminated && a.reset[e] == 1;
+    const int nsub = (P.freeze_terminated && !__any(!frozen)) ? 0 : P.nsub;
 
     // ---- state: the root lane carries the root pose/velocity, every other lane its joint
     Q4 q{0.f, 0.f, 0.f, 1.f}, jq{0.f, 0.f, 0.f, 1.f};
@@ -206,9 +210,9 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
     V3 r{0.f, 0.f, 0.f};
     int ksum = 0, kdep = 0;  // contact load of this env over the launch (pairing key)
 
-    for (int sub = 0; sub < P.nsub; ++sub) {
+    for (int sub = 0; sub < nsub; ++sub) {
         const bool wrench_on = sub < P.hold_sub;
-        const bool last = sub == P.nsub - 1;
+        const bool last = sub == nsub - 1;
         LLPH(0);
         // per-link model constants are (re)loaded where they are used (L1/K$ hits) instead of pinning ~20 registers for the whole
         // kernel; the opaque index keeps the compiler from hoisting the loads back out of the substep loop
@@ -559,7 +563,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                     cbias[c] = dz >= 0.f ? dz * ih : fmaxf(P.erp * dz * ih, -P.max_depen);
                 }
             }
-            if (last && valid && live_env) {
+            if (last && valid && live_env && !frozen) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) a.contact_ids[(e * NB + b) * 4 + c] = c < cnt ? b * 64 + sel4[c] : -1;
             }
@@ -822,7 +826,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
             if (b != 0) {
                 V3 wn = mulT(q2mat(q), w - pw);               // joint rate, body axes (undamped)
                 Q4 jold = qnormalize(qmul(qconj(pq), q));  // joint quaternion of the old configuration
-                if (last && valid && live_env) {  // joint drive torque actually applied over the substep (implicit form)
+                if (last && valid && live_env && !frozen) {  // joint drive torque actually applied over the substep (implicit form)
                     V3 tf = kp * (tar - quat_to_expmap_stable(jold) - h * wn) - kd * wn;
                     float* of = a.x_dof_force + e * NDOF + 3 * (b - 1);
                     of[0] = tf.x; of[1] = tf.y; of[2] = tf.z;
@@ -841,7 +845,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                 q = qnormalize(qmul(rotvec_to_quat(h * w0), q));  // world-frame rate: left multiply
             }
         }
-        if (last && valid && live_env) {
+        if (last && valid && live_env && !frozen) {
             // net contact force per body = sum of impulses / h  (refresh_net_contact_force_tensor)
             V3 cforce{0.f, 0.f, 0.f};
             if (CONTACT) {
@@ -856,6 +860,18 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
     }
 
     LLPH(7);
+    if (frozen && nsub > 0) {  // frozen env sharing a wave with a live one: it was carried along, its result is dropped
+        if (b == 0) {
+            q = Q4{st[SIDX(ST_ROOT_QUAT + 0)], st[SIDX(ST_ROOT_QUAT + 1)], st[SIDX(ST_ROOT_QUAT + 2)], st[SIDX(ST_ROOT_QUAT + 3)]};
+            x = V3{st[SIDX(ST_ROOT_POS + 0)], st[SIDX(ST_ROOT_POS + 1)], st[SIDX(ST_ROOT_POS + 2)]};
+            xd = V3{st[SIDX(ST_VEL + 0)], st[SIDX(ST_VEL + 1)], st[SIDX(ST_VEL + 2)]};
+            w = V3{st[SIDX(ST_VEL + 3)], st[SIDX(ST_VEL + 4)], st[SIDX(ST_VEL + 5)]};
+        } else {
+            const int jb = ST_JQUAT + 4 * (b - 1), vb = ST_VEL + 6 + 3 * (b - 1);
+            jq = Q4{st[SIDX(jb + 0)], st[SIDX(jb + 1)], st[SIDX(jb + 2)], st[SIDX(jb + 3)]};
+            wt = V3{st[SIDX(vb + 0)], st[SIDX(vb + 1)], st[SIDX(vb + 2)]};
+        }
+    }
     // ==================================================================== final kinematics -> state, rigid-body state, dof_pos
     const V3 lpos{S->local_pos[b][0], S->local_pos[b][1], S->local_pos[b][2]};
     for (int d = 1; d <= maxd; ++d) {
@@ -890,7 +906,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
             ksoon = __popc(half ? (unsigned)(nb2 >> 32) : (unsigned)nb2);
         }
         if (lb == 0 && live_env) {
-            int key = (ksum > ksoon ? ksum : ksoon) * 8 + (kdep > 7 ? 7 : kdep);
+            int key = frozen ? 0 : (ksum > ksoon ? ksum : ksoon) * 8 + (kdep > 7 ? 7 : kdep);
             key = key > PAIR_BINS - 1 ? PAIR_BINS - 1 : key;
             const int pos = atomicAdd(&a.pair_hist[PAIR_BINS - 1 - key], 1);
             a.pair_key[e] = key;

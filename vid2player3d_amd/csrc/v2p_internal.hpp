@@ -90,6 +90,7 @@ struct EnvParams {
     float gravity_z, mu, contact_offset, max_depen, erp, ang_damp, max_ang_vel;
     float pd_tar_lim, res_force_scale, res_torque_scale, ground_tolerance, max_episode_length;
     int enable_early_termination;
+    int freeze_terminated;  // envs whose reset flag is set are not simulated (their state stays as it is)
     int context_length, context_padding;
     float dt;              // control step
     float term_heights[NB];

@@ -330,6 +330,7 @@ class HumanoidSMPLIM:
         c.control_freq_inv = self.control_freq_inv
         c.num_solver_iterations = sp.physx.num_position_iterations
         c.enable_contact = int(env.get("enable_contact", True))
+        c.freeze_terminated_envs = int(env.get("freeze_terminated_envs", False))  # not the reference's behaviour: see v2p_rollout.h
         hold = env.get("residual_force_hold", "first_sim")
         c.residual_hold_sims = 1 if hold == "first_sim" else self.control_freq_inv
         c.gravity_z = sp.gravity[2]
