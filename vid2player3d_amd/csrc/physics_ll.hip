@@ -114,6 +114,7 @@ __device__ __forceinline__ void grp_argmax(float& v, int& k) {
 #define V2P_LL_WPS 2   // waves per SIMD the register budget is set for
 #endif
 constexpr int LL_WPB = V2P_LL_WPB;
+constexpr int PARK_TAR = 0, PARK_W0 = 3, PARK_XD0 = 6, PARK_Q = 9, PARK_X = 13, PARK_SLOTS = 16;  // LDS parking slots (dwords per lane)
 template <bool CONTACT, bool MULTI>
 __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(PhysArgs a) {
     const int64_t N = a.n;
@@ -141,6 +142,14 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
     // hull vertex `idx` of this env's shape, from the shape table through L1/L2.  (An LDS copy per workgroup measured 3.5 % slower
     // at 8192 envs: 4096 workgroups x 19 KB of staging traffic and a barrier before the first substep.)
     auto hullv = [&](int idx) -> float4 { return make_float4(S->hull_verts[idx][0], S->hull_verts[idx][1], S->hull_verts[idx][2], 0.f); };
+
+    // ---- LDS "parking": per-lane values that live for the whole launch but are touched once or twice per substep (the PD target,
+    // the velocities at the start of the sweep).  Holding them in registers made the allocator spill them (or something else) to
+    // scratch - private memory that ends up as HBM write traffic; 9 dwords x 64 lanes of LDS per wave cost nothing.
+    extern __shared__ float park_all[];
+    float* const park = park_all + (threadIdx.x >> 6) * (PARK_SLOTS * 64) + lane;  // slot k of this lane: park[k * 64]
+    auto park_put3 = [&](int slot, V3 v) { park[slot * 64] = v.x; park[(slot + 1) * 64] = v.y; park[(slot + 2) * 64] = v.z; };
+    auto park_get3 = [&](int slot) -> V3 { return V3{park[slot * 64], park[(slot + 1) * 64], park[(slot + 2) * 64]}; };
 
     // ---- per-lane model constants
     const int par = b ? M.parents[b] : 0;
@@ -203,6 +212,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
         }
     }
 
+    park_put3(PARK_TAR, tar);  // constant for the whole launch
     long long tprev = a.prof ? clock64() : 0;
     const long long wt0 = a.wave_times ? wall_clock64() : 0;
     const int key_pred = a.wave_times ? a.pair_key[e] : 0;  // what the launch order was built from (diagnostics)
@@ -219,7 +229,6 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
         int bo = b;
         asm volatile("" : "+v"(bo));
         const V3 lpos{S->local_pos[bo][0], S->local_pos[bo][1], S->local_pos[bo][2]};
-        const float kp = S->kp[bo], kd = S->kd[bo];
         // ================================================================ pass 1: kinematics, root -> leaves by level
         V3 zw{0.f, 0.f, 0.f}, zv{0.f, 0.f, 0.f};
         for (int d = 1; d <= maxd; ++d) {
@@ -251,7 +260,8 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
         V3 pn, pf;
         {
             const M3 R = q2mat(q);
-            if (b != 0) tau = mul(R, kp * (tar - quat_to_expmap_stable(jq)) - (kd + h * kp) * wt);
+            const float kp = S->kp[bo], kd = S->kd[bo];
+            if (b != 0) tau = mul(R, kp * (park_get3(PARK_TAR) - quat_to_expmap_stable(jq)) - (kd + h * kp) * wt);
             V3 dc = mul(R, com);
             V3 k0 = mul(Ib, V3{R.m[0], R.m[1], R.m[2]});
             V3 k1 = mul(Ib, V3{R.m[3], R.m[4], R.m[5]});
@@ -275,6 +285,9 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
             }
         }
 
+        // pose of the link: next used by contact generation, then by the integration
+        park[PARK_Q * 64] = q.x; park[(PARK_Q + 1) * 64] = q.y; park[(PARK_Q + 2) * 64] = q.z; park[(PARK_Q + 3) * 64] = q.w;
+        park_put3(PARK_X, x);
         LLPH(1);
         // ================================================================ pass 2: articulated inertia, leaves -> root by level
         Sym3 Di{1.f, 0.f, 0.f, 1.f, 0.f, 1.f};
@@ -402,6 +415,8 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
         }
 
         LLPH(3);
+        q = Q4{park[PARK_Q * 64], park[(PARK_Q + 1) * 64], park[(PARK_Q + 2) * 64], park[(PARK_Q + 3) * 64]};
+        x = park_get3(PARK_X);
         int cnt = 0;
         V3 cr[4];
         float cbias[4];
@@ -652,7 +667,8 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                 }
 
                 LLPH(5);
-                const V3 w0 = w, xd0 = xd;  // the sweep's total delta-velocity of a link = its velocity now - these
+                park_put3(PARK_W0, w);  // the sweep's total delta-velocity of a link = its velocity at the end - these
+                park_put3(PARK_XD0, xd);
                 // touched links whose parent is the touched link right before them (ascending): they continue a group (below)
                 unsigned chain0 = 0u, chain1 = 0u;
                 {
@@ -801,7 +817,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                     if (!moved) break;  // a whole iteration without any change: the remaining ones would repeat it
                 }
                 // links below the deepest touched one: one catch-up pass with the accumulated motion of their parents
-                V3 accw = w - w0, accv = xd - xd0;
+                V3 accw = w - park_get3(PARK_W0), accv = xd - park_get3(PARK_XD0);
                 for (int d = dmin + 1; d <= maxd; ++d) {
                     const bool nc = (nonchain >> d) & 1;
                     V3 pdw = pp(accw, nc), pdv = pp(accv, nc);
@@ -817,6 +833,8 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
         }
 
         LLPH(6);
+        q = Q4{park[PARK_Q * 64], park[(PARK_Q + 1) * 64], park[(PARK_Q + 2) * 64], park[(PARK_Q + 3) * 64]};
+        x = park_get3(PARK_X);
         // ================================================================ velocities -> generalized, damping, clamp, integrate
         const float sc = 1.f / (1.f + h * P.ang_damp);
         const float wmax = P.max_ang_vel;
@@ -827,7 +845,8 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                 V3 wn = mulT(q2mat(q), w - pw);               // joint rate, body axes (undamped)
                 Q4 jold = qnormalize(qmul(qconj(pq), q));  // joint quaternion of the old configuration
                 if (last && valid && live_env && !frozen) {  // joint drive torque actually applied over the substep (implicit form)
-                    V3 tf = kp * (tar - quat_to_expmap_stable(jold) - h * wn) - kd * wn;
+                    const float kp = S->kp[b], kd = S->kd[b];
+                    V3 tf = kp * (park_get3(PARK_TAR) - quat_to_expmap_stable(jold) - h * wn) - kd * wn;
                     float* of = a.x_dof_force + e * NDOF + 3 * (b - 1);
                     of[0] = tf.x; of[1] = tf.y; of[2] = tf.z;
                 }
@@ -1022,12 +1041,13 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s, float* actions) {
     a.shape_aug = env->shape_aug_dev;
     const bool multi = env->num_shapes > 1;  // per-env shapes: hull vertices come from the shape tables instead of the LDS copy
     const dim3 grid(blocks), block(64 * LL_WPB);
+    const size_t lds = sizeof(float) * PARK_SLOTS * 64 * LL_WPB;
     if (env->p.enable_contact) {
-        if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((physics_ll_kernel<true, false>), grid, block, 0, s, a);
+        if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((physics_ll_kernel<true, false>), grid, block, lds, s, a);
     } else {
-        if (multi) hipLaunchKernelGGL((physics_ll_kernel<false, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((physics_ll_kernel<false, false>), grid, block, 0, s, a);
+        if (multi) hipLaunchKernelGGL((physics_ll_kernel<false, true>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((physics_ll_kernel<false, false>), grid, block, lds, s, a);
     }
     env->pair_have = paired ? 1 : 0;
     return check_hip(hipGetLastError(), "physics_ll_kernel");
