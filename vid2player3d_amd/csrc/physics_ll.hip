@@ -13,9 +13,9 @@
 //   * envs are handed to waves in descending order of their contact load (the sweep costs max(load) of the pair), a
 //     counting sort spread over this kernel's epilogue and the pre-physics kernel; an env's arithmetic never depends on
 //     the env it shares a wave with
-//   * no global workspace, no LDS: the kernel reads the state once, keeps it in registers for the 4 substeps and
+//   * no global workspace: the kernel reads the state once, keeps it in registers for the 4 substeps and
 //     writes the state and the caller's row-major tensors once (lane = body gives contiguous rows); hull vertices and
-//     per-link constants come from the (per-env) shape table through L1/L2
+//     per-link constants come from the (per-env) shape table through L1/L2; LDS is only a parking area for a few long-lived values
 //   * 256 VGPRs, 2 waves per SIMD (needs -fno-slp-vectorize: SLP packing costs ~160 registers here)
 //
 // The sequential semantics of the Gauss-Seidel sweep (bodies ascending, points in slot order, rows
