@@ -13,45 +13,11 @@ namespace v2p {
 constexpr int EB_BLOCK = 192;          // 8 envs x 24 bodies = 3 wave64
 constexpr int ENVS_PER_BLOCK = EB_BLOCK / NB;
 
+#include "post_ops.inc"
+
 // ------------------------------------------------------------------------------------------
 // reward  (compute_humanoid_reward, humanoid_smpl_im.py:918-953; dof_to_obs, humanoid_smpl.py:604-635)
 // ------------------------------------------------------------------------------------------
-struct RewardPartial {
-    float dof, vel, pos, rot;
-};
-
-// contribution of body j: its joint (j>=1) to the dof / vel terms, itself to the pos / rot terms
-__device__ __forceinline__ RewardPartial reward_partial(int j, V3 body_pos, Q4 body_rot, V3 tgt_pos, Q4 tgt_rot, V3 dof_pos, V3 dof_vel,
-                                                        V3 tgt_dof_pos, V3 tgt_dof_vel, float w) {
-    RewardPartial r{0.f, 0.f, 0.f, 0.f};
-    if (j > 0) {
-        V3 t0, n0, t1, n1;
-        ref_quat_to_tan_norm(ref_exp_map_to_quat(dof_pos), t0, n0);
-        ref_quat_to_tan_norm(ref_exp_map_to_quat(tgt_dof_pos), t1, n1);
-        V3 dt = t0 - t1, dn = n0 - n1;
-        r.dof = dot(dt, dt) + dot(dn, dn);
-        V3 dv = tgt_dof_vel - dof_vel;
-        r.vel = dot(dv, dv);
-    }
-    V3 dp = (tgt_pos - body_pos) * w;
-    r.pos = dot(dp, dp) * (1.f / 3.f);
-    V3 ax;
-    float ang = ref_quat_to_angle_axis(qmul(tgt_rot, qconj(body_rot)), ax);
-    r.rot = ang * ang;
-    return r;
-}
-
-__device__ __forceinline__ void reward_finish(const float* specs, float sdof, float svel, float spos, float srot, float& rew, float sub[4]) {
-    sub[0] = expf(-specs[0] * (sdof * (1.f / 138.f)));
-    sub[1] = expf(-specs[1] * (svel * (1.f / 69.f)));
-    sub[2] = expf(-specs[2] * (spos * (1.f / 24.f)));
-    sub[3] = expf(-specs[3] * (srot * (1.f / 24.f)));
-    rew = specs[4] * sub[0] + specs[5] * sub[1] + specs[6] * sub[2] + specs[7] * sub[3];
-}
-
-__device__ __forceinline__ V3 ld3(const float* p) { return V3{p[0], p[1], p[2]}; }
-__device__ __forceinline__ Q4 ld4(const float* p) { return Q4{p[0], p[1], p[2], p[3]}; }
-
 struct RewardSpecs {
     float v[8];
 };
@@ -291,18 +257,9 @@ static EnvView make_view(const v2p_env* e) {
     return v;
 }
 
-// raw-state observation row (_compute_humanoid_obs, humanoid_smpl_im.py:653-668; order :198)
+// raw-state observation row of env e, body j
 __device__ __forceinline__ void write_obs(const EnvView& v, int64_t e, int j, V3 pos, Q4 rot, V3 vel, V3 ang, V3 dpos, V3 dvel) {
-    float* o = v.b.obs + e * NOBS;
-    st3(o + 3 * j, pos);
-    st4(o + 72 + 4 * j, rot);
-    if (j > 0) {
-        st3(o + 168 + 3 * (j - 1), dpos);
-        st3(o + 237 + 3 * (j - 1), dvel);
-    }
-    st3(o + 306 + 3 * j, vel);
-    st3(o + 378 + 3 * j, ang);
-    if (j < 11) o[450 + j] = v.t.motion_bodies[v.motion_id[e] * 11 + j];
+    write_obs_row(v.b.obs + e * NOBS, v.t.motion_bodies + v.motion_id[e] * 11, j, pos, rot, vel, ang, dpos, dvel);
 }
 
 // ---- reset: reference-state init (humanoid_smpl_im.py:489-528, 741-755; humanoid_smpl.py:153-173)
