@@ -274,3 +274,28 @@ def test_discount_values_wrapper(golden_task_ops):
     adv = discount_values(None, None, T(g["gae_fdones"]), T(g["gae_values"]), T(g["gae_rewards"]), T(g["gae_next_values"]), float(g["gae_gamma"]),
                           float(g["gae_tau"]))
     close(N(adv), g["gae_advs"], 2e-6, "discount_values")
+
+
+def test_replay_tool_on_the_golden_trace(tmp_path, golden_tables, capsys, monkeypatch):
+    """tools/replay_trace.py (the procedure that pins physics parity on a box with Isaac Gym) runs end to end on the golden trace:
+    teacher-forced task ops within float32 rounding of the recording."""
+    import importlib.util
+    import os
+    import sys
+
+    from tests.conftest import GOLDEN, REPO
+
+    keys = ("gts", "grs", "lrs", "grvs", "gravs", "dvs", "motion_lengths", "motion_num_frames", "motion_dt", "motion_fps", "motion_weights",
+            "motion_bodies", "motion_min_verts_h")
+    flat = tmp_path / "mlib.npz"
+    np.savez(str(flat), **{k: golden_tables[k] for k in keys})
+    spec = importlib.util.spec_from_file_location("replay_trace", os.path.join(REPO, "tools", "replay_trace.py"))
+    mod = importlib.util.module_from_spec(spec)
+    monkeypatch.chdir(REPO)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(sys, "argv", ["replay_trace.py", os.path.join(GOLDEN, "env_trace.npz"), "--motion", str(flat)])
+    mod.main()
+    out = capsys.readouterr().out
+    vals = {line[2:50].strip(): float(line[50:]) for line in out.splitlines() if line.startswith("  ")}
+    assert vals["obs"] <= 5e-6 and vals["reward"] <= 1e-4 and vals["reset flags"] == 0 and vals["terminate flags"] == 0
+    assert vals["target rb_pos"] <= 5e-6 and vals["actions masked in place"] == 0
