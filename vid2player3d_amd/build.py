@@ -47,6 +47,12 @@ def build(force=False, verbose=False):
             # the task-side kernels restate torch elementwise code: no FMA contraction, so that ill-conditioned spots of the
             # reference itself (acos of a dot product next to 1 in slerp / angle-axis) round the way torch rounds them
             fl = [f if f != "-ffp-contract=fast" else "-ffp-contract=off" for f in fl]
+        if s == "physics_ll.hip":
+            # the link-per-lane physics kernel: relaxed fp32 arithmetic (reassociation, approximate div / sqrt / sin / cos, no NaN or
+            # signed-zero bookkeeping): +3 %.  The physics model is this engine's own specification; its agreement with the float64
+            # oracle stays inside the tolerances of tests/test_gpu_physics.py (poses 2e-5, velocities 5e-4).  The task-side kernels,
+            # which restate the reference's torch arithmetic, keep strict semantics (above).
+            fl = fl + ["-ffast-math"]
         extra = os.environ.get("V2P_FLAGS_" + s.split(".")[0].upper())  # experiments: per-file flag override, e.g. V2P_FLAGS_PHYSICS_LL="-O1"
         if extra:
             fl = [f for f in fl if f != "-O3"] + extra.split()
