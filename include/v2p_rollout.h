@@ -34,7 +34,7 @@ extern "C" {
 #define V2P_NUM_OBS 461
 #define V2P_MOTION_STATE_DIM 331  /* root_pos3 root_rot4 dof_pos69 root_vel3 root_ang_vel3 dof_vel69 key_pos12 rb_pos72 rb_rot96 */
 #define V2P_CONTEXT_DIM 378       /* body_pos72 body_rot96 dof_pos69 body_pos_gt72 dof_pos_gt69 (humanoid_smpl_im.py:202) */
-#define V2P_ABI_VERSION 2
+#define V2P_ABI_VERSION 3
 
 typedef enum {
     V2P_OK = 0,
@@ -167,6 +167,16 @@ typedef struct {
     int32_t freeze_terminated_envs; /* 0 (reference behaviour): envs whose reset flag is set keep being simulated as ragdolls until the
                                      * epoch reset, although nothing downstream reads them (zero reward, masked by `dones` in
                                      * im_agent.py:392-414).  1: their physics state is frozen instead (link-per-lane schedule). */
+    /* ---- ABI 3 */
+    int32_t schedule;           /* kernel schedule a batch starts with (v2p_env_set_schedule changes it): 0 = one link per lane (default),
+                                 * 1 = one env per lane (cross-check) */
+    int32_t pair_envs_by_load;  /* 1 (default): envs are handed to waves in descending order of their contact load; 0: in index order.
+                                 * Results do not depend on it (tests), only the launch duration does. */
+    int32_t solver_type;        /* contact solver: 0 = projected Gauss-Seidel (default), 1 = temporal Gauss-Seidel with frozen Jacobians
+                                 * (sim.physx.solver_type of amass_im.yaml:41 is 1 = TGS in PhysX; see oracle/phys/v2p_phys_oracle.c for
+                                 * what either means here).  Link-per-lane schedule only. */
+    int32_t debug_substep_contacts; /* 1: keep the contact vertex ids of EVERY substep (v2p_env_debug_contacts_substeps); costs
+                                     * 384 B x substeps of extra stores per env-step, off by default */
 } v2p_sim_cfg;
 
 /* Caller-owned DEVICE buffers the engine reads/writes; these are the tensors the reference
@@ -235,6 +245,9 @@ int v2p_env_target_index(const v2p_env* e);
 
 /* diagnostics for tests: contact vertex ids chosen in the last substep, [N,24,4] int32, body*64+vertex or -1 */
 int v2p_env_debug_contacts(v2p_env* e, int32_t* out, void* stream);
+
+/* the same for every substep of the last control step, [N,substeps*control_freq_inv,24,4] (needs v2p_sim_cfg.debug_substep_contacts) */
+int v2p_env_debug_contacts_substeps(v2p_env* e, int32_t* out, void* stream);
 
 /* diagnostics for tests: the wave-slot -> env order used by the last physics launch (`perm`, [N] int32; envs are handed to
  * waves in descending order of their contact load, see DESIGN.md "pairing") and the load key it was built from (`key`, [N]) */

@@ -29,12 +29,16 @@
  *   contacts: hull vertices with z < contact_offset; <=4 per body (deepest, farthest,
  *        extreme left/right); rows n,t1,t2 per point; bias = d/h (d>=0) or
  *        max(erp*d/h, -max_depenetration_velocity) (d<0); box friction |lt| <= mu*ln
- *   PGS: n_iter sweeps, bodies ascending, points in slot order, rows n,t1,t2
+ *   PGS (solver_type 0): n_iter sweeps, bodies ascending, points in slot order, rows n,t1,t2;
+ *   TGS (solver_type 1): one sweep per time slice h/n_iter with re-evaluated gaps (see the substep)
  *   v+ = v* + Mt^-1 J^T lambda;  angular damping 1/(1+h*c); |w| clamp; integrate.
  */
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define NB 24
 #define NJ (NB - 1)
@@ -64,7 +68,15 @@ typedef struct {
     double erp;            /* 0.2: fraction of a penetration corrected per substep */
     int n_iter;            /* 4 */
     int enable_contact;
+    int solver_type;       /* 0 = PGS (default), 1 = TGS (see the substep) */
 } v2p_oparams;
+
+/* optional per-substep inputs / outputs for the parity tests (all nullable) */
+typedef struct {
+    const int *forced_ids; /* [NB*4] in: use these hull vertices (body*64+vertex, -1 = none) instead of the selection rule */
+    int *own_ids;          /* [NB*4] out: what the selection rule picks in this state (whether or not it was forced) */
+    double *margins;       /* [NB] out: how close the selection rule came to deciding otherwise, in metres (1e30 = no decision) */
+} v2p_osub_io;
 
 typedef struct {
     double root_pos[3];
@@ -325,49 +337,78 @@ typedef struct {
     double pos[NB * MAXC_BODY][3];
 } contacts_t;
 
-static void gen_contacts(const v2p_omodel *m, const v2p_oparams *p, const kin_t *k, contacts_t *cs) {
+/* Selection rule of one body (<=4 of the hull vertices below the contact offset: all if <= 4, else the deepest, the one
+ * farthest from it in the plane, and the extremes on either side of that line; ties go to the lowest index).  `margin` = how
+ * close the rule came to deciding otherwise, in metres: distance of any vertex to the offset plane, gap between the winner
+ * and the runner-up of every arg-extreme (areas divided by the base length). */
+static int select_body(const double (*P)[3], int nv, double coff, int sel[4], double *margin) {
+    int count = 0, first[4] = {-1, -1, -1, -1}, k0 = -1, ns = 0;
+    double zmin = 0, mg = 1e30;
+    for (int i = 0; i < nv; ++i) {
+        double dz = fabs(P[i][2] - coff);
+        if (dz < mg) mg = dz;
+        if (P[i][2] < coff) {
+            if (count < 4) first[count] = i;
+            if (k0 < 0 || P[i][2] < zmin) { k0 = i; zmin = P[i][2]; }
+            ++count;
+        }
+    }
+    if (count > 0 && count <= 4) {
+        for (int i = 0; i < count; ++i) sel[ns++] = first[i];
+    } else if (count > 4) {
+        int k1 = -1, k2 = -1, k3 = -1;
+        double best = -1.0, second = -1.0;
+        for (int i = 0; i < nv; ++i) {
+            if (!(P[i][2] < coff) || i == k0) continue;
+            double g = P[i][2] - zmin; /* runner-up of the deepest point */
+            if (g < mg) mg = g;
+            double dx = P[i][0] - P[k0][0], dy = P[i][1] - P[k0][1];
+            double d2 = dx * dx + dy * dy;
+            if (d2 > best) { second = best; best = d2; k1 = i; } else if (d2 > second) second = d2;
+        }
+        if (second >= 0 && sqrt(best) - sqrt(second) < mg) mg = sqrt(best) - sqrt(second);
+        double ex = P[k1][0] - P[k0][0], ey = P[k1][1] - P[k0][1];
+        double el = sqrt(ex * ex + ey * ey) + 1e-300;
+        double amax = 0.0, amin = 0.0, amax2 = 0.0, amin2 = 0.0;
+        for (int i = 0; i < nv; ++i) {
+            if (!(P[i][2] < coff) || i == k0 || i == k1) continue;
+            double area = ex * (P[i][1] - P[k0][1]) - ey * (P[i][0] - P[k0][0]);
+            if (area > amax) { amax2 = amax; amax = area; k2 = i; } else if (area > amax2) amax2 = area;
+            if (area < amin) { amin2 = amin; amin = area; k3 = i; } else if (area < amin2) amin2 = area;
+        }
+        if (k2 >= 0 && (amax - amax2) / el < mg) mg = (amax - amax2) / el;
+        if (k3 >= 0 && (amin2 - amin) / el < mg) mg = (amin2 - amin) / el;
+        sel[ns++] = k0;
+        sel[ns++] = k1;
+        if (k2 >= 0) sel[ns++] = k2;
+        if (k3 >= 0) sel[ns++] = k3;
+    }
+    if (margin) *margin = mg;
+    return ns;
+}
+
+static void gen_contacts(const v2p_omodel *m, const v2p_oparams *p, const kin_t *k, contacts_t *cs, const v2p_osub_io *io) {
     cs->n = 0;
     for (int b = 0; b < NB; ++b) {
         int v0 = m->hull_offsets[b], v1 = m->hull_offsets[b + 1];
         int nv = v1 - v0;
         double (*P)[3] = malloc(sizeof(double[3]) * (size_t)nv);
-        int count = 0, first[4] = {-1, -1, -1, -1};
-        int k0 = -1;
-        double zmin = 0;
         for (int i = 0; i < nv; ++i) {
             double t[3];
             matvec(k->R[b], &m->hull_verts[3 * (v0 + i)], t);
             for (int c = 0; c < 3; ++c) P[i][c] = k->x[b][c] + t[c];
-            if (P[i][2] < p->contact_offset) {
-                if (count < 4) first[count] = i;
-                if (k0 < 0 || P[i][2] < zmin) { k0 = i; zmin = P[i][2]; }
-                ++count;
-            }
         }
-        int sel[4], ns = 0;
-        if (count > 0 && count <= 4) {
-            for (int i = 0; i < count; ++i) sel[ns++] = first[i];
-        } else if (count > 4) {
-            int k1 = -1, k2 = -1, k3 = -1;
-            double best = -1.0;
-            for (int i = 0; i < nv; ++i) {
-                if (!(P[i][2] < p->contact_offset) || i == k0) continue;
-                double dx = P[i][0] - P[k0][0], dy = P[i][1] - P[k0][1];
-                double d2 = dx * dx + dy * dy;
-                if (d2 > best) { best = d2; k1 = i; }
+        int sel[4], ns;
+        double mg;
+        ns = select_body((const double (*)[3])P, nv, p->contact_offset, sel, &mg);
+        if (io && io->own_ids) for (int i = 0; i < 4; ++i) io->own_ids[4 * b + i] = i < ns ? b * 64 + sel[i] : -1;
+        if (io && io->margins) io->margins[b] = mg;
+        if (io && io->forced_ids) {
+            ns = 0;
+            for (int i = 0; i < 4; ++i) {
+                int id = io->forced_ids[4 * b + i];
+                if (id >= 0 && id / 64 == b && id % 64 < nv) sel[ns++] = id % 64;
             }
-            double ex = P[k1][0] - P[k0][0], ey = P[k1][1] - P[k0][1];
-            double amax = 0.0, amin = 0.0;
-            for (int i = 0; i < nv; ++i) {
-                if (!(P[i][2] < p->contact_offset) || i == k0 || i == k1) continue;
-                double area = ex * (P[i][1] - P[k0][1]) - ey * (P[i][0] - P[k0][0]);
-                if (area > amax) { amax = area; k2 = i; }
-                if (area < amin) { amin = area; k3 = i; }
-            }
-            sel[ns++] = k0;
-            sel[ns++] = k1;
-            if (k2 >= 0) sel[ns++] = k2;
-            if (k3 >= 0) sel[ns++] = k3;
         }
         for (int i = 0; i < ns; ++i) {
             int c = cs->n++;
@@ -380,9 +421,10 @@ static void gen_contacts(const v2p_omodel *m, const v2p_oparams *p, const kin_t 
 }
 
 /* ------------------------------------------------------------------ one substep */
-int v2p_oracle_substep(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s, const double *pd_target /*[69]*/,
-                       const double *ext_force /*[3] world, at root COM*/, const double *ext_torque /*[3] world*/,
-                       double *contact_force /*[NB*3] out*/, double *dof_force /*[69] out*/, int *contact_ids /*[NB*4] out: body*64+vertex, -1 padded*/) {
+int v2p_oracle_substep_io(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s, const double *pd_target /*[69]*/,
+                          const double *ext_force /*[3] world, at root COM*/, const double *ext_torque /*[3] world*/,
+                          double *contact_force /*[NB*3] out*/, double *dof_force /*[69] out*/, int *contact_ids /*[NB*4] out: body*64+vertex, -1 padded*/,
+                          const v2p_osub_io *io) {
     double *M = malloc(sizeof(double) * ND * ND), C[ND], J[6 * ND];
     double rhs[ND], q[3 * NJ];
     kin_t k;
@@ -417,13 +459,14 @@ int v2p_oracle_substep(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s,
     if (contact_ids) for (int i = 0; i < NB * 4; ++i) contact_ids[i] = -1;
     if (p->enable_contact) {
         contacts_t cs;
-        gen_contacts(m, p, &k, &cs);
+        gen_contacts(m, p, &k, &cs, io);
         int nrow = cs.n * 3;
         double *Jr = calloc((size_t)(nrow > 0 ? nrow : 1) * ND, sizeof(double));
         double *Tr = calloc((size_t)(nrow > 0 ? nrow : 1) * ND, sizeof(double));
         double *wii = calloc((size_t)(nrow > 0 ? nrow : 1), sizeof(double));
         double *lam = calloc((size_t)(nrow > 0 ? nrow : 1), sizeof(double));
         double *bias = calloc((size_t)(nrow > 0 ? nrow : 1), sizeof(double));
+        double gap[NB * MAXC_BODY];
         const double dirs[3][3] = {{0, 0, 1}, {1, 0, 0}, {0, 1, 0}};
         int slot_in_body[NB];
         memset(slot_in_body, 0, sizeof(slot_in_body));
@@ -449,9 +492,29 @@ int v2p_oracle_substep(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s,
                 wii[row] = sum;
             }
             double d = cs.pos[c][2];
+            gap[c] = d;
             bias[3 * c] = d >= 0 ? d / h : fmax(p->erp * d / h, -p->max_depen_vel);
         }
-        for (int it = 0; it < p->n_iter; ++it)
+        /* solver_type 0, PGS: n_iter sweeps against the biases of the start of the substep.
+         * solver_type 1, TGS (temporal Gauss-Seidel, the PhysX solver amass_im.yaml:41 selects; Macklin et al. 2019, "Small steps in
+         * physics simulation"), restated with the Jacobians frozen over the substep: the substep is cut into n_iter slices of length
+         * hs = h / n_iter, slice k re-evaluates every point's gap with the motion of the previous slices,
+         *     d_c(k) = d_c(k-1) + hs * vn_c(after sweep k-1),
+         * and runs ONE sweep against  d_c(k) / (h - k hs)  (separated: do not cross the plane in the time that is left)  or
+         * max(erp d_c(k) / hs, -max_depenetration)  (penetrating: correct a fraction per slice); impulses accumulate and are clamped
+         * on the accumulated value as in PGS. */
+        for (int it = 0; it < p->n_iter; ++it) {
+            if (p->solver_type == 1) {
+                double hs = h / p->n_iter;
+                for (int c = 0; c < cs.n; ++c) {
+                    if (it > 0) {
+                        double vn = 0;
+                        for (int col = 0; col < ND; ++col) vn += Jr[3 * c * ND + col] * v[col];
+                        gap[c] += hs * vn;
+                    }
+                    bias[3 * c] = gap[c] >= 0 ? gap[c] / (h - it * hs) : fmax(p->erp * gap[c] / hs, -p->max_depen_vel);
+                }
+            }
             for (int c = 0; c < cs.n; ++c)
                 for (int a = 0; a < 3; ++a) {
                     int row = 3 * c + a;
@@ -464,6 +527,7 @@ int v2p_oracle_substep(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s,
                     lam[row] = nl;
                     for (int col = 0; col < ND; ++col) v[col] += Tr[row * ND + col] * dl;
                 }
+        }
         if (contact_force)
             for (int c = 0; c < cs.n; ++c) {
                 int b = cs.body[c];
@@ -543,16 +607,68 @@ void v2p_oracle_get_state(const v2p_omodel *m, const v2p_ostate *s, double *root
         }
 }
 
+int v2p_oracle_substep(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s, const double *pd_target, const double *ext_force,
+                       const double *ext_torque, double *contact_force, double *dof_force, int *contact_ids) {
+    return v2p_oracle_substep_io(m, p, s, pd_target, ext_force, ext_torque, contact_force, dof_force, contact_ids, 0);
+}
+
 /* one control step = nsub substeps; the residual wrench is held for the first `hold` substeps
- * (Isaac Gym consumes applied forces in the next simulate() only: SURVEY.md section 7 hard parts). */
-int v2p_oracle_step(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s, const double *pd_target, const double *ext_force,
-                    const double *ext_torque, int nsub, int hold, double *contact_force, double *dof_force, int *contact_ids) {
+ * (Isaac Gym consumes applied forces in the next simulate() only: SURVEY.md section 7 hard parts).
+ * forced_ids [nsub][NB*4] (nullable): contact vertices to use in each substep instead of the selection rule;
+ * own_ids [nsub][NB*4], margins [nsub][NB] (nullable): what the rule selects in the state of each substep and how narrowly. */
+int v2p_oracle_step_io(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s, const double *pd_target, const double *ext_force,
+                       const double *ext_torque, int nsub, int hold, double *contact_force, double *dof_force, int *contact_ids,
+                       const int *forced_ids, int *own_ids, double *margins) {
     for (int i = 0; i < nsub; ++i) {
         int on = i < hold;
-        int rc = v2p_oracle_substep(m, p, s, pd_target, on ? ext_force : 0, on ? ext_torque : 0, contact_force, dof_force, contact_ids);
+        v2p_osub_io io = {forced_ids ? forced_ids + (size_t)i * NB * 4 : 0, own_ids ? own_ids + (size_t)i * NB * 4 : 0, margins ? margins + (size_t)i * NB : 0};
+        int rc = v2p_oracle_substep_io(m, p, s, pd_target, on ? ext_force : 0, on ? ext_torque : 0, contact_force, dof_force, contact_ids, &io);
         if (rc) return rc;
     }
     return 0;
+}
+
+int v2p_oracle_step(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s, const double *pd_target, const double *ext_force,
+                    const double *ext_torque, int nsub, int hold, double *contact_force, double *dof_force, int *contact_ids) {
+    return v2p_oracle_step_io(m, p, s, pd_target, ext_force, ext_torque, nsub, hold, contact_force, dof_force, contact_ids, 0, 0, 0);
+}
+
+/* A batch of independent humanoids, OpenMP over envs (the cpu_baseline leg of bench.py and the larger parity tests): env e uses
+ * models[model_of ? model_of[e] : 0]; every per-env array is contiguous [n][...]; the optional arrays as in v2p_oracle_step_io.
+ * rb_state [n][NB*13] (nullable) receives the rigid-body state after the step.  Returns the number of failed envs. */
+int v2p_oracle_step_batch(const v2p_omodel *const *models, const int *model_of, const v2p_oparams *p, v2p_ostate *states, int n,
+                          const double *pd_target /*[n][69]*/, const double *ext_force /*[n][3]*/, const double *ext_torque /*[n][3]*/,
+                          int nsub, int hold, double *contact_force /*[n][NB*3]*/, double *dof_force /*[n][69]*/, int *contact_ids /*[n][NB*4]*/,
+                          const int *forced_ids /*[n][nsub][NB*4]*/, int *own_ids, double *margins /*[n][nsub][NB]*/,
+                          double *root13 /*[n][13]*/, double *dof_pos /*[n][69]*/, double *dof_vel /*[n][69]*/, double *rb_state /*[n][NB*13]*/,
+                          int num_threads) {
+    int failed = 0;
+#ifdef _OPENMP
+    if (num_threads > 0) omp_set_num_threads(num_threads);
+#endif
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : failed)
+    for (int e = 0; e < n; ++e) {
+        const v2p_omodel *m = models[model_of ? model_of[e] : 0];
+        size_t E = (size_t)e;
+        int rc = v2p_oracle_step_io(m, p, &states[e], pd_target ? pd_target + E * 3 * NJ : 0, ext_force ? ext_force + E * 3 : 0,
+                                    ext_torque ? ext_torque + E * 3 : 0, nsub, hold, contact_force ? contact_force + E * NB * 3 : 0,
+                                    dof_force ? dof_force + E * 3 * NJ : 0, contact_ids ? contact_ids + E * NB * 4 : 0,
+                                    forced_ids ? forced_ids + E * nsub * NB * 4 : 0, own_ids ? own_ids + E * nsub * NB * 4 : 0,
+                                    margins ? margins + E * nsub * NB : 0);
+        if (rc) { ++failed; continue; }
+        if (root13 || dof_pos || dof_vel || rb_state)
+            v2p_oracle_get_state(m, &states[e], root13 ? root13 + E * 13 : 0, dof_pos ? dof_pos + E * 3 * NJ : 0, dof_vel ? dof_vel + E * 3 * NJ : 0,
+                                 rb_state ? rb_state + E * NB * 13 : 0);
+    }
+    return failed;
+}
+
+int v2p_oracle_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
 }
 
 /* ------------------------------------------------------------------ diagnostics for invariant tests */

@@ -24,7 +24,7 @@ class OModel(C.Structure):
 
 class OParams(C.Structure):
     _fields_ = [("h", C.c_double), ("gravity_z", C.c_double), ("mu", C.c_double), ("contact_offset", C.c_double), ("max_depen_vel", C.c_double),
-                ("ang_damp", C.c_double), ("max_ang_vel", C.c_double), ("erp", C.c_double), ("n_iter", C.c_int), ("enable_contact", C.c_int)]
+                ("ang_damp", C.c_double), ("max_ang_vel", C.c_double), ("erp", C.c_double), ("n_iter", C.c_int), ("enable_contact", C.c_int), ("solver_type", C.c_int)]
 
 
 class OState(C.Structure):
@@ -49,14 +49,35 @@ def lib():
 def default_params(h=1.0 / 120.0, enable_contact=True, **kw):
     """amass_im.yaml:37-52 + humanoid_smpl_im.py:273-276."""
     p = OParams(h=h, gravity_z=-9.81, mu=1.0, contact_offset=0.02, max_depen_vel=10.0, ang_damp=0.01, max_ang_vel=100.0, erp=0.2, n_iter=4,
-                enable_contact=int(enable_contact))
+                enable_contact=int(enable_contact), solver_type=0)
     for k, v in kw.items():
         setattr(p, k, v)
     return p
 
 
 def _dptr(a):
-    return a.ctypes.data_as(C.POINTER(C.c_double))
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _iptr(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def _omodel(body_model, kp=None, kd=None, armature=None):
+    """(OModel, keep-alive array) for a vid2player3d_amd.model.BodyModel."""
+    m = OModel()
+    m.parents[:] = [int(x) for x in body_model.parents]
+    m.local_pos[:] = body_model.local_pos.reshape(-1).tolist()
+    m.mass[:] = body_model.mass.tolist()
+    m.com[:] = body_model.com.reshape(-1).tolist()
+    m.inertia[:] = body_model.inertia.reshape(-1).tolist()
+    m.kp[:] = np.asarray(body_model.kp if kp is None else kp, dtype=np.float64).tolist()
+    m.kd[:] = np.asarray(body_model.kd if kd is None else kd, dtype=np.float64).tolist()
+    m.armature[:] = np.asarray(body_model.armature if armature is None else armature, dtype=np.float64).tolist()
+    m.hull_offsets[:] = [int(x) for x in body_model.hull_offsets]
+    hv = np.ascontiguousarray(body_model.hull_verts, dtype=np.float64)
+    m.hull_verts = _dptr(hv)
+    return m, hv
 
 
 class PhysOracle:
@@ -64,19 +85,7 @@ class PhysOracle:
 
     def __init__(self, body_model, params=None, kp=None, kd=None, armature=None):
         self.lib = lib()
-        m = OModel()
-        m.parents[:] = [int(x) for x in body_model.parents]
-        m.local_pos[:] = body_model.local_pos.reshape(-1).tolist()
-        m.mass[:] = body_model.mass.tolist()
-        m.com[:] = body_model.com.reshape(-1).tolist()
-        m.inertia[:] = body_model.inertia.reshape(-1).tolist()
-        m.kp[:] = np.asarray(body_model.kp if kp is None else kp, dtype=np.float64).tolist()
-        m.kd[:] = np.asarray(body_model.kd if kd is None else kd, dtype=np.float64).tolist()
-        m.armature[:] = np.asarray(body_model.armature if armature is None else armature, dtype=np.float64).tolist()
-        m.hull_offsets[:] = [int(x) for x in body_model.hull_offsets]
-        self._hv = np.ascontiguousarray(body_model.hull_verts, dtype=np.float64)
-        m.hull_verts = _dptr(self._hv)
-        self.model = m
+        self.model, self._hv = _omodel(body_model, kp, kd, armature)
         self.params = params or default_params()
         self.state = OState()
 
@@ -94,21 +103,70 @@ class PhysOracle:
         self.lib.v2p_oracle_get_state(C.byref(self.model), C.byref(self.state), _dptr(root), _dptr(dp), _dptr(dv), _dptr(rb))
         return root, dp, dv, rb
 
-    def step(self, pd_target=None, ext_force=None, ext_torque=None, nsub=4, hold=2):
+    def step(self, pd_target=None, ext_force=None, ext_torque=None, nsub=4, hold=2, forced_ids=None, want_selection=False):
+        """forced_ids [nsub,24,4] int32: contact vertices to use instead of the selection rule.  want_selection: also return the
+        rule's own picks [nsub,24,4] in the state of every substep and their decision margins [nsub,24] (metres)."""
         cf = np.zeros((NB, 3))
         df = np.zeros(69)
         ids = np.full(NB * 4, -1, dtype=np.int32)
         tar = None if pd_target is None else np.ascontiguousarray(pd_target, dtype=np.float64)
         f = None if ext_force is None else np.ascontiguousarray(ext_force, dtype=np.float64)
         t = None if ext_torque is None else np.ascontiguousarray(ext_torque, dtype=np.float64)
-        rc = self.lib.v2p_oracle_step(C.byref(self.model), C.byref(self.params), C.byref(self.state), None if tar is None else _dptr(tar),
-                                      None if f is None else _dptr(f), None if t is None else _dptr(t), int(nsub), int(hold), _dptr(cf),
-                                      _dptr(df), ids.ctypes.data_as(C.POINTER(C.c_int)))
+        forced = None if forced_ids is None else np.ascontiguousarray(forced_ids, dtype=np.int32).reshape(nsub, NB * 4)
+        own = np.full((nsub, NB, 4), -1, dtype=np.int32) if want_selection else None
+        mg = np.zeros((nsub, NB)) if want_selection else None
+        rc = self.lib.v2p_oracle_step_io(C.byref(self.model), C.byref(self.params), C.byref(self.state), _dptr(tar), _dptr(f), _dptr(t),
+                                         int(nsub), int(hold), _dptr(cf), _dptr(df), _iptr(ids), _iptr(forced), _iptr(own), _dptr(mg))
         if rc:
             raise RuntimeError("oracle substep failed (mass matrix not positive definite)")
+        if want_selection:
+            return cf, df, ids.reshape(NB, 4), own, mg
         return cf, df, ids.reshape(NB, 4)
 
     def diagnostics(self):
         out = np.zeros(8)
         self.lib.v2p_oracle_diagnostics(C.byref(self.model), C.byref(self.params), C.byref(self.state), _dptr(out))
         return {"ke": out[0], "pe": out[1], "P": out[2:5].copy(), "L": out[5:8].copy()}
+
+
+class BatchOracle:
+    """n independent humanoids stepped by one C call (OpenMP over envs).  `models` is one BodyModel or a list of them with
+    `model_of` [n] naming each env's; gains default to the models' own."""
+
+    def __init__(self, models, n, params=None, model_of=None, gains_f32=True, threads=0):
+        self.lib = lib()
+        models = list(models) if isinstance(models, (list, tuple)) else [models]
+        cast = (lambda x: x.astype(np.float32)) if gains_f32 else (lambda x: x)
+        self._m = [_omodel(bm, cast(bm.kp), cast(bm.kd)) for bm in models]
+        self._mptr = (C.POINTER(OModel) * len(models))(*[C.pointer(m) for m, _ in self._m])
+        self.model_of = None if model_of is None else np.ascontiguousarray(model_of, dtype=np.int32)
+        self.params = params or default_params()
+        self.n = int(n)
+        self.states = (OState * self.n)()
+        self.threads = int(threads)
+
+    def set_state(self, root13, dof_pos, dof_vel):
+        r = np.ascontiguousarray(root13, dtype=np.float64)
+        p = np.ascontiguousarray(dof_pos, dtype=np.float64)
+        v = np.ascontiguousarray(dof_vel, dtype=np.float64)
+        for e in range(self.n):
+            self.lib.v2p_oracle_set_state(C.byref(self.states[e]), _dptr(r[e]), _dptr(p[e]), _dptr(v[e]))
+
+    def step(self, pd_target, ext_force, ext_torque, nsub=4, hold=2, forced_ids=None, want_selection=False):
+        n = self.n
+        out = {"cf": np.zeros((n, NB, 3)), "df": np.zeros((n, 69)), "ids": np.full((n, NB, 4), -1, dtype=np.int32), "root": np.zeros((n, 13)),
+               "dpos": np.zeros((n, 69)), "dvel": np.zeros((n, 69)), "rb": np.zeros((n, NB, 13))}
+        tar = np.ascontiguousarray(pd_target, dtype=np.float64)
+        f = np.ascontiguousarray(ext_force, dtype=np.float64)
+        t = np.ascontiguousarray(ext_torque, dtype=np.float64)
+        forced = None if forced_ids is None else np.ascontiguousarray(forced_ids, dtype=np.int32).reshape(n, nsub, NB * 4)
+        if want_selection:
+            out["own"] = np.full((n, nsub, NB, 4), -1, dtype=np.int32)
+            out["margin"] = np.zeros((n, nsub, NB))
+        failed = self.lib.v2p_oracle_step_batch(self._mptr, _iptr(self.model_of), C.byref(self.params), self.states, n, _dptr(tar), _dptr(f), _dptr(t),
+                                                int(nsub), int(hold), _dptr(out["cf"]), _dptr(out["df"]), _iptr(out["ids"]), _iptr(forced),
+                                                _iptr(out.get("own")), _dptr(out.get("margin")), _dptr(out["root"]), _dptr(out["dpos"]),
+                                                _dptr(out["dvel"]), _dptr(out["rb"]), self.threads)
+        if failed:
+            raise RuntimeError("oracle step failed in %d envs (mass matrix not positive definite)" % failed)
+        return out

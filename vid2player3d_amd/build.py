@@ -31,8 +31,18 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
+def build_info():
+    """What the bench line records about the build."""
+    return {"arch": ARCH, "physics_ll_math": "precise" if os.environ.get("V2P_LL_STRICT_MATH") else "relaxed (" + " ".join(LL_MATH_FLAGS) + "; precise device libraries, strict pre-physics prologue)",
+            "hipcc": _hipcc()}
+
+
+LL_MATH_FLAGS = ["-fassociative-math", "-freciprocal-math", "-fno-signed-zeros", "-fno-trapping-math", "-fno-honor-nans"]
+
+
+def build(force=False, verbose=False, lib_out=None, tag=""):
+    """out / tag: build a variant library next to the default one (A/B experiments: tools/variants.sh)."""
+    if lib_out is None and not force and not needs_build():
         return LIB
     objs = []
     # -fno-slp-vectorize: the SLP vectoriser packs adjacent fp32 ops into v_pk_* on 64-bit register pairs, which costs the
@@ -41,18 +51,17 @@ def build(force=False, verbose=False):
              "-Wno-unused-function"]
     procs = []
     for s in SOURCES:
-        obj = os.path.join(CSRC, s.replace(".hip", ".o"))
+        obj = os.path.join(CSRC, s.replace(".hip", tag + ".o"))
         fl = list(flags)
         if s in ("motion_state.hip", "task_ops.hip"):
             # the task-side kernels restate torch elementwise code: no FMA contraction, so that ill-conditioned spots of the
             # reference itself (acos of a dot product next to 1 in slerp / angle-axis) round the way torch rounds them
             fl = [f if f != "-ffp-contract=fast" else "-ffp-contract=off" for f in fl]
         if s == "physics_ll.hip":
-            # the link-per-lane physics kernel: relaxed fp32 arithmetic (reassociation, approximate div / sqrt / sin / cos, no NaN or
-            # signed-zero bookkeeping): +3 %.  The physics model is this engine's own specification; its agreement with the float64
-            # oracle stays inside the tolerances of tests/test_gpu_physics.py (poses 2e-5, velocities 5e-4).  The task-side kernels,
-            # which restate the reference's torch arithmetic, keep strict semantics (above).
-            fl = fl + ["-ffast-math"]
+            # the link-per-lane physics kernel: relaxed fp32 arithmetic for the code of this file, precise device libraries (see the head
+            # of the file for why the flags are spelled out instead of -ffast-math); V2P_LL_STRICT_MATH=1 builds it precise (A/B, bisecting)
+            fl = [f if f != "-ffp-contract=fast" else "-ffp-contract=fast-honor-pragmas" for f in fl]
+            fl = fl + (["-DV2P_LL_STRICT_MATH"] if os.environ.get("V2P_LL_STRICT_MATH") else LL_MATH_FLAGS)
         extra = os.environ.get("V2P_FLAGS_" + s.split(".")[0].upper())  # experiments: per-file flag override, e.g. V2P_FLAGS_PHYSICS_LL="-O1"
         if extra:
             fl = [f for f in fl if f != "-O3"] + extra.split()
@@ -68,9 +77,9 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
         if verbose and out:
             print(out.decode())
-    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib_out or LIB] + objs
     subprocess.check_call(cmd)
-    return LIB
+    return lib_out or LIB
 
 
 if __name__ == "__main__":

@@ -44,6 +44,21 @@ struct DeviceGuard {
 
 using namespace v2p;
 
+namespace v2p {
+// out[N][525] + ws: only the env-per-lane cross-check schedule stages through global memory
+int ensure_env_per_lane_buffers(v2p_env* e) {
+    if (e->out && e->ws) return V2P_OK;
+    const size_t N = (size_t)e->n;
+    int rc = V2P_OK;
+    if (!e->out) rc = check_hip(hipMalloc((void**)&e->out, sizeof(float) * OUT_SLOTS * N), "hipMalloc(out)");
+    if (rc == V2P_OK && !e->ws) rc = check_hip(hipMalloc((void**)&e->ws, sizeof(float) * (size_t)physics_ws_slots() * N), "hipMalloc(ws)");
+    if (rc == V2P_OK) rc = check_hip(hipMemset(e->out, 0, sizeof(float) * OUT_SLOTS * N), "hipMemset(out)");
+    if (rc == V2P_OK) rc = check_hip(hipMemset(e->ws, 0, sizeof(float) * (size_t)physics_ws_slots() * N), "hipMemset(ws)");
+    if (rc == V2P_OK) rc = check_hip(hipDeviceSynchronize(), "hipDeviceSynchronize(env_per_lane buffers)");
+    return rc;
+}
+}  // namespace v2p
+
 extern "C" {
 
 const char* v2p_last_error(void) { return g_err; }
@@ -278,10 +293,10 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
     e->n = n;
     e->device = device;
     e->motion_id = env_motion_id;
-    {
-        const char* k = getenv("V2P_KERNEL");  // default schedule; v2p_env_set_schedule overrides it
-        e->schedule = (k && !strcmp(k, "lds")) ? 1 : 0;
-    }
+    if (c->schedule != 0 && c->schedule != 1) { set_error("v2p_env_create: schedule must be 0 or 1"); delete e; return V2P_ERR_INVALID; }
+    if (c->solver_type != 0 && c->solver_type != 1) { set_error("v2p_env_create: solver_type must be 0 (PGS) or 1 (TGS)"); delete e; return V2P_ERR_INVALID; }
+    if (c->solver_type == 1 && c->schedule == 1) { set_error("v2p_env_create: the env-per-lane cross-check kernel solves PGS only"); delete e; return V2P_ERR_UNSUPPORTED; }
+    e->schedule = c->schedule;
     EnvParams& p = e->p;
     p.h = c->sim_dt / (float)c->substeps;
     p.nsub = c->substeps * c->control_freq_inv;
@@ -294,6 +309,7 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
     p.ground_tolerance = c->ground_tolerance; p.max_episode_length = c->max_episode_length;
     p.enable_early_termination = c->enable_early_termination;
     p.freeze_terminated = c->freeze_terminated_envs;
+    p.solver_type = c->solver_type;
     p.context_length = c->context_length; p.context_padding = c->context_padding;
     p.dt = (float)c->control_freq_inv * c->sim_dt;
     memcpy(p.term_heights, c->term_heights, sizeof(p.term_heights));
@@ -306,13 +322,14 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
     size_t N = (size_t)n;
     int rc = check_hip(hipMalloc((void**)&e->state, sizeof(float) * STATE_SLOTS * N), "hipMalloc(state)");
     if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->ctrl, sizeof(float) * CTRL_SLOTS * N), "hipMalloc(ctrl)");
-    if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->out, sizeof(float) * OUT_SLOTS * N), "hipMalloc(out)");
-    if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->ws, sizeof(float) * (size_t)physics_ws_slots() * N), "hipMalloc(ws)");
     if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->contact_ids, sizeof(int32_t) * NB * 4 * N), "hipMalloc(contact_ids)");
     if (rc == V2P_OK) rc = check_hip(hipMemset(e->state, 0, sizeof(float) * STATE_SLOTS * N), "hipMemset(state)");
     if (rc == V2P_OK) rc = check_hip(hipMemset(e->ctrl, 0, sizeof(float) * CTRL_SLOTS * N), "hipMemset(ctrl)");
-    if (rc == V2P_OK) rc = check_hip(hipMemset(e->out, 0, sizeof(float) * OUT_SLOTS * N), "hipMemset(out)");
-    if (rc == V2P_OK) rc = check_hip(hipMemset(e->ws, 0, sizeof(float) * (size_t)physics_ws_slots() * N), "hipMemset(ws)");
+    if (rc == V2P_OK && e->schedule == 1) rc = ensure_env_per_lane_buffers(e);
+    if (rc == V2P_OK && c->debug_substep_contacts) {
+        rc = check_hip(hipMalloc((void**)&e->contact_ids_sub, sizeof(int32_t) * NB * 4 * N * (size_t)p.nsub), "hipMalloc(contact_ids_sub)");
+        if (rc == V2P_OK) rc = check_hip(hipMemset(e->contact_ids_sub, 0xff, sizeof(int32_t) * NB * 4 * N * (size_t)p.nsub), "hipMemset(contact_ids_sub)");
+    }
     if (rc == V2P_OK) rc = check_hip(hipMemset(e->contact_ids, 0xff, sizeof(int32_t) * NB * 4 * N), "hipMemset(contact_ids)");
     if (rc == V2P_OK && num_shapes > 1) {
         // per-env body shapes: the numeric tables of every shape + each shape's joint-diagonal augmentation, indexed by env_shape
@@ -329,7 +346,7 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
         if (rc == V2P_OK) rc = check_hip(hipMemcpy(e->env_shape_dev, env_shape_id, sizeof(int32_t) * N, hipMemcpyHostToDevice), "hipMemcpy(env_shape)");
         if (rc == V2P_OK) e->schedule = 0;  // the env-per-lane cross-check kernel is single-shape
     }
-    e->pair_period = getenv("V2P_PAIR_PERIOD") ? atoi(getenv("V2P_PAIR_PERIOD")) : 1;
+    e->pair_period = c->pair_envs_by_load ? 1 : 0;
     if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->pair_key, sizeof(int32_t) * N), "hipMalloc(pair_key)");
     if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->pair_pos, sizeof(int32_t) * N), "hipMalloc(pair_pos)");
     if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->perm, sizeof(int32_t) * N), "hipMalloc(perm)");
@@ -378,6 +395,7 @@ void v2p_env_destroy(v2p_env* e) {
     if (e->out) (void)hipFree(e->out);
     if (e->ws) (void)hipFree(e->ws);
     if (e->contact_ids) (void)hipFree(e->contact_ids);
+    if (e->contact_ids_sub) (void)hipFree(e->contact_ids_sub);
     if (e->shapes_dev) (void)hipFree(e->shapes_dev);
     if (e->shape_aug_dev) (void)hipFree(e->shape_aug_dev);
     if (e->env_shape_dev) (void)hipFree(e->env_shape_dev);
@@ -422,6 +440,7 @@ int v2p_env_pre_physics(v2p_env* e, float* actions, void* stream) {
 int v2p_env_physics(v2p_env* e, void* stream) {
     if (!e) { set_error("v2p_env_physics: bad argument"); return V2P_ERR_INVALID; }
     DeviceGuard g(e->device);
+    if (e->schedule != 0) { int rc = ensure_env_per_lane_buffers(e); if (rc != V2P_OK) return rc; }
     if (e->schedule != 0) return launch_env_physics(e, (hipStream_t)stream);
     return launch_env_physics_ll(e, (hipStream_t)stream);
 }
@@ -463,6 +482,12 @@ int v2p_env_push_state(v2p_env* e, const int64_t* env_ids, int64_t n, int with_r
 int v2p_env_set_schedule(v2p_env* e, int schedule) {
     if (!e || (schedule != 0 && schedule != 1)) { set_error("v2p_env_set_schedule: bad argument"); return V2P_ERR_INVALID; }
     if (schedule == 1 && e->num_shapes > 1) { set_error("v2p_env_set_schedule: the env-per-lane kernel handles single-shape batches only"); return V2P_ERR_UNSUPPORTED; }
+    if (schedule == 1 && e->p.solver_type == 1) { set_error("v2p_env_set_schedule: the env-per-lane cross-check kernel solves PGS only"); return V2P_ERR_UNSUPPORTED; }
+    if (schedule == 1) {
+        DeviceGuard g(e->device);
+        int rc = ensure_env_per_lane_buffers(e);
+        if (rc != V2P_OK) return rc;
+    }
     e->schedule = schedule;
     return V2P_OK;
 }
@@ -474,6 +499,14 @@ int v2p_env_debug_contacts(v2p_env* e, int32_t* out, void* stream) {
     DeviceGuard g(e->device);
     return check_hip(hipMemcpyAsync(out, e->contact_ids, sizeof(int32_t) * NB * 4 * (size_t)e->n, hipMemcpyDeviceToDevice, (hipStream_t)stream),
                      "hipMemcpyAsync(contact_ids)");
+}
+
+int v2p_env_debug_contacts_substeps(v2p_env* e, int32_t* out, void* stream) {
+    if (!e || !out) { set_error("v2p_env_debug_contacts_substeps: bad argument"); return V2P_ERR_INVALID; }
+    if (!e->contact_ids_sub) { set_error("v2p_env_debug_contacts_substeps: the batch was created without v2p_sim_cfg.debug_substep_contacts"); return V2P_ERR_INVALID; }
+    DeviceGuard g(e->device);
+    return check_hip(hipMemcpyAsync(out, e->contact_ids_sub, sizeof(int32_t) * NB * 4 * (size_t)e->n * (size_t)e->p.nsub, hipMemcpyDeviceToDevice, (hipStream_t)stream),
+                     "hipMemcpyAsync(contact_ids_sub)");
 }
 
 int v2p_env_debug_pairing(v2p_env* e, int32_t* perm, int32_t* key, void* stream) {

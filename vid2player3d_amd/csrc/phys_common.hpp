@@ -24,6 +24,7 @@ struct PhysArgs {
     float* __restrict__ out;
     float* __restrict__ ws;
     int32_t* __restrict__ contact_ids;
+    int32_t* __restrict__ contact_ids_sub;  // [N,nsub,24,4] or NULL
     // the caller's row-major tensors (link-per-lane kernel writes them directly: lane = body gives contiguous rows)
     float* __restrict__ x_root;     // [N,13]
     float* __restrict__ x_dof;      // [N,69,2]

@@ -20,7 +20,7 @@ __device__ __forceinline__ Sym3 inv(const Sym3& a) {
     float c01 = a.xz * a.yz - a.xy * a.zz;
     float c02 = a.xy * a.yz - a.xz * a.yy;
     float det = a.xx * c00 + a.xy * c01 + a.xz * c02;
-    float id = 1.f / det;
+    float id = PHYS_RCP(det);
     Sym3 r;
     r.xx = c00 * id; r.xy = c01 * id; r.xz = c02 * id;
     r.yy = (a.xx * a.zz - a.xz * a.xz) * id;

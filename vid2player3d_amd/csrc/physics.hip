@@ -449,11 +449,15 @@ __global__ __launch_bounds__(L) void physics_kernel(PhysArgs a) {
                         G(b, GCB + c) = d >= 0.f ? d / h : fmaxf(P.erp * d / h, -P.max_depen);
                         G(b, GCL + 3 * c) = 0.f; G(b, GCL + 3 * c + 1) = 0.f; G(b, GCL + 3 * c + 2) = 0.f;
                         a.contact_ids[(e * NB + b) * 4 + c] = c < cnt ? b * 64 + sel[c] : -1;
+                        if (a.contact_ids_sub) a.contact_ids_sub[((e * P.nsub + sub) * NB + b) * 4 + c] = c < cnt ? b * 64 + sel[c] : -1;
                     }
                     if (__any(cnt > 0)) touch |= 1u << b;
                 } else {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) a.contact_ids[(e * NB + b) * 4 + c] = -1;
+                    for (int c = 0; c < 4; ++c) {
+                        a.contact_ids[(e * NB + b) * 4 + c] = -1;
+                        if (a.contact_ids_sub) a.contact_ids_sub[((e * P.nsub + sub) * NB + b) * 4 + c] = -1;
+                    }
                 }
                 G(b, GCN) = (float)cnt;
             }
@@ -774,6 +778,7 @@ int launch_env_physics(v2p_env* env, hipStream_t s) {
     a.out = env->out;
     a.ws = env->ws;
     a.contact_ids = env->contact_ids;
+    a.contact_ids_sub = env->contact_ids_sub;
     a.prof = env->prof;
     a.par_pack[0] = a.par_pack[1] = a.ord_pack[0] = a.ord_pack[1] = 0ull;
     for (int i = 0; i < NB; ++i) {

@@ -20,13 +20,44 @@
 //
 // The sequential semantics of the Gauss-Seidel sweep (bodies ascending, points in slot order, rows
 // n, t1, t2) are unchanged, so results agree with the one-env-per-lane kernel to rounding.
+#include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
+// This translation unit is compiled with -fassociative-math -freciprocal-math -fno-signed-zeros -fno-trapping-math -fno-honor-nans
+// (build.py) and NOT with -ffast-math: reassociation and NaN-free selects for the code of this file, but the device libraries it
+// links and the way the HIP headers map sinf / cosf / atan2f stay the precise ones (-ffast-math, or the full set of its component
+// flags, turns them into the hardware approximations for the whole file, which no pragma undoes; the helpers that restate the
+// reference in the pre-physics prologue must round like task_ops.hip).  The physics model is this engine's own specification and
+// is checked against the float64 oracle at fixed tolerances; its transcendental / division shortcuts are written out below
+// (hardware sin, cos, sqrt, rcp).  V2P_LL_STRICT_MATH builds everything precise.
+#if !defined(V2P_LL_STRICT_MATH)
+#define PHYS_SINCOS(x, s, c) do { (s) = __sinf(x); (c) = __cosf(x); } while (0)
+#define PHYS_SQRT(x) __builtin_amdgcn_sqrtf(x)
+#define PHYS_RCP(x) __builtin_amdgcn_rcpf(x)
+#endif
 #include "phys_common.hpp"
 
 namespace v2p {
+
+// Pre-physics (humanoid_smpl_im.py:125-157, 391-396) restates the reference's torch arithmetic: PD-target clamp, residual root wrench
+// rotated into the heading frame.  ONE implementation, compiled here with precise semantics and without contraction (the pragma
+// below; this file is built -ffp-contract=fast-honor-pragmas), serves both the stand-alone env_pre_kernel and the prologue of the
+// physics kernel, so the fused step equals the staged step bit for bit (tests).
+namespace strict {
+#pragma clang fp reassociate(off) reciprocal(off) contract(off)
+#include "v2p_math.inc"
+__device__ __forceinline__ float pd_clamp(float act, float q, float lim) { return fmaxf(fminf(act, q + lim), q - lim); }
+// root_rot: rigid-body rotation of the root (xyzw); a3: the three action components of the force (or torque) part
+__device__ __forceinline__ V3 residual_wrench(const float* root_rot, float a0, float a1, float a2, float scale) {
+    const Q4 hq = ref_heading_quat(ref_calc_heading(ref_remove_base_rot(Q4{root_rot[0], root_rot[1], root_rot[2], root_rot[3]})));
+    return ref_quat_rotate(hq, V3{a0 * scale, a1 * scale, a2 * scale});
+}
+}  // namespace strict
+#if !defined(V2P_LL_STRICT_MATH)
+#pragma clang fp reassociate(on) reciprocal(on) contract(fast)  // (a file-scope fp pragma stays in force past the namespace: switch back)
+#endif
 
 constexpr int LPE = 32;  // lanes per environment
 
@@ -115,7 +146,9 @@ __device__ __forceinline__ void grp_argmax(float& v, int& k) {
 #endif
 constexpr int LL_WPB = V2P_LL_WPB;
 constexpr int PARK_TAR = 0, PARK_W0 = 3, PARK_XD0 = 6, PARK_Q = 9, PARK_X = 13, PARK_SLOTS = 16;  // LDS parking slots (dwords per lane)
-template <bool CONTACT, bool MULTI>
+// TGS: temporal Gauss-Seidel with frozen Jacobians (v2p_sim_cfg.solver_type 1; the model is stated in oracle/phys/v2p_phys_oracle.c):
+// cbias[] then holds the GAP of each point, advanced after every sweep, and the row bias is evaluated where it is used.
+template <bool CONTACT, bool MULTI, bool TGS>
 __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(PhysArgs a) {
     const int64_t N = a.n;
     const int lane = threadIdx.x & 63;
@@ -182,31 +215,32 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
         if (!a.actions) tar = V3{a.ctrl[CIDX(cb + 0)], a.ctrl[CIDX(cb + 1)], a.ctrl[CIDX(cb + 2)]};
     }
     if (a.actions && valid && live_env) {
-        // ---- pre-physics fused in (humanoid_smpl_im.py:125-157, 391-396; same arithmetic as env_pre_kernel): lane b owns the three
-        // action components of its joint, the root lane the residual wrench; dead envs are masked in place on the caller's tensor
+        // ---- pre-physics fused in (same functions, same rounding as env_pre_kernel below): lane b owns the three action components of
+        // its joint, the root lane the residual wrench; dead envs are masked in place on the caller's tensor
         const bool dead = a.reset[e] == 1;
         if (b != 0) {
             float* ap = a.actions + e * NACT + 3 * (b - 1);
-            V3 act{ap[0], ap[1], ap[2]};
-            if (dead) { act = V3{0.f, 0.f, 0.f}; ap[0] = 0.f; ap[1] = 0.f; ap[2] = 0.f; }
+            float ax = ap[0], ay = ap[1], az = ap[2];
+            if (dead) { ax = ay = az = 0.f; ap[0] = 0.f; ap[1] = 0.f; ap[2] = 0.f; }
             const float* qd = a.x_dof + (e * NDOF + 3 * (b - 1)) * 2;
             const float lim = P.pd_tar_lim;
-            tar = V3{fmaxf(fminf(act.x, qd[0] + lim), qd[0] - lim), fmaxf(fminf(act.y, qd[2] + lim), qd[2] - lim), fmaxf(fminf(act.z, qd[4] + lim), qd[4] - lim)};
+            tar = V3{strict::pd_clamp(ax, qd[0], lim), strict::pd_clamp(ay, qd[2], lim), strict::pd_clamp(az, qd[4], lim)};
             float* pt = a.pd_target + e * NDOF + 3 * (b - 1);
             pt[0] = tar.x; pt[1] = tar.y; pt[2] = tar.z;
             const int cb = CT_PD + 3 * (b - 1);
             a.ctrl[CIDX(cb + 0)] = tar.x; a.ctrl[CIDX(cb + 1)] = tar.y; a.ctrl[CIDX(cb + 2)] = tar.z;
         } else {
             float* ap = a.actions + e * NACT + NDOF;
-            V3 af{ap[0], ap[1], ap[2]}, at{ap[3], ap[4], ap[5]};
-            if (dead) {
-                af = at = V3{0.f, 0.f, 0.f};
+            float af[6];
 #pragma unroll
-                for (int k = 0; k < 6; ++k) ap[k] = 0.f;
+            for (int k = 0; k < 6; ++k) af[k] = ap[k];
+            if (dead) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { af[k] = 0.f; ap[k] = 0.f; }
             }
             const float* rq4 = a.x_rb + e * NB * 13 + 3;
-            const Q4 hq = ref_heading_quat(ref_calc_heading(ref_remove_base_rot(Q4{rq4[0], rq4[1], rq4[2], rq4[3]})));
-            const V3 F = ref_quat_rotate(hq, P.res_force_scale * af), Tq = ref_quat_rotate(hq, P.res_torque_scale * at);
+            const strict::V3 F = strict::residual_wrench(rq4, af[0], af[1], af[2], P.res_force_scale);
+            const strict::V3 Tq = strict::residual_wrench(rq4, af[3], af[4], af[5], P.res_torque_scale);
             a.ctrl[CIDX(CT_FORCE + 0)] = F.x; a.ctrl[CIDX(CT_FORCE + 1)] = F.y; a.ctrl[CIDX(CT_FORCE + 2)] = F.z;
             a.ctrl[CIDX(CT_TORQUE + 0)] = Tq.x; a.ctrl[CIDX(CT_TORQUE + 1)] = Tq.y; a.ctrl[CIDX(CT_TORQUE + 2)] = Tq.z;
         }
@@ -575,12 +609,16 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                     const float4 uu = hullv(v0 + (sel4[c] < 0 ? 0 : sel4[c]));
                     cr[c] = mul(R, V3{uu.x, uu.y, uu.z});
                     float dz = x.z + cr[c].z;
-                    cbias[c] = dz >= 0.f ? dz * ih : fmaxf(P.erp * dz * ih, -P.max_depen);
+                    cbias[c] = TGS ? dz : (dz >= 0.f ? dz * ih : fmaxf(P.erp * dz * ih, -P.max_depen));
                 }
             }
             if (last && valid && live_env && !frozen) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) a.contact_ids[(e * NB + b) * 4 + c] = c < cnt ? b * 64 + sel4[c] : -1;
+            }
+            if (a.contact_ids_sub && valid && live_env && !frozen) {  // diagnostics: the ids of every substep (parity tests)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) a.contact_ids_sub[((e * nsub + sub) * NB + b) * 4 + c] = c < cnt ? b * 64 + sel4[c] : -1;
             }
 
             LLSUB(18);
@@ -686,9 +724,19 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                     }
                 }
                 // ======================================================== block Gauss-Seidel: k-th touched body of each env at once
+                const float hs = h / (float)P.n_iter;  // TGS: length of a time slice
+                float tgs_irem = 1.f / h;                // TGS: 1 / (time left in the substep) for separated points
+                const float tgs_pen = P.erp / hs;
+                auto rowbias = [&](float v) -> float { return TGS ? (v >= 0.f ? v * tgs_irem : fmaxf(tgs_pen * v, -P.max_depen)) : v; };
                 for (int it = 0; it < P.n_iter; ++it) {
                     unsigned t0 = m0, t1 = m1;
                     bool moved = false;
+                    if (TGS && it > 0) {
+                        // gaps advance with the normal velocity the points have after the previous sweep (touched links are current)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) cbias[c] += hs * (cr[c].y * w.x - cr[c].x * w.y + xd.z);
+                        tgs_irem = 1.f / (h - (float)it * hs);
+                    }
                     while (t0 | t1) {
                         // ---- one GROUP per env: a touched link and, while the next touched link (ascending order) is a child of the
                         // one just solved, that child too.  Inside a group a link sees its parent's impulses through the parent's own
@@ -725,7 +773,8 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                                     // a point without normal impulse (hence without friction impulses: they are clamped to mu x normal)
                                     // that is separating stays as it is: its three rows would change nothing
                                     // (masked per lane as well, so that an env's numbers do not depend on what its wave partner does)
-                                    const bool act = active && !(ln == 0.f && rr.y * wl.x - rr.x * wl.y + xl.z + cbias[c] >= 0.f);
+                                    const float bias_c = rowbias(cbias[c]);
+                                    const bool act = active && !(ln == 0.f && rr.y * wl.x - rr.x * wl.y + xl.z + bias_c >= 0.f);
                                     if (!__any(act)) continue;
 #pragma unroll
                                     for (int ax = 0; ax < 3; ++ax) {
@@ -734,7 +783,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                                         V3 yw = mul(Lam.A, jn) + mul(Lam.B, dir);
                                         V3 yv = V3{dot(col(Lam.B, 0), jn), dot(col(Lam.B, 1), jn), dot(col(Lam.B, 2), jn)} + mul(Lam.C, dir);
                                         float wii = dot(jn, yw) + dot(dir, yv);
-                                        float rel = dot(jn, wl) + dot(dir, xl) + (ax == 0 ? cbias[c] : 0.f);
+                                        float rel = dot(jn, wl) + dot(dir, xl) + (ax == 0 ? bias_c : 0.f);
                                         float old = ax == 0 ? ln : (ax == 1 ? l1 : l2);
                                         float nl = old - rel * __builtin_amdgcn_rcpf(wii);
                                         if (ax == 0) nl = fmaxf(nl, 0.f);
@@ -814,7 +863,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                         }
                         LLSUB(14);
                     }
-                    if (!moved) break;  // a whole iteration without any change: the remaining ones would repeat it
+                    if (!TGS && !moved) break;  // a whole iteration without any change: the remaining ones would repeat it (PGS: fixed biases)
                 }
                 // links below the deepest touched one: one catch-up pass with the accumulated motion of their parents
                 V3 accw = w - park_get3(PARK_W0), accv = xd - park_get3(PARK_XD0);
@@ -989,6 +1038,49 @@ __global__ void pair_scatter_kernel(PairView pv, int64_t n) {
     if (e < n) pair_scatter(pv, e);
 }
 
+// ---- stand-alone pre-physics (the staged API, v2p_env_pre_physics): one thread per action component; also hosts the scatter of
+// the pairing order for the next physics launch
+__global__ void env_pre_kernel(PhysArgs a, PairView pv) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t e = tid / NACT;
+    const int c = (int)(tid - e * NACT);
+    if (e >= a.n) return;
+    if (c == 0 && pv.perm) pair_scatter(pv, e);
+    const bool dead = a.reset[e] == 1;
+    float act = a.actions[tid];
+    if (dead) { act = 0.f; a.actions[tid] = 0.f; }  // in place on the caller's tensor, like the reference
+    if (c < NDOF) {
+        const float tar = strict::pd_clamp(act, a.x_dof[(e * NDOF + c) * 2], a.p.pd_tar_lim);
+        a.pd_target[e * NDOF + c] = tar;
+        a.ctrl[CIDX(CT_PD + c)] = tar;
+    } else if (c == NDOF || c == NDOF + 3) {
+        const float a1 = dead ? 0.f : a.actions[tid + 1], a2 = dead ? 0.f : a.actions[tid + 2];
+        const strict::V3 w = strict::residual_wrench(a.x_rb + e * NB * 13 + 3, act, a1, a2, c == NDOF ? a.p.res_force_scale : a.p.res_torque_scale);
+        const int base = c == NDOF ? CT_FORCE : CT_TORQUE;
+        a.ctrl[CIDX(base + 0)] = w.x; a.ctrl[CIDX(base + 1)] = w.y; a.ctrl[CIDX(base + 2)] = w.z;
+    }
+}
+
+int launch_env_pre(v2p_env* env, float* actions, hipStream_t s) {
+    PhysArgs a = {};
+    a.ctrl = env->ctrl;
+    a.actions = actions;
+    a.reset = env->buf.reset;
+    a.pd_target = env->buf.pd_target;
+    a.x_dof = env->buf.dof_state;
+    a.x_rb = env->buf.rb_state;
+    a.n = env->n;
+    a.p = env->p;
+    PairView pv{nullptr, nullptr, nullptr, nullptr};
+    if (env_pairing_on(env) && env->pair_have) {  // the wave order of the next physics launch, from the keys the last one left
+        pv = env_pair_view(env);
+        env->pair_have = 0;
+    }
+    const int64_t threads = env->n * NACT;
+    hipLaunchKernelGGL(env_pre_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a, pv);
+    return check_hip(hipGetLastError(), "env_pre_kernel");
+}
+
 bool env_pairing_on(const v2p_env* env) { return env->pair_period > 0 && env->schedule == 0 && env->p.enable_contact && env->n > 2; }
 
 PairView env_pair_view(const v2p_env* env) { return PairView{env->pair_key, env->pair_pos, env->pair_start, env->perm}; }
@@ -1026,6 +1118,7 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s, float* actions) {
     a.out = env->out;
     a.ws = env->ws;
     a.contact_ids = env->contact_ids;
+    a.contact_ids_sub = env->contact_ids_sub;
     a.x_root = env->buf.root_states;
     a.x_dof = env->buf.dof_state;
     a.x_rb = env->buf.rb_state;
@@ -1042,12 +1135,16 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s, float* actions) {
     const bool multi = env->num_shapes > 1;  // per-env shapes: hull vertices come from the shape tables instead of the LDS copy
     const dim3 grid(blocks), block(64 * LL_WPB);
     const size_t lds = sizeof(float) * PARK_SLOTS * 64 * LL_WPB;
-    if (env->p.enable_contact) {
-        if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true>), grid, block, lds, s, a);
-        else hipLaunchKernelGGL((physics_ll_kernel<true, false>), grid, block, lds, s, a);
+    const bool tgs = env->p.solver_type == 1;
+    if (env->p.enable_contact && tgs) {
+        if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, true>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((physics_ll_kernel<true, false, true>), grid, block, lds, s, a);
+    } else if (env->p.enable_contact) {
+        if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, false>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((physics_ll_kernel<true, false, false>), grid, block, lds, s, a);
     } else {
-        if (multi) hipLaunchKernelGGL((physics_ll_kernel<false, true>), grid, block, lds, s, a);
-        else hipLaunchKernelGGL((physics_ll_kernel<false, false>), grid, block, lds, s, a);
+        if (multi) hipLaunchKernelGGL((physics_ll_kernel<false, true, false>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((physics_ll_kernel<false, false, false>), grid, block, lds, s, a);
     }
     env->pair_have = paired ? 1 : 0;
     return check_hip(hipGetLastError(), "physics_ll_kernel");

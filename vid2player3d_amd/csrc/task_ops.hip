@@ -352,44 +352,8 @@ int launch_env_reset(v2p_env* env, const int64_t* env_ids, int64_t n, const floa
     return rc;
 }
 
-// ---- pre-physics (humanoid_smpl_im.py:125-157, 391-396): one thread per action component
-__global__ void env_pre_kernel(EnvView v, float* __restrict__ actions) {
-    int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t e = tid / NACT;
-    int a = (int)(tid - e * NACT);
-    if (e >= v.n) return;
-    if (a == 0 && v.pair.perm) pair_scatter(v.pair, e);
-    bool dead = v.b.reset[e] == 1;
-    float act = actions[tid];
-    if (dead) { act = 0.f; actions[tid] = 0.f; }  // in place on the caller's tensor, like the reference
-    if (a < NDOF) {
-        float q = v.b.dof_state[(e * NDOF + a) * 2];
-        float tar = fmaxf(fminf(act, q + v.p.pd_tar_lim), q - v.p.pd_tar_lim);
-        v.b.pd_target[e * NDOF + a] = tar;
-        v.ctrl[CIDX(CT_PD + a)] = tar;
-    } else if (a == NDOF || a == NDOF + 3) {
-        // residual root wrench, rotated into the heading frame of the root body
-        float a1 = dead ? 0.f : actions[tid + 1], a2 = dead ? 0.f : actions[tid + 2];
-        float sc = a == NDOF ? v.p.res_force_scale : v.p.res_torque_scale;
-        Q4 rq = ref_remove_base_rot(ld4(v.b.rb_state + e * NB * 13 + 3));
-        Q4 hq = ref_heading_quat(ref_calc_heading(rq));
-        V3 w = ref_quat_rotate(hq, V3{act * sc, a1 * sc, a2 * sc});
-        int base = a == NDOF ? CT_FORCE : CT_TORQUE;
-        v.ctrl[CIDX(base + 0)] = w.x; v.ctrl[CIDX(base + 1)] = w.y; v.ctrl[CIDX(base + 2)] = w.z;
-    }
-}
-
-int launch_env_pre(v2p_env* env, float* actions, hipStream_t s) {
-    EnvView v = make_view(env);
-    if (env_pairing_on(env) && env->pair_have) {  // the wave order of the next physics launch, from the keys the last one left
-        v.pair = env_pair_view(env);
-        env->pair_have = 0;
-    }
-    int64_t threads = env->n * NACT;
-    unsigned blocks = (unsigned)((threads + 255) / 256);
-    hipLaunchKernelGGL(env_pre_kernel, dim3(blocks), dim3(256), 0, s, v, actions);
-    return check_hip(hipGetLastError(), "env_pre_kernel");
-}
+// (pre-physics, humanoid_smpl_im.py:125-157, lives in physics_ll.hip: one implementation, compiled once with precise semantics,
+// serves both the stand-alone env_pre_kernel and the prologue of the physics kernel)
 
 // ---- export: physics outputs (structure-of-arrays) -> the row-major tensors the reference exposes
 //      (the six gym.refresh_*_tensor calls, humanoid_smpl_im.py:452-468)

@@ -91,6 +91,7 @@ struct EnvParams {
     float pd_tar_lim, res_force_scale, res_torque_scale, ground_tolerance, max_episode_length;
     int enable_early_termination;
     int freeze_terminated;  // envs whose reset flag is set are not simulated (their state stays as it is)
+    int solver_type;        // 0 PGS, 1 TGS (frozen Jacobians)
     int context_length, context_padding;
     float dt;              // control step
     float term_heights[NB];
@@ -120,6 +121,7 @@ struct v2p_env {
     float* out;               // [N][OUT_SLOTS]: physics outputs before export
     float* ws;                // SoA [WS_SLOTS][N] physics workspace
     int32_t* contact_ids;     // [N,24,4] debug
+    int32_t* contact_ids_sub; // [N,nsub,24,4] debug, every substep (v2p_sim_cfg.debug_substep_contacts), else NULL
     long long* prof;          // [8] phase cycle counters when V2P_PHASE_TIMING is set (device), else NULL
     long long* wave_times;    // [waves][4] per-wave wall-clock stamps of the last launch when V2P_WAVE_TIMES=<file> is set
     // pairing (physics_ll.hip): envs are handed to waves in descending order of their contact load
@@ -129,7 +131,7 @@ struct v2p_env {
     int32_t* pair_start;
     int32_t* pair_done;
     int32_t* perm;            // [N] wave slot -> env for the next physics launch
-    int pair_period;          // 0 = pairing off (V2P_PAIR_PERIOD=0), else on
+    int pair_period;          // 0 = pairing off (v2p_sim_cfg.pair_envs_by_load = 0), else on
     int pair_have;            // the last physics launch left (key, pos, start) that have not been scattered into perm yet
 };
 
@@ -176,6 +178,7 @@ struct PairView;
 PairView env_pair_view(const v2p_env* e);
 int launch_env_pairing(v2p_env* e, hipStream_t s);  // scatter (key, pos, start) -> perm when env_pre_kernel has not done it
 int launch_env_export(v2p_env* e, hipStream_t s);
+int ensure_env_per_lane_buffers(v2p_env* e);  // the env-per-lane schedule's global workspace, allocated on first use
 int launch_env_post(v2p_env* e, hipStream_t s);
 int launch_env_push_state(v2p_env* e, const int64_t* env_ids, int64_t n, int with_rb, hipStream_t s);
 int physics_ws_slots();

@@ -331,6 +331,12 @@ class HumanoidSMPLIM:
         c.num_solver_iterations = sp.physx.num_position_iterations
         c.enable_contact = int(env.get("enable_contact", True))
         c.freeze_terminated_envs = int(env.get("freeze_terminated_envs", False))  # not the reference's behaviour: see v2p_rollout.h
+        c.schedule = {"link_per_lane": 0, "env_per_lane": 1}[env.get("kernel_schedule", "link_per_lane")]
+        c.pair_envs_by_load = int(env.get("pair_envs_by_load", True))
+        # contact solver of the engine's own physics model: "pgs" (default) or "tgs" (sim.physx.solver_type 1 of amass_im.yaml:41 names
+        # PhysX's TGS; the engine's TGS restates the published algorithm with frozen Jacobians, see oracle/phys/v2p_phys_oracle.c)
+        c.solver_type = {"pgs": 0, "tgs": 1}[env.get("contact_solver", "pgs")]
+        c.debug_substep_contacts = int(env.get("debug_substep_contacts", False))
         hold = env.get("residual_force_hold", "first_sim")
         c.residual_hold_sims = 1 if hold == "first_sim" else self.control_freq_inv
         c.gravity_z = sp.gravity[2]
@@ -526,6 +532,13 @@ class HumanoidSMPLIM:
     def debug_contacts(self):
         out = torch.empty((self.num_envs, self.num_bodies, 4), dtype=torch.int32, device=self.device)
         _lib.check(self._lib.v2p_env_debug_contacts(self._h_env, _lib.ptr(out), self._stream()), "v2p_env_debug_contacts")
+        return out
+
+    def debug_contacts_substeps(self):
+        """[N, substeps of a control step, 24, 4] contact vertex ids of every substep of the last step (cfg env debug_substep_contacts)."""
+        nsub = self.sim_params.substeps * self.control_freq_inv
+        out = torch.empty((self.num_envs, nsub, self.num_bodies, 4), dtype=torch.int32, device=self.device)
+        _lib.check(self._lib.v2p_env_debug_contacts_substeps(self._h_env, _lib.ptr(out), self._stream()), "v2p_env_debug_contacts_substeps")
         return out
 
     def debug_pairing(self):
