@@ -1,27 +1,34 @@
 #!/usr/bin/env python
 """bench.py -- env-steps/s of the imitation rollout hot path on N MI355X GPUs of one node.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--num-envs E] [--no-contact]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--num-envs E] [--no-contact] ...
 
-Workload (BASELINE.json configs[2], the one the metric is quoted on): amass_im, num_envs=8192 per
-GPU, full contact PGS + imitation reward, 64 seeded synthetic clips, one body shape,
-random residual-policy actions a ~ N(target_dof_pos (+) 0, 0.17^2).  A "step" is one VecTask
-`step()` of ALL envs of a rank (pre-physics + 4 physics substeps + export + post: new target, obs,
-reward, reset); every `horizon`=32 steps the per-epoch `reset()` of all envs (RSI + target + 48-frame
-context window) runs INSIDE the timed region, as in the reference's play_steps.  Policy inference is
-excluded.  Envs shard across ranks with no data-path collective ("scaling": "weak").
+With --gpus N > 1 and no torch.distributed environment the script launches itself as N ranks (python -m torch.distributed.run
+--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...), one rank per GPU over RCCL; started under an external torchrun it
+just takes its rank from the environment.
+
+Workload (BASELINE.json configs[2], the one the metric is quoted on): amass_im, num_envs=8192 per GPU, full contact PGS +
+imitation reward, 64 seeded synthetic clips, one body shape, random residual-policy actions
+a ~ N(target_dof_pos (+) 0, 0.17^2).  A "step" is one VecTask `step()` of ALL envs of a rank (pre-physics + 4 physics substeps +
+post: new target, obs, reward, reset); every `horizon`=32 steps the per-epoch `reset()` of all envs (RSI + target + 48-frame
+context window) runs INSIDE the timed region, as in the reference's play_steps.  Policy inference is excluded.  Envs shard across
+ranks with no data-path collective ("scaling": "weak").
 
 One JSON line on rank 0, with
-  roofline      dominant kernel = physics_ll_kernel: algorithmic HBM bytes of one step (SURVEY.md 8d:
-                9,896 B per env-step x envs per launch) / its mean duration measured here with HIP
-                events on the launch stream; peak = 8 TB/s.
-  cpu_baseline  the oracle (C physics restatement + numpy task ops) timed on this host's cores on a
-                bounded sample of the same workload (rank 0, N=1 only).
+  roofline      dominant kernel = physics_ll_kernel.  kernel_ms = its mean duration over the TIMED steps themselves, from HIP
+                events the engine records around every launch on the launch stream (v2p_env_profile_begin/_end).  achieved =
+                algorithmic HBM bytes of one step (9,896 B per env-step x envs per launch) / kernel_ms against
+                8 TB/s.  The kernel is VALU-issue bound, not HBM bound, so the line also carries valu_frac = fp32 FLOP/s of the
+                kernel / 157.3 TFLOP/s (vector peak), with the FLOPs per launch taken from the committed SQ counter profile
+                (labelled "from_profiles"); `traffic` (HBM bytes per launch, PMC) is "from_profiles" as well.
+  cpu_baseline  the oracle timed on this host's cores on a bounded sample of the same workload (rank 0, N=1 only): the C float64
+                physics restatement stepped as ONE batched OpenMP call per control step + the numpy task ops; kind "port".
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,14 +41,43 @@ sys.path.insert(0, REPO)
 ALGO_BYTES_PER_ENV_STEP = 9896          # SURVEY.md 8(d) per-step total (config 3)
 ALGO_BYTES_PER_ENV_STEP_AMORTISED = 16090  # + per-epoch reset/context / 32
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: 8 TB/s spec
+FP32_VECTOR_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md
 HORIZON = 32
 
 
-def build_task(num_envs, device_id, seed, contact=True, per_clip_shapes=False, djokovic=False, freeze=False):
+# ---------------------------------------------------------------------------------------------- launching the ranks
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def rank_command(gpus, argv, port=None):
+    """The command line that runs this script as `gpus` ranks of one node (the driver's own launch line)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port or free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(gpus, argv, stub):
+    """--gpus N without a torch.distributed environment: become the launcher of N ranks; their rank 0 prints the JSON line."""
+    if not stub:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < gpus:
+            raise SystemExit("--gpus %d: only %d GPU(s) visible on this node" % (gpus, have))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL between the ranks
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(rank_command(gpus, argv), env=env)
+
+
+# ---------------------------------------------------------------------------------------------- the workload
+def build_task(num_envs, device_id, seed, contact=True, per_clip_shapes=False, djokovic=False, freeze=False, solver="pgs"):
     from vid2player3d_amd.tasks import HumanoidSMPLIM, default_cfg
 
     cfg = default_cfg(num_envs, synthetic_motions={"seed": 7, "num_clips": 64, "min_frames": 90, "max_frames": 300},
-                      enable_contact=contact)
+                      enable_contact=contact, contact_solver=solver)
     if freeze:  # NOT the reference's behaviour (it keeps simulating terminated envs as ragdolls): reported separately, never as `value` of the default run
         cfg["env"]["freeze_terminated_envs"] = True
     if djokovic:  # BASELINE config 4 = cfg/djokovic_im.yaml: same task class, head termination height -0.5, faster (tennis-like) clips
@@ -54,6 +90,31 @@ def build_task(num_envs, device_id, seed, contact=True, per_clip_shapes=False, d
         cfg["env"]["body_model"] = [base.scaled(0.85 + 0.3 * k / 63.0) for k in range(64)]
     torch.manual_seed(seed)
     return HumanoidSMPLIM(cfg, device_type="cuda", device_id=device_id)
+
+
+class StubTask:
+    """Stand-in for the task when the LAUNCH logic of this script is tested without GPUs (tests/test_bench_launch.py): a few torch
+    ops on the CPU per step, the same surface bench.py drives.  It simulates nothing and is never part of a measured number."""
+
+    def __init__(self, num_envs):
+        self.num_envs, self.device = num_envs, "cpu"
+        self._target_dof_pos = torch.zeros((num_envs, 331))[:, 7:76]
+        self.reset_buf = torch.zeros(num_envs, dtype=torch.long)
+        self._x = torch.zeros(num_envs, 75)
+        self._launches = 0
+
+    def reset(self):
+        self.reset_buf.zero_()
+
+    def step_fused(self, a):
+        self._x = 0.5 * self._x + a
+        self._launches += 1
+
+    def profile_begin(self, n):
+        self._launches = 0
+
+    def profile_end(self):
+        return 0.001 * self._launches, self._launches
 
 
 _ACT_MASK = {}
@@ -70,48 +131,75 @@ def make_actions(task, noise):
     return torch.addcmul(noise, tgt75, _ACT_MASK[dev])
 
 
-def cpu_baseline(num_envs_sample=None, max_steps=100000, budget_s=12.0):
-    """Oracle on the host cores: C physics (one env per thread-pool task) + numpy task ops."""
-    from concurrent.futures import ThreadPoolExecutor
-
+def cpu_baseline(budget_s=12.0, max_steps=HORIZON, sigma=0.17):
+    """The oracle on the host cores, same workload (contacts on, sigma-noise actions around the target pose): per control step ONE
+    batched C call for the physics of all sample envs (OpenMP over envs, float64 dense restatement) and the numpy task ops
+    (single-threaded restatement of the reference's torch ops), timed separately."""
     from oracle import task_oracle as O
-    from oracle.phys_oracle import PhysOracle, default_params
+    from oracle.phys_oracle import BatchOracle, default_params, lib
     from vid2player3d_amd import motion_tables, synth
     from vid2player3d_amd.model import load_baked_model
 
     cores = os.cpu_count() or 1
+    threads = min(cores, lib().v2p_oracle_max_threads())
     bm = load_baked_model()
     clips = synth.make_clips(7, 8, 90, 300)
     tabs = motion_tables.build_tables(clips, bm.parents, bm.local_pos)
     rng = np.random.default_rng(7)
-    n = num_envs_sample or max(64, 4 * cores)
+    n = max(64, 4 * threads)
     ids = np.arange(n) % 8
     task = O.TaskOracle(tabs, ids, bm.kp.astype(np.float32))
     task.reset_all(rng.uniform(0.1, 1.0, size=n).astype(np.float32))
-    oracles = [PhysOracle(bm, default_params()) for _ in range(n)]
-    for e in range(n):
-        oracles[e].set_state(task.root_states[e], task.dof_pos[e], task.dof_vel[e])
-
-    def one(e, pd, f, t):
-        oracles[e].step(pd_target=pd, ext_force=f, ext_torque=t, nsub=4, hold=2)
-        return oracles[e].get_state()
-
-    pool = ThreadPoolExecutor(max_workers=cores)
-    t0 = time.perf_counter()
+    oracle = BatchOracle(bm, n, default_params(), threads=threads)
+    oracle.set_state(task.root_states, task.dof_pos, task.dof_vel)
+    t_phys = t_task = 0.0
     steps = 0
+    t0 = time.perf_counter()
     while steps < max_steps and time.perf_counter() - t0 < budget_s:
         steps += 1
-        act = np.concatenate([task.target[2] + rng.normal(0, 0.17, size=(n, 69)), rng.normal(0, 0.17, size=(n, 6))], axis=1).astype(np.float32)
+        ta = time.perf_counter()
+        act = np.concatenate([task.target[2] + rng.normal(0, sigma, size=(n, 69)), rng.normal(0, sigma, size=(n, 6))], axis=1).astype(np.float32)
         _, pd, _, force, torque = task.pre_physics_step(act)
-        res = list(pool.map(lambda e: one(e, pd[e], force[e], torque[e]), range(n)))
-        task.set_sim_state(np.stack([r[1] for r in res]).astype(np.float32), np.stack([r[2] for r in res]).astype(np.float32),
-                           np.stack([r[3] for r in res]).astype(np.float32))
+        tb = time.perf_counter()
+        res = oracle.step(pd, force, torque, nsub=4, hold=2)
+        tc = time.perf_counter()
+        task.set_sim_state(res["dpos"].astype(np.float32), res["dvel"].astype(np.float32), res["rb"].astype(np.float32))
         task.post_physics_step()
-    dt = time.perf_counter() - t0
-    pool.shutdown()
-    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d envs x %d control steps (4 substeps each, contacts on), C float64 dense oracle + numpy task ops, %d threads, %.1f s"
-                      % (n, steps, cores, dt)}
+        td = time.perf_counter()
+        t_phys += tc - tb
+        t_task += (tb - ta) + (td - tc)
+    dt = t_phys + t_task
+    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "physics_env_steps_per_s": n * steps / t_phys, "physics_env_steps_per_s_per_core": n * steps / t_phys / threads,
+            "task_ops_env_steps_per_s": n * steps / t_task, "task_ops_threads": 1,
+            "sample": "%d envs x %d control steps (4 substeps each, contacts on): C float64 dense oracle, one batched OpenMP call per step on %d threads "
+                      "(%.2f s) + numpy task ops on 1 thread (%.2f s); host has %d logical cores" % (n, steps, threads, t_phys, t_task, cores)}
+
+
+def profiles_view():
+    """What the committed profiles say about the physics kernel: FLOPs and HBM bytes per launch (labelled from_profiles in the line)."""
+    valu = traffic = None
+    vc = os.path.join(REPO, "profiles", "valu_counters.json")
+    if os.path.exists(vc):
+        try:
+            c = json.load(open(vc))
+            g = lambda k: c[k]["avg"]
+            lanes = g("SQ_THREAD_CYCLES_VALU") / g("SQ_ACTIVE_INST_VALU")
+            wave_ops = 2.0 * g("SQ_INSTS_VALU_FMA_F32") + g("SQ_INSTS_VALU_MUL_F32") + g("SQ_INSTS_VALU_ADD_F32")
+            valu = {"flops_per_launch": wave_ops * lanes, "lanes_active_per_valu_op": lanes,
+                    "valu_insts_per_wave": g("SQ_INSTS_VALU") / g("SQ_WAVES"),
+                    "wave_time_issuing_valu": g("SQ_ACTIVE_INST_VALU") / g("SQ_WAVE_CYCLES"),
+                    "source": "from_profiles: " + c.get("source", "profiles/valu_counters.json")}
+        except Exception:
+            valu = None
+    pmc = os.path.join(REPO, "profiles", "pmc_summary.json")
+    if os.path.exists(pmc):
+        try:
+            p = json.load(open(pmc))
+            traffic = {"bytes_per_launch": p.get("physics_kernel_hbm_bytes_per_launch"), "source": "from_profiles: " + p.get("source", "profiles/pmc_summary.json")}
+        except Exception:
+            traffic = None
+    return valu, traffic
 
 
 def main():
@@ -122,121 +210,129 @@ def main():
     ap.add_argument("--num-envs", type=int, default=8192, help="envs per GPU")
     ap.add_argument("--no-contact", action="store_true", help="BASELINE config 2 (PD only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--action-noise", type=float, default=0.17, help="sigma of the stand-in policy (0.17 = SURVEY 8d; small values = tracking-quality actions, fewer falls)")
+    ap.add_argument("--solver", choices=["pgs", "tgs"], default="pgs")
     ap.add_argument("--freeze-terminated", action="store_true", help="opt-in engine feature: terminated envs are not simulated until the epoch reset (not reference behaviour)")
     ap.add_argument("--djokovic", action="store_true", help="BASELINE config 4 (djokovic_im.yaml: terminationHeadHeight -0.5, faster clips)")
     ap.add_argument("--per-clip-shapes", action="store_true", help="one body shape per clip (64 scaled bodies) instead of one shape for all envs")
+    ap.add_argument("--stub-task", action="store_true", help=argparse.SUPPRESS)  # launch-logic test without GPUs (gloo, CPU); never a measurement
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:], args.stub_task))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
-    if not torch.cuda.is_available():
+    stub = args.stub_task
+    if not stub and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the rollout engine has no CPU path")
-    torch.cuda.set_device(local_rank)
+    if args.steps % HORIZON and rank == 0:
+        sys.stderr.write("bench.py: --steps %d is not a multiple of the %d-step epoch: the timed region is not a whole number of epochs "
+                         "(early steps of an epoch are lighter than late ones), quote a multiple of %d\n" % (args.steps, HORIZON, HORIZON))
+    if not stub:
+        torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or os.environ.get("V2P_BENCH_FORCE_DIST"):  # (the env var runs the collective path on a single GPU: CI of the N>1 code)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        if stub:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from vid2player3d_amd import build
-    if local_rank == 0:
-        build.build()  # no-op when the in-tree .so is current; one rank per node compiles otherwise
-    if dist is not None:
-        dist.barrier()
     n = args.num_envs
-    task = build_task(n, local_rank, seed=7 + rank, contact=not args.no_contact, per_clip_shapes=args.per_clip_shapes, djokovic=args.djokovic, freeze=args.freeze_terminated)  # per-rank seed like run.py:37
+    if stub:
+        task = StubTask(n)
+    else:
+        from vid2player3d_amd import build
+        if local_rank == 0:
+            build.build()  # no-op when the in-tree .so is current; one rank per node compiles otherwise
+        if dist is not None:
+            dist.barrier()
+        task = build_task(n, local_rank, seed=7 + rank, contact=not args.no_contact, per_clip_shapes=args.per_clip_shapes, djokovic=args.djokovic,
+                          freeze=args.freeze_terminated, solver=args.solver)  # per-rank seed like run.py:37
     dev = task.device
     gen = torch.Generator(device=dev)
     gen.manual_seed(7 + rank)
-    noise = [0.17 * torch.randn((n, 75), device=dev, generator=gen) for _ in range(HORIZON)]
+    noise = [args.action_noise * torch.randn((n, 75), device=dev, generator=gen) for _ in range(HORIZON)]
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+    def sync():
+        if not stub:
             torch.cuda.synchronize()
 
-    ev_pairs = []
+    def barrier():
+        sync()
+        if dist is not None:
+            dist.barrier()
+            sync()
 
-    def run(nsteps, timed_events=False):
+    def run(nsteps):
         for i in range(nsteps):
             if i % HORIZON == 0:
                 task.reset()
-            a = make_actions(task, noise[i % HORIZON])
-            if timed_events:
-                task.pre_physics_step(a)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                from vid2player3d_amd import _lib
-                _lib.check(task._lib.v2p_env_physics(task._h_env, task._stream()), "v2p_env_physics")
-                e1.record()
-                _lib.check(task._lib.v2p_env_export(task._h_env, task._stream()), "v2p_env_export")
-                task.post_physics_step()
-                ev_pairs.append((e0, e1))
-            else:
-                task.step_fused(a)
+            task.step_fused(make_actions(task, noise[i % HORIZON]))
 
     run(args.warmup)
     barrier()
+    task.profile_begin(args.steps)  # events around the physics kernel of every timed step, recorded by the engine on the launch stream
     t0 = time.perf_counter()
     run(args.steps)
     barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # dominant-kernel duration with HIP events on the launch stream (separate, untimed pass)
-    run(HORIZON, timed_events=True)
-    torch.cuda.synchronize()
-    phys_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_pairs]))
+    elapsed_local = time.perf_counter() - t0
+    phys_ms_total, launches = task.profile_end()
+    phys_ms = phys_ms_total / max(launches, 1)
     alive = float((task.reset_buf == 0).float().mean().item())
+    elapsed, per_rank = elapsed_local, [n * args.steps / elapsed_local]
+    world_seen = 1
+    if dist is not None:
+        world_seen = dist.get_world_size()
+        t = torch.tensor([elapsed_local], device=dev, dtype=torch.float64)
+        allt = [torch.zeros_like(t) for _ in range(world_seen)]
+        dist.all_gather(allt, t)
+        times = [float(x.item()) for x in allt]
+        elapsed = max(times)  # MAX over ranks
+        per_rank = [n * args.steps / x for x in times]
 
     if rank == 0:
         value = world * n * args.steps / elapsed
         achieved = ALGO_BYTES_PER_ENV_STEP * n / (phys_ms * 1e-3) / 1e9
-        valu = None  # VALU-side view of the same kernel from the committed SQ counter passes (tools/valu_probe.sh): the binding resource
-        vc = os.path.join(REPO, "profiles", "r01e_valu_counters.json")
-        if os.path.exists(vc):
-            try:
-                c = json.load(open(vc))
-                valu = {"valu_insts_per_wave": c["SQ_INSTS_VALU"]["avg"] / c["SQ_WAVES"]["avg"],
-                        "wave_time_issuing_valu": c["SQ_ACTIVE_INST_VALU"]["avg"] / c["SQ_WAVE_CYCLES"]["avg"],
-                        "lanes_active_per_valu_op": c["SQ_THREAD_CYCLES_VALU"]["avg"] / c["SQ_ACTIVE_INST_VALU"]["avg"],
-                        "source": "profiles/r01e_valu_counters.json (rocprofv3 --pmc, 8192 envs)"}
-            except Exception:
-                valu = None
-        traffic = None
-        pmc = os.path.join(REPO, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("physics_kernel_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        valu, traffic = profiles_view()
+        roof = {"bound": "hbm", "kernel": "physics_ll_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None if traffic is None else traffic["bytes_per_launch"],
+                "traffic_source": None if traffic is None else traffic["source"], "kernel_ms": phys_ms, "kernel_launches_timed": launches,
+                "kernel_ms_source": "HIP events recorded by the engine around every physics launch of the timed steps (launch stream)",
+                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n,
+                "note": "the kernel is VALU-issue bound, not HBM bound (DESIGN.md): valu_frac is the fraction that says how good it is"}
+        if valu is not None and n == 8192 and not args.no_contact:
+            tflops = valu["flops_per_launch"] / (phys_ms * 1e-3) / 1e12
+            roof.update({"valu_tflops": tflops, "valu_peak_tflops": FP32_VECTOR_PEAK_TFLOPS, "valu_frac": tflops / FP32_VECTOR_PEAK_TFLOPS, "valu": valu})
         out = {
             "metric": "env-steps/sec at num_envs=8192, SMPL humanoid imitation", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "amass_im num_envs=%d per GPU, %s, imitation reward, per-epoch reset+context every %d steps, 64 synthetic clips%s"
-                                   % (n, "PD control only (no contact solve)" if args.no_contact else "full contact PGS (4 substeps x 4 iterations)", HORIZON,
-                                      (", one body shape per clip" if args.per_clip_shapes else "") + (", djokovic_im variant" if args.djokovic else "") + (", TERMINATED ENVS FROZEN (not reference behaviour)" if args.freeze_terminated else "")),
+            "config": {"workload": "amass_im num_envs=%d per GPU, %s, imitation reward, per-epoch reset+context every %d steps, 64 synthetic clips, action noise %.3g%s"
+                                   % (n, "PD control only (no contact solve)" if args.no_contact else "full contact %s (4 substeps x 4 iterations)" % args.solver.upper(), HORIZON,
+                                      args.action_noise, (", one body shape per clip" if args.per_clip_shapes else "") + (", djokovic_im variant" if args.djokovic else "") +
+                                      (", TERMINATED ENVS FROZEN (not reference behaviour)" if args.freeze_terminated else "") + (", STUB TASK (launch-logic test, not a measurement)" if stub else "")),
                        "num_envs_per_gpu": n, "global_envs": world * n, "parallelism": "env-sharded x%d, no data-path collective" % world,
-                       "alive_fraction_at_end": alive},
-            "roofline": {"bound": "hbm", "kernel": "physics_ll_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": phys_ms,
-                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n,
-                         "note": "latency/VALU bound, not HBM bound: see DESIGN.md", "valu": valu},
+                       "world_size_seen": world_seen, "backend": None if dist is None else ("gloo" if stub else "nccl(rccl)"),
+                       "per_rank_env_steps_per_s": per_rank, "alive_fraction_at_end": alive},
+            "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if not stub:
+            from vid2player3d_amd import build
+            out["build"] = build.build_info()
+        if world == 1 and not args.no_cpu_baseline and not stub:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
+        sys.stdout.flush()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -253,6 +253,13 @@ int v2p_env_debug_contacts_substeps(v2p_env* e, int32_t* out, void* stream);
  * waves in descending order of their contact load, see DESIGN.md "pairing") and the load key it was built from (`key`, [N]) */
 int v2p_env_debug_pairing(v2p_env* e, int32_t* perm, int32_t* key, void* stream);
 
+/* measurement: HIP events around every launch of the physics kernel (the dominant kernel of the step), recorded on the launch stream
+ * by v2p_env_step / v2p_env_physics between _begin and _end (at most max_launches of them).  _end synchronises the events and returns
+ * the summed kernel time in milliseconds and the number of launches measured.  bench.py's roofline.kernel_ms comes from here, from
+ * the very steps it times. */
+int v2p_env_profile_begin(v2p_env* e, int64_t max_launches);
+int v2p_env_profile_end(v2p_env* e, double* physics_ms_total, int64_t* launches);
+
 const char* v2p_last_error(void);
 int v2p_abi_version(void);
 

@@ -45,6 +45,7 @@
 #define ND (6 + 3 * NJ)
 #define MAXC_BODY 4
 #define MAXROWS (NB * MAXC_BODY * 3)
+#define MAXV_BODY 64 /* hull vertices per body (the engine's limit as well) */
 
 typedef struct {
     int parents[NB];
@@ -392,7 +393,8 @@ static void gen_contacts(const v2p_omodel *m, const v2p_oparams *p, const kin_t 
     for (int b = 0; b < NB; ++b) {
         int v0 = m->hull_offsets[b], v1 = m->hull_offsets[b + 1];
         int nv = v1 - v0;
-        double (*P)[3] = malloc(sizeof(double[3]) * (size_t)nv);
+        double P[MAXV_BODY][3]; /* (no heap traffic inside the OpenMP batch loop) */
+        if (nv > MAXV_BODY) nv = MAXV_BODY;
         for (int i = 0; i < nv; ++i) {
             double t[3];
             matvec(k->R[b], &m->hull_verts[3 * (v0 + i)], t);
@@ -416,7 +418,6 @@ static void gen_contacts(const v2p_omodel *m, const v2p_oparams *p, const kin_t 
             cs->vert[c] = sel[i];
             memcpy(cs->pos[c], P[sel[i]], sizeof(double) * 3);
         }
-        free(P);
     }
 }
 
@@ -425,7 +426,7 @@ int v2p_oracle_substep_io(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate 
                           const double *ext_force /*[3] world, at root COM*/, const double *ext_torque /*[3] world*/,
                           double *contact_force /*[NB*3] out*/, double *dof_force /*[69] out*/, int *contact_ids /*[NB*4] out: body*64+vertex, -1 padded*/,
                           const v2p_osub_io *io) {
-    double *M = malloc(sizeof(double) * ND * ND), C[ND], J[6 * ND];
+    double M[ND * ND], C[ND], J[6 * ND];
     double rhs[ND], q[3 * NJ];
     kin_t k;
     const double h = p->h;
@@ -449,7 +450,7 @@ int v2p_oracle_substep_io(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate 
         rhs[6 + j] += m->kp[j] * (tar - q[j]) - (m->kd[j] + h * m->kp[j]) * wj;
         M[(6 + j) * ND + 6 + j] += m->armature[j] + h * m->kd[j] + h * h * m->kp[j];
     }
-    if (cholesky(M, ND)) { free(M); return -1; }
+    if (cholesky(M, ND)) return -1;
     chol_solve(M, ND, rhs);
     double v[ND];
     for (int i = 0; i < ND; ++i) v[i] = s->vel[i] + h * rhs[i];
@@ -461,11 +462,12 @@ int v2p_oracle_substep_io(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate 
         contacts_t cs;
         gen_contacts(m, p, &k, &cs, io);
         int nrow = cs.n * 3;
-        double *Jr = calloc((size_t)(nrow > 0 ? nrow : 1) * ND, sizeof(double));
-        double *Tr = calloc((size_t)(nrow > 0 ? nrow : 1) * ND, sizeof(double));
-        double *wii = calloc((size_t)(nrow > 0 ? nrow : 1), sizeof(double));
-        double *lam = calloc((size_t)(nrow > 0 ? nrow : 1), sizeof(double));
-        double *bias = calloc((size_t)(nrow > 0 ? nrow : 1), sizeof(double));
+        /* one heap block per substep for the row matrices (up to 2 x 288 x 75 doubles) */
+        double *Jr = calloc((size_t)(nrow > 0 ? nrow : 1) * (2 * ND + 3), sizeof(double));
+        double *Tr = Jr + (size_t)(nrow > 0 ? nrow : 1) * ND;
+        double *wii = Tr + (size_t)(nrow > 0 ? nrow : 1) * ND;
+        double *lam = wii + (nrow > 0 ? nrow : 1);
+        double *bias = lam + (nrow > 0 ? nrow : 1);
         double gap[NB * MAXC_BODY];
         const double dirs[3][3] = {{0, 0, 1}, {1, 0, 0}, {0, 1, 0}};
         int slot_in_body[NB];
@@ -535,7 +537,7 @@ int v2p_oracle_substep_io(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate 
                 contact_force[3 * b + 0] += lam[3 * c + 1] / h;
                 contact_force[3 * b + 1] += lam[3 * c + 2] / h;
             }
-        free(Jr); free(Tr); free(wii); free(lam); free(bias);
+        free(Jr);
     }
 
     /* joint drive torque actually applied (implicit form) */
@@ -568,7 +570,6 @@ int v2p_oracle_substep_io(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate 
         qnormalize(nq);
         memcpy(s->jquat[b - 1], nq, sizeof(nq));
     }
-    free(M);
     return 0;
 }
 

@@ -24,12 +24,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
+TOTAL_ENVS = 13  # odd on purpose: shard_envs gives the two ranks 7 and 6 envs, the gather must cope with uneven shards
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    full = torch.arange(32 * 12, dtype=torch.float32).reshape(32, 12) * 0.37 - 3.0
-    mask_full = (torch.arange(32 * 12).reshape(32, 12) % 5 != 0).float()
-    lo, hi = shard_envs(12, rank, world)
+    full = torch.arange(32 * TOTAL_ENVS, dtype=torch.float32).reshape(32, TOTAL_ENVS) * 0.37 - 3.0
+    mask_full = (torch.arange(32 * TOTAL_ENVS).reshape(32, TOTAL_ENVS) % 5 != 0).float()
+    lo, hi = shard_envs(TOTAL_ENVS, rank, world)
     adv, mask = full[:, lo:hi].clone(), mask_full[:, lo:hi].clone()
     gathered = all_gather_advantages(adv)
     mean, std, cnt = global_advantage_stats(adv, mask)
@@ -49,10 +52,11 @@ def test_collectives_world_size_2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    full = (np.arange(32 * 12, dtype=np.float32).reshape(32, 12) * 0.37 - 3.0)
-    mask = (np.arange(32 * 12).reshape(32, 12) % 5 != 0).astype(np.float64)
+    full = (np.arange(32 * TOTAL_ENVS, dtype=np.float32).reshape(32, TOTAL_ENVS) * 0.37 - 3.0)
+    mask = (np.arange(32 * TOTAL_ENVS).reshape(32, TOTAL_ENVS) % 5 != 0).astype(np.float64)
     mean = (full * mask).sum() / mask.sum()
     std = np.sqrt(((full.astype(np.float64) - mean) ** 2 * mask).sum() / (mask.sum() - 1))  # unbiased, like torch.std
+    assert sorted(hi - lo for _, _, _, _, _, _, lo, hi in res) == [6, 7]
     for rank, gathered, m, s, c, norm, lo, hi in res:
         assert np.array_equal(gathered, full)
         assert abs(m - mean) < 1e-5 and abs(s - std) < 1e-5 and c == mask.sum()

@@ -215,8 +215,17 @@ def test_legacy_pth_motion_file_drives_the_task():
 
     cfg = default_cfg(6, motion_file=os.path.join(GOLDEN, "legacy_mlib"))
     cfg["env"]["sample_first_motions"] = True
+    # the fixture's three clips carry three different betas: one baked body for all of them is refused unless the caller says so
+    with pytest.raises(RuntimeError, match="different body shapes"):
+        HumanoidSMPLIM(cfg, device_type="cuda", device_id=0)
+    cfg["env"]["body_shape_mismatch"] = "ignore"
     task = HumanoidSMPLIM(cfg, device_type="cuda", device_id=0)
     assert task._motion_lib.num_motions() == 3
+    with pytest.raises(RuntimeError, match="handed to an env batch"):
+        task._motion_lib.merge_multiple_motion_libs([])
+    bad = default_cfg(6, motion_lib=task._motion_lib, body_shape_mismatch="ignore", motion_ids=[0, 1, 2, 3, 0, 1])
+    with pytest.raises(ValueError, match="motion ids"):
+        HumanoidSMPLIM(bad, device_type="cuda", device_id=0)
     with np.load(os.path.join(GOLDEN, "legacy_mlib_expected.npz")) as z:
         exp = {k: z[k] for k in z.files}
     res = task._motion_lib.get_motion_state(T(exp["state_ids"], torch.long), T(exp["state_times"]), return_rigid_body=True, adjust_height=True,
@@ -271,9 +280,43 @@ def test_discount_values_wrapper(golden_task_ops):
     from vid2player3d_amd.learning import discount_values
 
     g = golden_task_ops
-    adv = discount_values(None, None, T(g["gae_fdones"]), T(g["gae_values"]), T(g["gae_rewards"]), T(g["gae_next_values"]), float(g["gae_gamma"]),
-                          float(g["gae_tau"]))
+    from vid2player3d_amd.learning import DiscountValuesMixin
+
+    args = (T(g["gae_fdones"]), T(g["gae_values"]), T(g["gae_rewards"]), T(g["gae_next_values"]))
+    adv = discount_values(*args, float(g["gae_gamma"]), float(g["gae_tau"]))
     close(N(adv), g["gae_advs"], 2e-6, "discount_values")
+
+    class Agent(DiscountValuesMixin):  # the reference's 4-argument method signature (common_agent.py:423)
+        gamma, tau = float(g["gae_gamma"]), float(g["gae_tau"])
+
+    assert torch.equal(Agent().discount_values(*args), adv)
+
+
+def test_imitation_obs_running_norm_semantics(golden_task_ops):
+    """RunningNorm.forward (models/running_norm.py:32-43): a fresh model (n == 0) does not normalise, clip None / 0 does not clamp,
+    statistics that still live on the CPU are moved to the observations' device instead of reaching the kernel as host pointers."""
+    from vid2player3d_amd.learning import ImitationObs
+
+    g = golden_task_ops
+    n = g["obs734"].shape[0]
+    obs, frame = _packed_inputs(g, n)
+    ctx = np.zeros((n, 48, 378), np.float32)
+    ctx[:, 8 + 3] = frame
+    raw = ImitationObs(8).rollout(T(obs), T(ctx), 3)
+
+    class RN:  # duck-typed RunningNorm
+        def __init__(self, n, clip):
+            self.n, self.clip = torch.tensor(n), clip
+            self.mean, self.std = torch.full((734,), 0.25), torch.full((734,), 2.0)  # CPU buffers on purpose
+            self.demean = self.destd = True
+
+    assert torch.equal(ImitationObs.from_running_norm(RN(0, 5.0)).rollout(T(obs), T(ctx), 3), raw)
+    unclamped = ImitationObs.from_running_norm(RN(10, None)).rollout(T(obs), T(ctx), 3)
+    close(N(unclamped), (N(raw) - 0.25) / (2.0 + 1e-8), 2e-6, "no clamp")
+    clamped = ImitationObs.from_running_norm(RN(10, 0.5)).rollout(T(obs), T(ctx), 3)
+    close(N(clamped), np.clip((N(raw) - 0.25) / (2.0 + 1e-8), -0.5, 0.5), 2e-6, "clamp 0.5")
+    with pytest.raises(ValueError):
+        ImitationObs(8, torch.zeros(10), torch.ones(10))
 
 
 def test_replay_tool_on_the_golden_trace(tmp_path, golden_tables, capsys, monkeypatch):

@@ -37,7 +37,7 @@ def main():
     with np.load(args.motion) as z:
         lib = MotionLib({k: z[k] for k in z.files}, dev)
     n = len(g["motion_ids"])
-    cfg = default_cfg(n, motion_lib=lib, record_pd_torque=True, motion_ids=g["motion_ids"])
+    cfg = default_cfg(n, motion_lib=lib, record_pd_torque=True, motion_ids=g["motion_ids"], body_shape_mismatch="warn")  # a trace names its own body; the baked one is used here
     if args.body_model:
         with np.load(args.body_model) as z:
             cfg["env"]["body_model"] = BodyModel({k: z[k] for k in z.files})

@@ -59,6 +59,8 @@ int ensure_env_per_lane_buffers(v2p_env* e) {
 }
 }  // namespace v2p
 
+static void profile_free(v2p_env* e);
+
 extern "C" {
 
 const char* v2p_last_error(void) { return g_err; }
@@ -396,6 +398,7 @@ void v2p_env_destroy(v2p_env* e) {
     if (e->ws) (void)hipFree(e->ws);
     if (e->contact_ids) (void)hipFree(e->contact_ids);
     if (e->contact_ids_sub) (void)hipFree(e->contact_ids_sub);
+    profile_free(e);
     if (e->shapes_dev) (void)hipFree(e->shapes_dev);
     if (e->shape_aug_dev) (void)hipFree(e->shape_aug_dev);
     if (e->env_shape_dev) (void)hipFree(e->env_shape_dev);
@@ -437,12 +440,61 @@ int v2p_env_pre_physics(v2p_env* e, float* actions, void* stream) {
     return launch_env_pre(e, actions, (hipStream_t)stream);
 }
 
+// the physics launch of either schedule, bracketed by events while a measurement is open
+static int physics_launch(v2p_env* e, hipStream_t s, float* actions) {
+    const bool rec = e->prof_ev && e->prof_n < e->prof_cap;
+    if (rec) (void)hipEventRecord(e->prof_ev[2 * e->prof_n], s);
+    int rc = e->schedule != 0 ? launch_env_physics(e, s) : launch_env_physics_ll(e, s, actions);
+    if (rec) { (void)hipEventRecord(e->prof_ev[2 * e->prof_n + 1], s); ++e->prof_n; }
+    return rc;
+}
+
 int v2p_env_physics(v2p_env* e, void* stream) {
     if (!e) { set_error("v2p_env_physics: bad argument"); return V2P_ERR_INVALID; }
     DeviceGuard g(e->device);
     if (e->schedule != 0) { int rc = ensure_env_per_lane_buffers(e); if (rc != V2P_OK) return rc; }
-    if (e->schedule != 0) return launch_env_physics(e, (hipStream_t)stream);
-    return launch_env_physics_ll(e, (hipStream_t)stream);
+    return physics_launch(e, (hipStream_t)stream, nullptr);
+}
+
+static void profile_free(v2p_env* e) {
+    if (!e->prof_ev) return;
+    for (int64_t i = 0; i < 2 * e->prof_cap; ++i)
+        if (e->prof_ev[i]) (void)hipEventDestroy(e->prof_ev[i]);
+    delete[] e->prof_ev;
+    e->prof_ev = nullptr;
+    e->prof_cap = e->prof_n = 0;
+}
+
+int v2p_env_profile_begin(v2p_env* e, int64_t max_launches) {
+    if (!e || max_launches <= 0 || max_launches > (1 << 20)) { set_error("v2p_env_profile_begin: bad argument"); return V2P_ERR_INVALID; }
+    DeviceGuard g(e->device);
+    profile_free(e);
+    e->prof_ev = new (std::nothrow) hipEvent_t[2 * max_launches]();
+    if (!e->prof_ev) { set_error("v2p_env_profile_begin: out of host memory"); return V2P_ERR_NOMEM; }
+    e->prof_cap = max_launches;
+    for (int64_t i = 0; i < 2 * max_launches; ++i) {
+        int rc = check_hip(hipEventCreate(&e->prof_ev[i]), "hipEventCreate");
+        if (rc != V2P_OK) { profile_free(e); return rc; }
+    }
+    return V2P_OK;
+}
+
+int v2p_env_profile_end(v2p_env* e, double* physics_ms_total, int64_t* launches) {
+    if (!e || !physics_ms_total || !launches) { set_error("v2p_env_profile_end: bad argument"); return V2P_ERR_INVALID; }
+    if (!e->prof_ev) { set_error("v2p_env_profile_end: no measurement is open"); return V2P_ERR_INVALID; }
+    DeviceGuard g(e->device);
+    double total = 0.0;
+    int rc = V2P_OK;
+    for (int64_t k = 0; k < e->prof_n && rc == V2P_OK; ++k) {
+        float ms = 0.f;
+        rc = check_hip(hipEventSynchronize(e->prof_ev[2 * k + 1]), "hipEventSynchronize");
+        if (rc == V2P_OK) rc = check_hip(hipEventElapsedTime(&ms, e->prof_ev[2 * k], e->prof_ev[2 * k + 1]), "hipEventElapsedTime");
+        total += ms;
+    }
+    *physics_ms_total = total;
+    *launches = e->prof_n;
+    profile_free(e);
+    return rc;
 }
 
 int v2p_env_export(v2p_env* e, void* stream) {
@@ -462,7 +514,7 @@ int v2p_env_step(v2p_env* e, float* actions, void* stream) {
     if (e && actions && e->schedule == 0) {
         // link-per-lane schedule: pre-physics runs in the physics kernel's prologue (lane = link owns its joint's action components)
         DeviceGuard g(e->device);
-        int rc = launch_env_physics_ll(e, (hipStream_t)stream, actions);
+        int rc = physics_launch(e, (hipStream_t)stream, actions);
         if (rc == V2P_OK) rc = launch_env_post(e, (hipStream_t)stream);
         return rc;
     }

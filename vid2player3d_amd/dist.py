@@ -23,14 +23,27 @@ def shard_envs(num_envs_total, rank, world_size):
 
 
 def all_gather_advantages(adv, group=None):
-    """[T, N_local, ...] on every rank -> [T, N_global, ...] (envs concatenated in rank order)."""
+    """[T, N_local, ...] on every rank -> [T, N_global, ...] (envs concatenated in rank order).  Ranks may own different
+    numbers of envs (shard_envs hands out uneven shards when N % W != 0): the per-rank counts are exchanged first and the
+    payload is padded to the largest shard (one collective of equal-sized buffers), then trimmed."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return adv
     world = dist.get_world_size(group)
     local = adv.transpose(0, 1).contiguous()  # env-major so that the gather concatenates envs
-    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=adv.dtype, device=adv.device)
+    counts = torch.zeros(world, dtype=torch.int64, device=adv.device)
+    mine = torch.tensor([local.shape[0]], dtype=torch.int64, device=adv.device)
+    dist.all_gather_into_tensor(counts, mine, group=group)
+    counts = [int(c) for c in counts.tolist()]
+    cap = max(counts)
+    if local.shape[0] < cap:
+        pad = torch.zeros((cap - local.shape[0],) + tuple(local.shape[1:]), dtype=adv.dtype, device=adv.device)
+        local = torch.cat([local, pad], dim=0)
+    out = torch.empty((world * cap,) + tuple(local.shape[1:]), dtype=adv.dtype, device=adv.device)
     dist.all_gather_into_tensor(out, local, group=group)
-    return out.transpose(0, 1).contiguous()
+    if all(c == cap for c in counts):
+        return out.transpose(0, 1).contiguous()
+    parts = [out[r * cap:r * cap + counts[r]] for r in range(world)]
+    return torch.cat(parts, dim=0).transpose(0, 1).contiguous()
 
 
 def global_advantage_stats(adv, mask=None, group=None):

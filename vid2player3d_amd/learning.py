@@ -24,27 +24,45 @@ class ImitationObs:
 
     def __init__(self, context_padding=8, mean=None, std=None, clip=5.0):
         self.context_padding = int(context_padding)
-        self.clip = float(clip)
+        # RunningNorm.forward clamps only `if self.clip` (running_norm.py:41-42): None / 0 = no clamp
+        self.clip = float(clip) if clip else float("inf")
         self.set_running_stats(mean, std)
         self._lib = _lib.load()
 
     @classmethod
     def from_running_norm(cls, running_norm, context_padding=8):
-        """running_norm: the reference's models.running_norm.RunningNorm in eval mode (or anything with .mean .std .clip)."""
+        """running_norm: the reference's models.running_norm.RunningNorm in eval mode (or anything with .mean .std .clip [.n]).
+        A fresh model (n == 0) does not normalise at all (running_norm.py:36): raw features, like mean = std = None."""
+        n = getattr(running_norm, "n", None)
+        if n is not None and int(n) == 0:
+            return cls(context_padding, None, None, running_norm.clip)
+        if not (getattr(running_norm, "demean", True) and getattr(running_norm, "destd", True)):
+            raise NotImplementedError("RunningNorm with demean=False or destd=False is not built (the reference's networks use both)")
         return cls(context_padding, running_norm.mean, running_norm.std, running_norm.clip)
 
     def set_running_stats(self, mean, std):
         if (mean is None) != (std is None):
             raise ValueError("mean and std go together")
+        for name, t in (("mean", mean), ("std", std)):
+            if t is not None and tuple(t.shape) != (OBS_IMITATION_DIM,):
+                raise ValueError("%s must have shape [%d], got %s" % (name, OBS_IMITATION_DIM, tuple(t.shape)))
         self._mean = None if mean is None else mean.detach().float().contiguous()
         self._std = None if std is None else std.detach().float().contiguous()
+
+    def _stats_on(self, device):
+        """the statistics on the device of the observations (RunningNorm buffers of a model still on the CPU are moved, never passed
+        to the kernel as host pointers)"""
+        if self._mean is not None and self._mean.device != device:
+            self._mean, self._std = self._mean.to(device), self._std.to(device)
+        return self._mean, self._std
 
     def _run(self, obs, context_feat, steps, first_frame):
         rows = obs.shape[0]
         out = torch.empty((rows, OBS_IMITATION_DIM), dtype=torch.float32, device=obs.device)
         stream = torch.cuda.current_stream(obs.device).cuda_stream
+        mean, std = self._stats_on(obs.device)
         _lib.check(self._lib.v2p_obs_imitation_packed(rows, steps, _lib.ptr(obs), _lib.ptr(context_feat), context_feat.shape[1], first_frame,
-                                                      _lib.ptr(self._mean), _lib.ptr(self._std), self.clip, _lib.ptr(out), stream),
+                                                      _lib.ptr(mean), _lib.ptr(std), self.clip, _lib.ptr(out), stream),
                    "v2p_obs_imitation_packed")
         return out
 
@@ -65,19 +83,27 @@ class ImitationObs:
         return self._run(flat, context_feat, flat.shape[0] // n, self.context_padding)
 
 
-def discount_values(fdones, last_extrinsic_values, mb_fdones, mb_extrinsic_values, mb_rewards, mb_next_values, gamma, tau):
-    """CommonAgent.discount_values (learning/common_agent.py:423-435): same arguments (the first two are unused there as well);
-    mb_* are [T,N] / [T,N,1] float32 CUDA tensors; returns mb_advs like mb_rewards."""
-    for name, t in (("mb_fdones", mb_fdones), ("mb_extrinsic_values", mb_extrinsic_values), ("mb_rewards", mb_rewards), ("mb_next_values", mb_next_values)):
+def discount_values(mb_fdones, mb_values, mb_rewards, mb_next_values, gamma, tau):
+    """CommonAgent.discount_values (learning/common_agent.py:423-435) with the agent's gamma / tau passed in (the method reads
+    self.gamma, self.tau, self.horizon_length): mb_fdones [T,N], the others [T,N,1] (or [T,N]) float32 CUDA tensors; returns
+    mb_advs like mb_rewards."""
+    for name, t in (("mb_fdones", mb_fdones), ("mb_values", mb_values), ("mb_rewards", mb_rewards), ("mb_next_values", mb_next_values)):
         if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
             raise RuntimeError("%s must be a contiguous float32 CUDA tensor" % name)
     horizon = mb_rewards.shape[0]
     n = mb_rewards[0].numel()
-    if mb_fdones.numel() != horizon * n or mb_extrinsic_values.numel() != horizon * n or mb_next_values.numel() != horizon * n:
+    if mb_fdones.numel() != horizon * n or mb_values.numel() != horizon * n or mb_next_values.numel() != horizon * n:
         raise RuntimeError("discount_values: tensors disagree on [T,N]")
     advs = torch.empty_like(mb_rewards)
     lib = _lib.load()
     stream = torch.cuda.current_stream(mb_rewards.device).cuda_stream
-    _lib.check(lib.v2p_gae(horizon, n, _lib.ptr(mb_fdones), _lib.ptr(mb_extrinsic_values), _lib.ptr(mb_rewards), _lib.ptr(mb_next_values),
+    _lib.check(lib.v2p_gae(horizon, n, _lib.ptr(mb_fdones), _lib.ptr(mb_values), _lib.ptr(mb_rewards), _lib.ptr(mb_next_values),
                            float(gamma), float(tau), _lib.ptr(advs), stream), "v2p_gae")
     return advs
+
+
+class DiscountValuesMixin:
+    """Drop-in for CommonAgent.discount_values on an agent object that has .gamma and .tau (same 4-argument signature)."""
+
+    def discount_values(self, mb_fdones, mb_values, mb_rewards, mb_next_values):
+        return discount_values(mb_fdones, mb_values, mb_rewards, mb_next_values, self.gamma, self.tau)

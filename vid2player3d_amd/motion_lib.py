@@ -45,6 +45,7 @@ class MotionLib:
         self.generate_length_starts()
         self.motion_ids = torch.arange(len(self._motion_lengths), dtype=torch.long, device=self._device)
         self._handle = None
+        self._borrowed = False  # set by the task that hands handle() to an env batch
 
     # ---- construction helpers -------------------------------------------------------------
     @classmethod
@@ -52,7 +53,9 @@ class MotionLib:
         """Synthetic / converted clips -> tables (motion_tables.py) -> device."""
         if isinstance(body_model, (list, tuple)):  # one body shape per clip
             return cls(mt.build_tables(clips, body_model[0].parents, np.stack([m.local_pos for m in body_model])), device, **kw)
-        return cls(mt.build_tables(clips, body_model.parents, body_model.local_pos), device, **kw)
+        lib = cls(mt.build_tables(clips, body_model.parents, body_model.local_pos), device, **kw)
+        lib._single_skeleton = True  # every clip was built on this one skeleton, whatever beta labels the clips carry
+        return lib
 
     def generate_length_starts(self):
         """motion_lib.py:95-99"""
@@ -62,7 +65,10 @@ class MotionLib:
         self.length_starts = shifted.cumsum(0)
 
     def merge_multiple_motion_libs(self, motion_lib_arr):
-        """motion_lib.py:101-118"""
+        """motion_lib.py:101-118.  Must happen before the library is handed to a task: an env batch borrows the table pointers."""
+        if getattr(self, "_borrowed", False):
+            raise RuntimeError("merge_multiple_motion_libs after the library was handed to an env batch: the batch borrows the device tables "
+                               "(merge first, then create the task)")
         keys = list(mt.TABLE_KEYS) + ["_motion_weights", "_motion_lengths", "_motion_num_frames", "_motion_dt", "_motion_fps",
                                       "_motion_bodies", "_motion_min_verts_h"]
         for k in keys:

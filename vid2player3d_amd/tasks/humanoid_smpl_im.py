@@ -183,9 +183,12 @@ class HumanoidSMPLIM:
             ids[:] = env["motion_id"]
         if "motion_ids" in env:  # explicit clip of every env (tests)
             ids = torch.as_tensor(np.asarray(env["motion_ids"]), dtype=torch.long)
+        if ids.numel() != self.num_envs or int(ids.min()) < 0 or int(ids.max()) >= self._motion_lib.num_motions():
+            raise ValueError("motion ids must be %d values in [0, %d)" % (self.num_envs, self._motion_lib.num_motions()))
         self._reset_ref_motion_ids = ids.to(self.device).contiguous()
         self._reset_ref_motion_bodies = self._motion_lib._motion_bodies[self._reset_ref_motion_ids].to(self.device)
 
+        self._check_body_shapes(env)
         self._allocate_buffers()
         self._build_termination_heights()
         key_bodies, contact_bodies = env.get("keyBodies", []), env.get("contactBodies", [])
@@ -231,6 +234,27 @@ class HumanoidSMPLIM:
         self.actions = None
 
     # ------------------------------------------------------------------ construction helpers
+    def _check_body_shapes(self, env):
+        """The reference builds one humanoid asset per sampled clip from the clip's betas (humanoid_smpl_im.py:247-296).  A library whose
+        clips carry different betas, simulated with ONE body model, gives targets / observations / termination heights of per-beta
+        skeletons against a simulated skeleton that is not theirs: refuse unless the caller says so (cfg env body_shape_mismatch =
+        'warn' | 'ignore'); per-clip bodies go in cfg env body_model=[BodyModel, ...] (+ motion_shape_ids)."""
+        if self.body_shapes is not None and len(self.body_shapes) > 1:
+            return
+        mb = self._motion_lib._motion_bodies
+        if mb.shape[0] < 2 or bool((mb == mb[0]).all()) or getattr(self._motion_lib, "_single_skeleton", False):
+            return
+        how = env.get("body_shape_mismatch", "error")
+        msg = ("the motion library's clips carry %d different body shapes (gender + betas) but a single body model is simulated; pass one "
+               "BodyModel per clip (cfg['env']['body_model'] = [...], optionally 'motion_shape_ids') or set cfg['env']['body_shape_mismatch'] "
+               "to 'warn' / 'ignore'" % len(torch.unique(mb, dim=0)))
+        if how == "error":
+            raise RuntimeError(msg)
+        if how == "warn":
+            import warnings
+
+            warnings.warn(msg)
+
     def _load_motion(self, env):
         lib = env.get("motion_lib")
         if isinstance(lib, MotionLib):
@@ -392,6 +416,7 @@ class HumanoidSMPLIM:
                                                  C.byref(self._h_env)), "v2p_env_create_shapes")
         self._lib = lib
         self._cur = 0
+        self._motion_lib._borrowed = True  # the batch keeps the table pointers: no merge from now on
 
     def close(self):
         if getattr(self, "_h_env", None):
@@ -540,6 +565,16 @@ class HumanoidSMPLIM:
         out = torch.empty((self.num_envs, nsub, self.num_bodies, 4), dtype=torch.int32, device=self.device)
         _lib.check(self._lib.v2p_env_debug_contacts_substeps(self._h_env, _lib.ptr(out), self._stream()), "v2p_env_debug_contacts_substeps")
         return out
+
+    def profile_begin(self, max_launches):
+        """HIP events around every physics-kernel launch from now on (engine side, on the launch stream)."""
+        _lib.check(self._lib.v2p_env_profile_begin(self._h_env, int(max_launches)), "v2p_env_profile_begin")
+
+    def profile_end(self):
+        """(summed physics-kernel milliseconds, launches measured) since profile_begin; synchronises."""
+        ms, cnt = C.c_double(0.0), C.c_int64(0)
+        _lib.check(self._lib.v2p_env_profile_end(self._h_env, C.byref(ms), C.byref(cnt)), "v2p_env_profile_end")
+        return ms.value, cnt.value
 
     def debug_pairing(self):
         """(perm, key): wave-slot -> env order of the last physics launch and the contact-load key of each env after it."""
