@@ -175,8 +175,9 @@ typedef struct {
     int32_t solver_type;        /* contact solver: 0 = projected Gauss-Seidel (default), 1 = temporal Gauss-Seidel with frozen Jacobians
                                  * (sim.physx.solver_type of amass_im.yaml:41 is 1 = TGS in PhysX; see oracle/phys/v2p_phys_oracle.c for
                                  * what either means here).  Link-per-lane schedule only. */
-    int32_t debug_substep_contacts; /* 1: keep the contact vertex ids of EVERY substep (v2p_env_debug_contacts_substeps); costs
-                                     * 384 B x substeps of extra stores per env-step, off by default */
+    int32_t debug_contacts;     /* diagnostics, off (0) by default: 1 = keep the contact vertex ids of the last substep
+                                 * (v2p_env_debug_contacts; 384 B of extra stores per env-step), 2 = of EVERY substep as well
+                                 * (v2p_env_debug_contacts_substeps) */
 } v2p_sim_cfg;
 
 /* Caller-owned DEVICE buffers the engine reads/writes; these are the tensors the reference
@@ -243,10 +244,11 @@ int v2p_env_set_schedule(v2p_env* e, int schedule);
 /* index (0/1) of the CURRENT target inside v2p_env_buffers.target; the other one is the previous target */
 int v2p_env_target_index(const v2p_env* e);
 
-/* diagnostics for tests: contact vertex ids chosen in the last substep, [N,24,4] int32, body*64+vertex or -1 */
+/* diagnostics for tests: contact vertex ids chosen in the last substep, [N,24,4] int32, body*64+vertex or -1
+ * (needs v2p_sim_cfg.debug_contacts >= 1) */
 int v2p_env_debug_contacts(v2p_env* e, int32_t* out, void* stream);
 
-/* the same for every substep of the last control step, [N,substeps*control_freq_inv,24,4] (needs v2p_sim_cfg.debug_substep_contacts) */
+/* the same for every substep of the last control step, [N,substeps*control_freq_inv,24,4] (needs v2p_sim_cfg.debug_contacts == 2) */
 int v2p_env_debug_contacts_substeps(v2p_env* e, int32_t* out, void* stream);
 
 /* diagnostics for tests: the wave-slot -> env order used by the last physics launch (`perm`, [N] int32; envs are handed to

@@ -31,6 +31,7 @@ def synth_tables(seed=7, num_clips=16, min_frames=60, max_frames=200):
 
 
 def make_task(num_envs, motion_lib, motion_ids=None, **env_overrides):
+    env_overrides.setdefault("debug_contacts", 1)  # tests look at the selected contact vertices
     env_overrides.setdefault("body_shape_mismatch", "ignore")  # the golden libraries carry per-clip betas over one baked body on purpose
     cfg = default_cfg(num_envs, motion_lib=motion_lib, **env_overrides)
     if motion_ids is None:

@@ -49,7 +49,7 @@ def selection_report(hip_ids, own_ids, margin, what, min_rate=0.99):
 
 def _perturbed_task(mlib, n, contact, rng, lift, vel_sigma, hold, shapes, **env):
     extra = {} if shapes is None else {"body_model": shapes}
-    task = make_task(n, mlib, enable_contact=contact, residual_force_hold=hold, debug_substep_contacts=True, **extra, **env)
+    task = make_task(n, mlib, enable_contact=contact, residual_force_hold=hold, debug_contacts=2, **extra, **env)
     times = T(rng.uniform(0.1, 1.0, size=n))
     task.reset_with_times(None, times)
     # perturb the reference state so that the drives, Coriolis terms and contacts all have work to do
@@ -198,7 +198,7 @@ def _epoch_against_oracles(lib, tabs, n, steps, seed, sigma, **env):
     the one-step tolerances on EVERY env, and the task oracle continues from the ORACLE's result with its own sticky buffers:
     rewards to 1e-3, reset / terminate / progress flags flag for flag at every step."""
     rng = np.random.default_rng(seed)
-    task = make_task(n, lib, debug_substep_contacts=True, **env)
+    task = make_task(n, lib, debug_contacts=2, **env)
     bm = task.body_model
     times = rng.uniform(0.05, 0.6, size=n).astype(np.float32)
     task.reset_with_times(None, T(times))

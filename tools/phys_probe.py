@@ -8,7 +8,7 @@ from vid2player3d_amd.tasks import HumanoidSMPLIM, default_cfg
 
 
 def run(n, iters, contact, steps=64, fall=True):
-    cfg = default_cfg(n, synthetic_motions={"seed": 7, "num_clips": 64}, enable_contact=contact)
+    cfg = default_cfg(n, debug_contacts=1, synthetic_motions={"seed": 7, "num_clips": 64}, enable_contact=contact)
     cfg["sim"]["physx"]["num_position_iterations"] = iters
     task = HumanoidSMPLIM(cfg, device_type="cuda", device_id=0)
     g = torch.Generator(device=task.device); g.manual_seed(1)

@@ -1,0 +1,57 @@
+// VALU issue model of one gfx950 SIMD: throughput of independent / dependent v_fma_f32 and v_pk_fma_f32 streams at 1, 2, 4 waves per SIMD.
+// Build: hipcc --offload-arch=gfx950 -O3 -o valu_issue valu_issue.hip ; run on the GPU box.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef float f2 __attribute__((ext_vector_type(2)));
+constexpr int ITER = 4096;
+
+template <int MODE> __global__ void k(float* out, float seed) {
+    float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    f2 p0{a0, a1}, p1{a2, a3}, p2{a4, a5}, p3{a6, a7}, p4{a1, a0}, p5{a3, a2}, p6{a5, a4}, p7{a7, a6};
+    const float m = 1.0000001f, c = 1e-9f;
+    const f2 m2{m, m}, c2{c, c};
+    for (int i = 0; i < ITER; ++i) {
+        if (MODE == 0) {  // 8 independent scalar fma chains
+            a0 = a0 * m + c; a1 = a1 * m + c; a2 = a2 * m + c; a3 = a3 * m + c; a4 = a4 * m + c; a5 = a5 * m + c; a6 = a6 * m + c; a7 = a7 * m + c;
+        } else if (MODE == 1) {  // one dependent chain, 8 per iteration
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a0 = a0 * m + c;
+        } else if (MODE == 2) {  // 8 independent packed chains
+            p0 = p0 * m2 + c2; p1 = p1 * m2 + c2; p2 = p2 * m2 + c2; p3 = p3 * m2 + c2; p4 = p4 * m2 + c2; p5 = p5 * m2 + c2; p6 = p6 * m2 + c2; p7 = p7 * m2 + c2;
+        } else if (MODE == 3) {  // one dependent packed chain
+#pragma unroll
+            for (int j = 0; j < 8; ++j) p0 = p0 * m2 + c2;
+        } else if (MODE == 4) {  // two dependent chains interleaved
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a0 = a0 * m + c; a1 = a1 * m + c; }
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p2.x + p3.x + p4.x + p5.x + p6.x + p7.y;
+}
+
+template <int MODE> void run(const char* name, int waves_per_simd, float* d) {
+    const int cus = 256, blocks = cus * 4 * waves_per_simd;  // one wave per block: spread over all SIMDs
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(64), 0, 0, d, 1.f);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(64), 0, 0, d, 1.f);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double insts_per_wave = 8.0 * ITER;
+    const double cyc = ms * 1e-3 * 2.4e9;  // at 2.4 GHz nominal
+    printf("%-34s waves/SIMD %d: %.3f ms  -> %.2f cycles per wave-instruction (per wave), %.2f cycles per instruction per SIMD\n", name, waves_per_simd, ms,
+           cyc / insts_per_wave, cyc / (insts_per_wave * waves_per_simd));
+}
+
+int main() {
+    float* d; hipMalloc(&d, 256 * 4 * 8 * 64 * sizeof(float));
+    for (int w : {1, 2, 4, 8}) {
+        run<0>("8 independent v_fma_f32", w, d);
+        run<1>("dependent v_fma_f32 chain", w, d);
+        run<4>("2 interleaved dependent chains", w, d);
+        run<2>("8 independent v_pk_fma_f32", w, d);
+        run<3>("dependent v_pk_fma_f32 chain", w, d);
+    }
+    return 0;
+}

@@ -40,7 +40,7 @@ class SimCfg(C.Structure):
                 ("max_episode_length", C.c_float), ("enable_early_termination", C.c_int32), ("context_length", C.c_int32),
                 ("context_padding", C.c_int32), ("term_heights", C.c_float * 24), ("body_pos_weights", C.c_float * 24),
                 ("reward_specs", C.c_float * 8), ("freeze_terminated_envs", C.c_int32), ("schedule", C.c_int32), ("pair_envs_by_load", C.c_int32),
-                ("solver_type", C.c_int32), ("debug_substep_contacts", C.c_int32)]
+                ("solver_type", C.c_int32), ("debug_contacts", C.c_int32)]
 
 
 class EnvBuffers(C.Structure):

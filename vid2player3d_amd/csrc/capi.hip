@@ -324,15 +324,15 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
     size_t N = (size_t)n;
     int rc = check_hip(hipMalloc((void**)&e->state, sizeof(float) * STATE_SLOTS * N), "hipMalloc(state)");
     if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->ctrl, sizeof(float) * CTRL_SLOTS * N), "hipMalloc(ctrl)");
-    if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->contact_ids, sizeof(int32_t) * NB * 4 * N), "hipMalloc(contact_ids)");
+    if (rc == V2P_OK && c->debug_contacts >= 1) rc = check_hip(hipMalloc((void**)&e->contact_ids, sizeof(int32_t) * NB * 4 * N), "hipMalloc(contact_ids)");
     if (rc == V2P_OK) rc = check_hip(hipMemset(e->state, 0, sizeof(float) * STATE_SLOTS * N), "hipMemset(state)");
     if (rc == V2P_OK) rc = check_hip(hipMemset(e->ctrl, 0, sizeof(float) * CTRL_SLOTS * N), "hipMemset(ctrl)");
     if (rc == V2P_OK && e->schedule == 1) rc = ensure_env_per_lane_buffers(e);
-    if (rc == V2P_OK && c->debug_substep_contacts) {
+    if (rc == V2P_OK && c->debug_contacts >= 2) {
         rc = check_hip(hipMalloc((void**)&e->contact_ids_sub, sizeof(int32_t) * NB * 4 * N * (size_t)p.nsub), "hipMalloc(contact_ids_sub)");
         if (rc == V2P_OK) rc = check_hip(hipMemset(e->contact_ids_sub, 0xff, sizeof(int32_t) * NB * 4 * N * (size_t)p.nsub), "hipMemset(contact_ids_sub)");
     }
-    if (rc == V2P_OK) rc = check_hip(hipMemset(e->contact_ids, 0xff, sizeof(int32_t) * NB * 4 * N), "hipMemset(contact_ids)");
+    if (rc == V2P_OK && e->contact_ids) rc = check_hip(hipMemset(e->contact_ids, 0xff, sizeof(int32_t) * NB * 4 * N), "hipMemset(contact_ids)");
     if (rc == V2P_OK && num_shapes > 1) {
         // per-env body shapes: the numeric tables of every shape + each shape's joint-diagonal augmentation, indexed by env_shape
         std::vector<float> aug((size_t)num_shapes * NB, 0.f);
@@ -548,6 +548,7 @@ int v2p_env_target_index(const v2p_env* e) { return e ? e->cur_target : V2P_ERR_
 
 int v2p_env_debug_contacts(v2p_env* e, int32_t* out, void* stream) {
     if (!e || !out) { set_error("v2p_env_debug_contacts: bad argument"); return V2P_ERR_INVALID; }
+    if (!e->contact_ids) { set_error("v2p_env_debug_contacts: the batch was created with v2p_sim_cfg.debug_contacts = 0"); return V2P_ERR_INVALID; }
     DeviceGuard g(e->device);
     return check_hip(hipMemcpyAsync(out, e->contact_ids, sizeof(int32_t) * NB * 4 * (size_t)e->n, hipMemcpyDeviceToDevice, (hipStream_t)stream),
                      "hipMemcpyAsync(contact_ids)");
@@ -555,7 +556,7 @@ int v2p_env_debug_contacts(v2p_env* e, int32_t* out, void* stream) {
 
 int v2p_env_debug_contacts_substeps(v2p_env* e, int32_t* out, void* stream) {
     if (!e || !out) { set_error("v2p_env_debug_contacts_substeps: bad argument"); return V2P_ERR_INVALID; }
-    if (!e->contact_ids_sub) { set_error("v2p_env_debug_contacts_substeps: the batch was created without v2p_sim_cfg.debug_substep_contacts"); return V2P_ERR_INVALID; }
+    if (!e->contact_ids_sub) { set_error("v2p_env_debug_contacts_substeps: the batch was created with v2p_sim_cfg.debug_contacts < 2"); return V2P_ERR_INVALID; }
     DeviceGuard g(e->device);
     return check_hip(hipMemcpyAsync(out, e->contact_ids_sub, sizeof(int32_t) * NB * 4 * (size_t)e->n * (size_t)e->p.nsub, hipMemcpyDeviceToDevice, (hipStream_t)stream),
                      "hipMemcpyAsync(contact_ids_sub)");

@@ -448,14 +448,14 @@ __global__ __launch_bounds__(L) void physics_kernel(PhysArgs a) {
                         float d = x.z + rr.z;
                         G(b, GCB + c) = d >= 0.f ? d / h : fmaxf(P.erp * d / h, -P.max_depen);
                         G(b, GCL + 3 * c) = 0.f; G(b, GCL + 3 * c + 1) = 0.f; G(b, GCL + 3 * c + 2) = 0.f;
-                        a.contact_ids[(e * NB + b) * 4 + c] = c < cnt ? b * 64 + sel[c] : -1;
+                        if (a.contact_ids) a.contact_ids[(e * NB + b) * 4 + c] = c < cnt ? b * 64 + sel[c] : -1;
                         if (a.contact_ids_sub) a.contact_ids_sub[((e * P.nsub + sub) * NB + b) * 4 + c] = c < cnt ? b * 64 + sel[c] : -1;
                     }
                     if (__any(cnt > 0)) touch |= 1u << b;
                 } else {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        a.contact_ids[(e * NB + b) * 4 + c] = -1;
+                        if (a.contact_ids) a.contact_ids[(e * NB + b) * 4 + c] = -1;
                         if (a.contact_ids_sub) a.contact_ids_sub[((e * P.nsub + sub) * NB + b) * 4 + c] = -1;
                     }
                 }

@@ -135,8 +135,8 @@ __device__ __forceinline__ void grp_argmax(float& v, int& k) {
     grp_arg_step<true>(v, k, grp_xor1); grp_arg_step<true>(v, k, grp_xor2); grp_arg_step<true>(v, k, grp_mirror);
 }
 
-#define LLSUB(k) do { if (a.prof) { long long t_ = clock64(); if ((blockIdx.x & 63) == 0 && lane == 0) atomicAdd((unsigned long long*)&a.prof[k], (unsigned long long)(t_ - tsub)); tsub = t_; } } while (0)
-#define LLPH(k) do { if (a.prof) { long long t_ = clock64(); if ((blockIdx.x & 63) == 0 && lane == 0) atomicAdd((unsigned long long*)&a.prof[k], (unsigned long long)(t_ - tprev)); tprev = t_; } } while (0)
+#define LLSUB(k) do { if (DIAG && a.prof) { long long t_ = clock64(); if ((blockIdx.x & 63) == 0 && lane == 0) atomicAdd((unsigned long long*)&a.prof[k], (unsigned long long)(t_ - tsub)); tsub = t_; } } while (0)
+#define LLPH(k) do { if (DIAG && a.prof) { long long t_ = clock64(); if ((blockIdx.x & 63) == 0 && lane == 0) atomicAdd((unsigned long long*)&a.prof[k], (unsigned long long)(t_ - tprev)); tprev = t_; } } while (0)
 
 #ifndef V2P_LL_WPB
 #define V2P_LL_WPB 1   // waves per workgroup (they share the LDS hull copy)
@@ -148,7 +148,9 @@ constexpr int LL_WPB = V2P_LL_WPB;
 constexpr int PARK_TAR = 0, PARK_W0 = 3, PARK_XD0 = 6, PARK_Q = 9, PARK_X = 13, PARK_SLOTS = 16;  // LDS parking slots (dwords per lane)
 // TGS: temporal Gauss-Seidel with frozen Jacobians (v2p_sim_cfg.solver_type 1; the model is stated in oracle/phys/v2p_phys_oracle.c):
 // cbias[] then holds the GAP of each point, advanced after every sweep, and the row bias is evaluated where it is used.
-template <bool CONTACT, bool MULTI, bool TGS>
+// DIAG: the per-phase cycle counters (V2P_PHASE_TIMING) and per-wave timeline stamps (V2P_WAVE_TIMES) are compiled into a separate
+// instantiation: in the production kernel they cost registers (spills) and ~2 scalar instructions per probe inside the sweep loops.
+template <bool CONTACT, bool MULTI, bool TGS, bool DIAG>
 __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(PhysArgs a) {
     const int64_t N = a.n;
     const int lane = threadIdx.x & 63;
@@ -247,9 +249,9 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
     }
 
     park_put3(PARK_TAR, tar);  // constant for the whole launch
-    long long tprev = a.prof ? clock64() : 0;
-    const long long wt0 = a.wave_times ? wall_clock64() : 0;
-    const int key_pred = a.wave_times ? a.pair_key[e] : 0;  // what the launch order was built from (diagnostics)
+    long long tprev = DIAG && a.prof ? clock64() : 0;
+    const long long wt0 = DIAG && a.wave_times ? wall_clock64() : 0;
+    const int key_pred = DIAG && a.wave_times ? a.pair_key[e] : 0;  // what the launch order was built from (diagnostics)
     int tsum = 0, tmaxs = 0;
     V3 r{0.f, 0.f, 0.f};
     int ksum = 0, kdep = 0;  // contact load of this env over the launch (pairing key)
@@ -469,7 +471,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                                (fabsf(rz0) * S->aabb_e[bo][0] + fabsf(rz1) * S->aabb_e[bo][1] + fabsf(rz2) * S->aabb_e[bo][2]);
             const bool near = valid && (zlow < coff + 1e-4f);
             int pack = 0x0fffffff;  // four 7-bit vertex slots (127 = none), manifold size in bits 28..30
-            long long tsub = a.prof ? clock64() : 0;
+            long long tsub = DIAG && a.prof ? clock64() : 0;
             const unsigned long long nball = __ballot(near);
             LLSUB(16);
             if (nball) {
@@ -483,7 +485,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                 const int myidx = __popc(nm & ((1u << lb) - 1u));  // rank of this link among the near links of its env
                 const int grp = lb >> 3, gl = lb & 7;
                 unsigned remn = nm;
-                if (a.prof && (blockIdx.x & 63) == 0 && lane == 0) atomicAdd((unsigned long long*)&a.prof[13], (unsigned long long)rounds);
+                if (DIAG && a.prof && (blockIdx.x & 63) == 0 && lane == 0) atomicAdd((unsigned long long*)&a.prof[13], (unsigned long long)rounds);
                 for (int rd = 0; rd < rounds; ++rd) {
                     unsigned cb = remn;
                     if (grp >= 1) cb &= cb - 1;
@@ -541,7 +543,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                     int ns = cntg < 4 ? cntg : 4;
                     const bool big = gon && cntg > 4;
                     if (__any(big)) {
-                        if (a.prof && (blockIdx.x & 63) == 0 && lane == 0) atomicAdd((unsigned long long*)&a.prof[15], 1ull);
+                        if (DIAG && a.prof && (blockIdx.x & 63) == 0 && lane == 0) atomicAdd((unsigned long long*)&a.prof[15], 1ull);
                         // manifold reduction: deepest, farthest from it, extreme on either side of that line
                         const int k0s = k0 < 0 ? 0 : k0;
                         const float4 u0 = hullv(v0L + k0s);
@@ -612,7 +614,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                     cbias[c] = TGS ? dz : (dz >= 0.f ? dz * ih : fmaxf(P.erp * dz * ih, -P.max_depen));
                 }
             }
-            if (last && valid && live_env && !frozen) {
+            if (a.contact_ids && last && valid && live_env && !frozen) {  // diagnostics (v2p_sim_cfg.debug_contacts)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) a.contact_ids[(e * NB + b) * 4 + c] = c < cnt ? b * 64 + sel4[c] : -1;
             }
@@ -624,14 +626,14 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
             LLSUB(18);
             const unsigned long long tb = __ballot(valid && cnt > 0);
             const unsigned m0 = (unsigned)tb, m1 = (unsigned)(tb >> 32);
-            if (a.wave_times) { const int tt = __popc(half ? m1 : m0); tsum += tt; tmaxs = tt > tmaxs ? tt : tmaxs; }
+            if (DIAG && a.wave_times) { const int tt = __popc(half ? m1 : m0); tsum += tt; tmaxs = tt > tmaxs ? tt : tmaxs; }
             if (last) {
                 const unsigned mine = half ? m1 : m0;
                 ksum = __popc(mine);
                 kdep = 0;
                 for (unsigned t = mine; t; t &= t - 1) { const int dd = M.depth[__ffs(t) - 1]; kdep = dd > kdep ? dd : kdep; }
             }
-            if (a.prof && (blockIdx.x & 63) == 0 && lane == 0) { atomicAdd((unsigned long long*)&a.prof[9], (unsigned long long)(__popc(m0) + __popc(m1))); atomicAdd((unsigned long long*)&a.prof[10], 1ull); }
+            if (DIAG && a.prof && (blockIdx.x & 63) == 0 && lane == 0) { atomicAdd((unsigned long long*)&a.prof[9], (unsigned long long)(__popc(m0) + __popc(m1))); atomicAdd((unsigned long long*)&a.prof[10], 1ull); }
             if ((m0 | m1) && P.n_iter > 0) {
                 // deepest touched link of either env: links below it are never read during the sweep, so Lambda and the
                 // per-update propagation stop there; their velocities catch up once at the end (the propagation is linear)
@@ -747,8 +749,8 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                         t0 &= t0 - 1;
                         t1 &= t1 - 1;
                         int last0 = b0, last1 = b1;
-                        long long tsub = a.prof ? clock64() : 0;
-                        if (a.prof && (blockIdx.x & 63) == 0 && lane == 0) atomicAdd((unsigned long long*)&a.prof[8], 1ull);
+                        long long tsub = DIAG && a.prof ? clock64() : 0;
+                        if (DIAG && a.prof && (blockIdx.x & 63) == 0 && lane == 0) atomicAdd((unsigned long long*)&a.prof[8], 1ull);
                         V3 un{0.f, 0.f, 0.f}, uf{0.f, 0.f, 0.f};
                         V3 Dw{0.f, 0.f, 0.f}, Dv{0.f, 0.f, 0.f};  // velocity change of the link just solved due to the group's impulses so far
                         for (int step = 0;; ++step) {
@@ -814,7 +816,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                         LLSUB(11);
                         // an update that changed no impulse (separated or saturated points) moves nothing: skip the propagation
                         if (!__any(un.x != 0.f || un.y != 0.f || un.z != 0.f || uf.x != 0.f || uf.y != 0.f || uf.z != 0.f)) {
-                            if (a.prof && (blockIdx.x & 63) == 0 && lane == 0) atomicAdd((unsigned long long*)&a.prof[19], 1ull);
+                            if (DIAG && a.prof && (blockIdx.x & 63) == 0 && lane == 0) atomicAdd((unsigned long long*)&a.prof[19], 1ull);
                             continue;
                         }
                         moved = true;
@@ -954,7 +956,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
             xd = pxd + cross(pw, rr);
         }
     }
-    if (a.wave_times && lane == 0) {
+    if (DIAG && a.wave_times && lane == 0) {
         long long* wt = a.wave_times + ((int64_t)blockIdx.x * LL_WPB + (threadIdx.x >> 6)) * 4;
         wt[0] = wt0; wt[1] = wall_clock64(); wt[2] = ksum * 8 + kdep + 1024 * (long long)tsum + 1048576ll * tmaxs + 1073741824ll * key_pred;
         unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); wt[3] = hw;
@@ -996,6 +998,12 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
             if (lane == 0) *a.pair_done = 0;
         }
     }
+    // the output addresses are formed here, from an index the compiler cannot trace back to the prologue: computed up front they were
+    // kept across the whole kernel as spilled 64-bit pointers (36 B of scratch per lane = 9 MB of HBM traffic per launch)
+    int64_t e_out = e;
+    asm volatile("" : "+v"(e_out));
+    {
+    const int64_t e = e_out;
     if (valid && live_env) {
         if (b == 0) {
             st[SIDX(ST_ROOT_QUAT + 0)] = q.x; st[SIDX(ST_ROOT_QUAT + 1)] = q.y; st[SIDX(ST_ROOT_QUAT + 2)] = q.z; st[SIDX(ST_ROOT_QUAT + 3)] = q.w;
@@ -1011,12 +1019,6 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
             float* od = a.x_dof + (e * NDOF + 3 * (b - 1)) * 2;
             od[0] = qe.x; od[1] = wt.x; od[2] = qe.y; od[3] = wt.y; od[4] = qe.z; od[5] = wt.z;
         }
-        // rigid-body state row of this link (and the root state = rigid body 0): 13 contiguous floats per lane
-        float* ob = a.x_rb + (e * NB + b) * 13;
-        ob[0] = x.x; ob[1] = x.y; ob[2] = x.z;
-        ob[3] = q.x; ob[4] = q.y; ob[5] = q.z; ob[6] = q.w;
-        ob[7] = xd.x; ob[8] = xd.y; ob[9] = xd.z;
-        ob[10] = w.x; ob[11] = w.y; ob[12] = w.z;
         if (b == 0) {
             float* orr = a.x_root + e * 13;
             orr[0] = x.x; orr[1] = x.y; orr[2] = x.z;
@@ -1024,6 +1026,29 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
             orr[7] = xd.x; orr[8] = xd.y; orr[9] = xd.z;
             orr[10] = w.x; orr[11] = w.y; orr[12] = w.z;
         }
+    }
+    // rigid-body state [24][13] of the env: a lane's row is 13 dwords at a 52-byte stride, which as 13 scalar stores per lane left the
+    // L2 with partial lines from two XCDs' worth of neighbours (PMC WRITE_SIZE 1.7x the bytes).  The rows are staged through the
+    // (now idle) LDS parking area and leave as 78 contiguous 16-byte stores per env: full lines.
+    {
+        float* const stage = park_all + (threadIdx.x >> 6) * (PARK_SLOTS * 64) + half * (NB * 13);
+        if (valid) {
+            float* o = stage + b * 13;
+            o[0] = x.x; o[1] = x.y; o[2] = x.z;
+            o[3] = q.x; o[4] = q.y; o[5] = q.z; o[6] = q.w;
+            o[7] = xd.x; o[8] = xd.y; o[9] = xd.z;
+            o[10] = w.x; o[11] = w.y; o[12] = w.z;
+        }
+        if (live_env) {
+            const float4* src = (const float4*)stage;
+            float4* dst = (float4*)(a.x_rb + e * NB * 13);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int j = lb + 32 * r;
+                if (j < NB * 13 / 4) dst[j] = src[j];
+            }
+        }
+    }
     }
 }
 
@@ -1136,15 +1161,18 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s, float* actions) {
     const dim3 grid(blocks), block(64 * LL_WPB);
     const size_t lds = sizeof(float) * PARK_SLOTS * 64 * LL_WPB;
     const bool tgs = env->p.solver_type == 1;
-    if (env->p.enable_contact && tgs) {
-        if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, true>), grid, block, lds, s, a);
-        else hipLaunchKernelGGL((physics_ll_kernel<true, false, true>), grid, block, lds, s, a);
+    const bool diag = a.prof || a.wave_times;
+    if (diag && env->p.enable_contact && !tgs && !multi) {  // the instrumented build exists for the headline configuration only
+        hipLaunchKernelGGL((physics_ll_kernel<true, false, false, true>), grid, block, lds, s, a);
+    } else if (env->p.enable_contact && tgs) {
+        if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, true, false>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((physics_ll_kernel<true, false, true, false>), grid, block, lds, s, a);
     } else if (env->p.enable_contact) {
-        if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, false>), grid, block, lds, s, a);
-        else hipLaunchKernelGGL((physics_ll_kernel<true, false, false>), grid, block, lds, s, a);
+        if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, false, false>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((physics_ll_kernel<true, false, false, false>), grid, block, lds, s, a);
     } else {
-        if (multi) hipLaunchKernelGGL((physics_ll_kernel<false, true, false>), grid, block, lds, s, a);
-        else hipLaunchKernelGGL((physics_ll_kernel<false, false, false>), grid, block, lds, s, a);
+        if (multi) hipLaunchKernelGGL((physics_ll_kernel<false, true, false, false>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((physics_ll_kernel<false, false, false, false>), grid, block, lds, s, a);
     }
     env->pair_have = paired ? 1 : 0;
     return check_hip(hipGetLastError(), "physics_ll_kernel");

@@ -360,7 +360,7 @@ class HumanoidSMPLIM:
         # contact solver of the engine's own physics model: "pgs" (default) or "tgs" (sim.physx.solver_type 1 of amass_im.yaml:41 names
         # PhysX's TGS; the engine's TGS restates the published algorithm with frozen Jacobians, see oracle/phys/v2p_phys_oracle.c)
         c.solver_type = {"pgs": 0, "tgs": 1}[env.get("contact_solver", "pgs")]
-        c.debug_substep_contacts = int(env.get("debug_substep_contacts", False))
+        c.debug_contacts = int(env.get("debug_contacts", 0))  # 0 off, 1 last substep's contact vertices kept, 2 every substep's
         hold = env.get("residual_force_hold", "first_sim")
         c.residual_hold_sims = 1 if hold == "first_sim" else self.control_freq_inv
         c.gravity_z = sp.gravity[2]
@@ -560,7 +560,7 @@ class HumanoidSMPLIM:
         return out
 
     def debug_contacts_substeps(self):
-        """[N, substeps of a control step, 24, 4] contact vertex ids of every substep of the last step (cfg env debug_substep_contacts)."""
+        """[N, substeps of a control step, 24, 4] contact vertex ids of every substep of the last step (cfg env debug_contacts = 2)."""
         nsub = self.sim_params.substeps * self.control_freq_inv
         out = torch.empty((self.num_envs, nsub, self.num_bodies, 4), dtype=torch.int32, device=self.device)
         _lib.check(self._lib.v2p_env_debug_contacts_substeps(self._h_env, _lib.ptr(out), self._stream()), "v2p_env_debug_contacts_substeps")
