@@ -202,6 +202,48 @@ def profiles_view():
     return valu, traffic
 
 
+def run_ppo(args, task, dist, world, rank):
+    """BASELINE config 5 (per GPU: --num-envs envs, horizon 32, the amass_im.yaml MLP and PPO hyper-parameters): epochs of
+    play_steps + update; the reference's meters `fps step` = frames / T_play and `fps total` = frames / (T_play + T_update)
+    (im_agent.py:204-214), whole job = sum over ranks of frames over the slowest rank's time."""
+    from vid2player3d_amd.ppo import PPOAgent
+
+    agent = PPOAgent(task, seed=7)
+    agent.train_epoch()  # warm-up epoch (allocator, rocBLAS heuristics, running statistics)
+    rows = []
+    for _ in range(args.ppo_epochs):
+        r = agent.train_epoch()
+        rows.append(r)
+        if rank == 0:
+            sys.stderr.write(agent.format_epoch_line(r) + "\n")
+    play = sum(r["play_time"] for r in rows)
+    total = sum(r["total_time"] for r in rows)
+    frames = sum(r["frames"] for r in rows)
+    if dist is not None:
+        t = torch.tensor([play, total], device=task.device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        play, total = float(t[0]), float(t[1])
+    if rank == 0:
+        from vid2player3d_amd import build
+        out = {"metric": "env-steps/sec at num_envs=8192, SMPL humanoid imitation", "value": world * frames / total, "unit": "env-steps/s", "n_gpus": world,
+               "steps": args.ppo_epochs * HORIZON, "warmup": HORIZON, "ms_per_step": 1e3 * total / (args.ppo_epochs * HORIZON), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "FULL PPO LOOP (BASELINE config 5 shape, reported separately from the rollout metric): amass_im num_envs=%d per GPU, "
+                                      "horizon 32, actor/critic MLP [1024,1024,512] on the 734-d observation, 6 mini-epochs x minibatches of 512 envs; value = fps total"
+                                      % args.num_envs,
+                          "num_envs_per_gpu": args.num_envs, "global_envs": world * args.num_envs,
+                          "parallelism": "env-sharded x%d; advantage statistics, running norms and gradients all-reduced over RCCL at the update" % world,
+                          "fps_step": world * frames / play, "fps_total": world * frames / total,
+                          "T_play_s_per_epoch": play / args.ppo_epochs, "T_update_s_per_epoch": (total - play) / args.ppo_epochs,
+                          "step_rewards_last_epoch": rows[-1]["step_rewards"], "alive_ratio_last_epoch": rows[-1]["alive_ratio"]},
+               "build": build.build_info()}
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -215,6 +257,8 @@ def main():
     ap.add_argument("--freeze-terminated", action="store_true", help="opt-in engine feature: terminated envs are not simulated until the epoch reset (not reference behaviour)")
     ap.add_argument("--djokovic", action="store_true", help="BASELINE config 4 (djokovic_im.yaml: terminationHeadHeight -0.5, faster clips)")
     ap.add_argument("--per-clip-shapes", action="store_true", help="one body shape per clip (64 scaled bodies) instead of one shape for all envs")
+    ap.add_argument("--ppo", action="store_true", help="BASELINE config 5 loop: device-resident rollout (play_steps) + GAE + PPO update per epoch; prints the reference's fps step / fps total")
+    ap.add_argument("--ppo-epochs", type=int, default=4, help="timed PPO epochs (after one untimed warm-up epoch)")
     ap.add_argument("--stub-task", action="store_true", help=argparse.SUPPRESS)  # launch-logic test without GPUs (gloo, CPU); never a measurement
     args = ap.parse_args()
 
@@ -256,6 +300,8 @@ def main():
             dist.barrier()
         task = build_task(n, local_rank, seed=7 + rank, contact=not args.no_contact, per_clip_shapes=args.per_clip_shapes, djokovic=args.djokovic,
                           freeze=args.freeze_terminated, solver=args.solver)  # per-rank seed like run.py:37
+    if args.ppo:
+        return run_ppo(args, task, dist, world, rank)
     dev = task.device
     gen = torch.Generator(device=dev)
     gen.manual_seed(7 + rank)
