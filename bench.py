@@ -83,11 +83,11 @@ def build_task(num_envs, device_id, seed, contact=True, per_clip_shapes=False, d
     if djokovic:  # BASELINE config 4 = cfg/djokovic_im.yaml: same task class, head termination height -0.5, faster (tennis-like) clips
         cfg["env"]["terminationHeadHeight"] = -0.5
         cfg["env"]["synthetic_motions"]["speed"] = 2.0
-    if per_clip_shapes:  # one body shape per clip like the reference's per-clip SMPL assets: 64 uniformly scaled bodies, 0.85 .. 1.15
+    if per_clip_shapes:  # one body shape per clip like the reference's per-clip SMPL assets: 64 non-uniform shapes built from vertex clouds
+        from vid2player3d_amd import body_shapes
         from vid2player3d_amd.model import load_baked_model
 
-        base = load_baked_model()
-        cfg["env"]["body_model"] = [base.scaled(0.85 + 0.3 * k / 63.0) for k in range(64)]
+        cfg["env"]["body_model"] = body_shapes.synthetic_shape_family(load_baked_model(), 64, seed=7)
     torch.manual_seed(seed)
     return HumanoidSMPLIM(cfg, device_type="cuda", device_id=device_id)
 
@@ -363,7 +363,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "amass_im num_envs=%d per GPU, %s, imitation reward, per-epoch reset+context every %d steps, 64 synthetic clips, action noise %.3g%s"
                                    % (n, "PD control only (no contact solve)" if args.no_contact else "full contact %s (4 substeps x 4 iterations)" % args.solver.upper(), HORIZON,
-                                      args.action_noise, (", one body shape per clip" if args.per_clip_shapes else "") + (", djokovic_im variant" if args.djokovic else "") +
+                                      args.action_noise, (", one NON-UNIFORM body shape per clip (64 shapes from vertex clouds)" if args.per_clip_shapes else "") + (", djokovic_im variant" if args.djokovic else "") +
                                       (", TERMINATED ENVS FROZEN (not reference behaviour)" if args.freeze_terminated else "") + (", STUB TASK (launch-logic test, not a measurement)" if stub else "")),
                        "num_envs_per_gpu": n, "global_envs": world * n, "parallelism": "env-sharded x%d, no data-path collective" % world,
                        "world_size_seen": world_seen, "backend": None if dist is None else ("gloo" if stub else "nccl(rccl)"),

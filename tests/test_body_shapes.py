@@ -1,0 +1,77 @@
+"""Per-clip body assets, geometry half (vid2player3d_amd/body_shapes.py): the own convex hull against scipy's qhull
+(the reference's `ConvexHull`, smpl_local_robot.py:103), mass properties of hulls, hull reduction to the engine's vertex limit,
+non-uniform shape variants."""
+import numpy as np
+import pytest
+from scipy.spatial import ConvexHull
+
+from vid2player3d_amd import body_shapes as bs
+from vid2player3d_amd.model import hull_mass_properties, load_baked_model
+
+
+@pytest.mark.parametrize("seed,n,aniso", [(0, 40, (1, 1, 1)), (1, 300, (1.0, 0.3, 2.0)), (2, 1500, (0.2, 0.2, 1.0)), (3, 8, (1, 1, 1))])
+def test_convex_hull_matches_qhull(seed, n, aniso):
+    rng = np.random.default_rng(seed)
+    pts = rng.normal(size=(n, 3)) * np.array(aniso) + rng.normal(size=3)
+    vid, faces = bs.convex_hull(pts)
+    ref = ConvexHull(pts)
+    assert np.array_equal(vid, np.sort(ref.vertices))
+    assert len(faces) == len(ref.simplices)  # simplicial hulls of points in general position: same triangulation size
+    # outward winding: every point is behind every face
+    a, b, c = (pts[faces[:, k]] for k in range(3))
+    nrm = np.cross(b - a, c - a)
+    assert ((pts[None, :, :] - a[:, None, :]) * nrm[:, None, :]).sum(-1).max() < 1e-9
+    m, com, inertia = bs.hull_mass_properties_faces(pts, faces, density=900.0)
+    assert abs(m - 900.0 * ref.volume) < 1e-9 * m
+    m2, com2, inertia2, _ = hull_mass_properties(pts, 900.0)  # the scipy-based integration the MJCF compiler uses
+    assert np.allclose(com, com2, atol=1e-10) and np.allclose(inertia, inertia2, rtol=1e-9, atol=1e-12)
+
+
+def test_hull_handles_coplanar_and_duplicate_points():
+    cube = np.array([[x, y, z] for x in (0, 1) for y in (0, 1) for z in (0, 2)], dtype=np.float64)
+    extra = np.array([[0.5, 0.5, 0.0], [0.5, 0.0, 1.0], [0.5, 0.5, 1.0], [1.0, 1.0, 2.0]])  # face centres, an interior point, a duplicate corner
+    vid, faces = bs.convex_hull(np.concatenate([cube, extra]))
+    assert set(vid.tolist()) <= set(range(8)) | {11} and len(set(map(tuple, np.concatenate([cube, extra])[vid]))) == 8
+    m, com, inertia = bs.hull_mass_properties_faces(np.concatenate([cube, extra]), faces, density=1.0)
+    assert abs(m - 2.0) < 1e-12 and np.allclose(com, [0.5, 0.5, 1.0])
+    assert np.allclose(np.diag(inertia), [2.0 * (1 + 4) / 12, 2.0 * (1 + 4) / 12, 2.0 * (1 + 1) / 12])
+    with pytest.raises(ValueError):
+        bs.convex_hull(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0.0], [0.3, 0.3, 0]]))
+
+
+def test_reduce_hull_keeps_the_extent():
+    rng = np.random.default_rng(5)
+    pts = rng.normal(size=(2000, 3)) * np.array([0.05, 0.08, 0.2])
+    keep = bs.reduce_hull(pts, 64)
+    assert len(keep) <= 64 and len(keep) > 40
+    full = pts[bs.convex_hull(pts)[0]]
+    d = bs.fibonacci_directions(500)
+    assert ((full @ d.T).max(0) - (pts[keep] @ d.T).max(0)).max() < 0.012  # support function within ~1 cm on a 20 cm body
+    v_full, v_red = ConvexHull(full).volume, ConvexHull(pts[keep]).volume
+    assert 0.85 < v_red / v_full <= 1.0 + 1e-12
+
+
+def test_identity_deformation_reproduces_the_baked_body():
+    base = load_baked_model()
+    same = bs.deform(base)
+    assert np.allclose(same.local_pos, base.local_pos)
+    assert abs(same.total_mass / base.total_mass - 1.0) < 1e-6
+    assert np.allclose(same.com, base.com, atol=1e-6) and np.allclose(same.inertia, base.inertia, rtol=1e-5, atol=1e-9)
+    assert np.array_equal(same.hull_offsets, base.hull_offsets)
+
+
+def test_shape_family_is_non_uniform():
+    base = load_baked_model()
+    fam = bs.synthetic_shape_family(base, 6, seed=3)
+    ratios, legs = [], []
+    for m in fam:
+        assert m.num_bodies == 24 and np.diff(m.hull_offsets).max() <= 64 and np.diff(m.hull_offsets).min() >= 4
+        assert np.all(np.linalg.eigvalsh(m.inertia) > 0)
+        ratios.append(m.mass[base.body_index("Torso")] / m.mass[base.body_index("L_Knee")])
+        legs.append(np.linalg.norm(m.local_pos[base.body_index("L_Knee")]) / np.linalg.norm(m.local_pos[base.body_index("L_Elbow")]))
+        assert abs(m.kp[0] / base.kp[0] - m.total_mass / base.total_mass) < 1e-9  # gains follow the mass (humanoid_smpl_im.py:376-385)
+    # not copies of one body at different sizes: mass ratios between bodies and limb proportions change from shape to shape
+    assert np.ptp(ratios) / np.mean(ratios) > 0.1 and np.ptp(legs) / np.mean(legs) > 0.03
+    assert len({tuple(np.diff(m.hull_offsets)) for m in fam}) == len(fam)  # non-affine: every shape has its own hull topology
+    uni = base.scaled(1.1)
+    assert abs(uni.mass[9] / uni.mass[2] - base.mass[9] / base.mass[2]) < 1e-12  # (what uniform scaling cannot do)

@@ -401,6 +401,23 @@ def test_per_env_body_shapes_match_oracle():
     t.close()
 
 
+def test_non_uniform_body_shapes_match_oracle():
+    """Per-clip assets from vertex clouds (body_shapes.py: own hulls, reduced to <= 64 vertices, hull-integrated mass properties):
+    eight NON-uniform shapes - limb proportions, girth, shoulder width differ, so hull topology and mass ratios do - one per clip;
+    every env against the oracle of its own shape, with and without contacts."""
+    from vid2player3d_amd import body_shapes, synth
+    from vid2player3d_amd.model import load_baked_model
+    from vid2player3d_amd.motion_lib import MotionLib
+
+    base = load_baked_model()
+    shapes = body_shapes.synthetic_shape_family(base, 8, seed=1)
+    assert len({tuple(np.diff(m.hull_offsets)) for m in shapes}) > 1  # different vertex counts per body: different hull topology
+    lib = MotionLib.from_clips(synth.make_clips(6, 8, 60, 120), shapes, DEV)
+    for contact, lift, seed in ((False, 0.0, 51), (True, -0.05, 52), (True, -0.7, 53)):
+        (got, ref), = _run_pair(lib, 48, contact, seed, lift=lift, shapes=shapes, what="non-uniform shapes")
+        _compare(got, ref, "non-uniform shapes contact=%s lift=%.2f" % (contact, lift), contact=contact, tol_force=2e-2 if lift < -0.5 else TOL_FORCE)
+
+
 def test_fused_step_equals_staged_step(mlib):
     """v2p_env_step (pre-physics inside the physics kernel's prologue, compiled with precise semantics there) against pre_physics +
     physics + post_physics as separate kernels: bit-identical state, observations, rewards and masks over 3 steps; dead envs get
