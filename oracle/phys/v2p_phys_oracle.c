@@ -72,6 +72,23 @@ typedef struct {
     int solver_type;       /* 0 = PGS (default), 1 = TGS (see the substep) */
 } v2p_oparams;
 
+/* ---- racket + ball (vid2player/env/tasks/humanoid_smpl_im_mvae.py:367-442, 711-783; data/assets/tennis_ball.urdf,
+ * smpl_mesh_humanoid_djokovic.xml:188-190).  The racket is welded to a link of the articulation (its mass is part of that link's
+ * body model, its two cylinders are given here in the link's frame); the ball is a free sphere.  Modelled contacts: ball-ground
+ * and ball-racket (sphere against the two solid cylinders); ball against the humanoid's hulls is NOT modelled. */
+typedef struct { double center[3], axis[3], half_len, radius; } v2p_ocyl;
+typedef struct {
+    double radius, mass, inertia;   /* 0.032, 0.057, 4e-5 (tennis_ball.urdf) */
+    double rest_ground, fric_ground; /* ball x plane, PhysX default combine = average: (1.0 + 0.0) / 2, (0.8 + 1.0) / 2 */
+    double rest_racket, fric_racket; /* ball x racket head: 1.0, 0.8 (humanoid_smpl_im_mvae.py:414-416, 436-438) */
+    double bounce_threshold;         /* 0.2 m/s (sim.physx.bounce_threshold_velocity) */
+    double ang_damp, max_ang_vel;    /* AssetOptions defaults of the ball asset: 0.5, 64 */
+    int racket_link;                 /* 22 = R_Wrist */
+    int ncyl;
+    v2p_ocyl cyl[2];
+} v2p_oball_params;
+typedef struct { double pos[3], quat[4], vel[3], angvel[3]; } v2p_oball;
+
 /* optional per-substep inputs / outputs for the parity tests (all nullable) */
 typedef struct {
     const int *forced_ids; /* [NB*4] in: use these hull vertices (body*64+vertex, -1 = none) instead of the selection rule */
@@ -85,6 +102,9 @@ typedef struct {
     double jquat[NJ][4];  /* parent->child, xyzw */
     double vel[ND];
 } v2p_ostate;
+
+int v2p_oracle_substep_io(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s, const double *pd_target, const double *ext_force,
+                          const double *ext_torque, double *contact_force, double *dof_force, int *contact_ids, const v2p_osub_io *io);
 
 /* ------------------------------------------------------------------ small helpers */
 static void cross(const double a[3], const double b[3], double o[3]) {
@@ -422,10 +442,45 @@ static void gen_contacts(const v2p_omodel *m, const v2p_oparams *p, const kin_t 
 }
 
 /* ------------------------------------------------------------------ one substep */
-int v2p_oracle_substep_io(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s, const double *pd_target /*[69]*/,
-                          const double *ext_force /*[3] world, at root COM*/, const double *ext_torque /*[3] world*/,
-                          double *contact_force /*[NB*3] out*/, double *dof_force /*[69] out*/, int *contact_ids /*[NB*4] out: body*64+vertex, -1 padded*/,
-                          const v2p_osub_io *io) {
+/* closest point of a solid cylinder (centre c, unit axis a, half length hl, radius rc) to the point s; returns the distance */
+static double cyl_closest(const double c[3], const double a[3], double hl, double rc, const double s[3], double pt[3], double n[3]) {
+    double d[3] = {s[0] - c[0], s[1] - c[1], s[2] - c[2]};
+    double t = dot3(d, a);
+    double q[3] = {d[0] - t * a[0], d[1] - t * a[1], d[2] - t * a[2]};
+    double rho = sqrt(dot3(q, q));
+    double tc = t > hl ? hl : (t < -hl ? -hl : t);
+    double k = rho > rc ? rc / rho : 1.0;
+    for (int i = 0; i < 3; ++i) pt[i] = c[i] + tc * a[i] + k * q[i];
+    double e[3] = {s[0] - pt[0], s[1] - pt[1], s[2] - pt[2]};
+    double dist = sqrt(dot3(e, e));
+    if (dist > 1e-9) { for (int i = 0; i < 3; ++i) n[i] = e[i] / dist; }
+    else { double sg = t >= 0 ? 1.0 : -1.0; for (int i = 0; i < 3; ++i) n[i] = sg * a[i]; } /* centre inside the solid: leave through the nearer cap */
+    return dist;
+}
+/* tangent basis of a contact normal (the same rule in the kernel): t1 = normalize(n x z) unless n is within 1e-3 of +-z, then n x x */
+static void tangent_basis(const double n[3], double t1[3], double t2[3]) {
+    const double ez[3] = {0, 0, 1}, ex[3] = {1, 0, 0};
+    cross(n, ez, t1);
+    if (dot3(t1, t1) < 1e-6) cross(n, ex, t1);
+    double l = sqrt(dot3(t1, t1));
+    for (int i = 0; i < 3; ++i) t1[i] /= l;
+    cross(n, t1, t2);
+}
+
+#define NDT (ND + 6) /* generalized velocity with the ball appended: [articulation ND | ball linear 3 | ball angular 3] */
+typedef struct {
+    int kind;     /* 0 hull vertex x ground, 1 ball x racket cylinder, 2 ball x ground */
+    int body, vert;
+    double pos[3]; /* contact point, world */
+    double n[3], t1[3], t2[3];
+    double gap, mu, rest;
+} crow_t;
+
+static int substep_impl(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s, const double *pd_target /*[69]*/,
+                        const double *ext_force /*[3] world, at root COM*/, const double *ext_torque /*[3] world*/,
+                        double *contact_force /*[NB*3] out*/, double *dof_force /*[69] out*/, int *contact_ids /*[NB*4] out: body*64+vertex, -1 padded*/,
+                        const v2p_osub_io *io, const v2p_oball_params *bp, v2p_oball *ball, const double *ball_force /*[3] world*/,
+                        double *ball_contact /*[6] out: force on the ball from the racket, from the ground*/) {
     double M[ND * ND], C[ND], J[6 * ND];
     double rhs[ND], q[3 * NJ];
     kin_t k;
@@ -452,50 +507,127 @@ int v2p_oracle_substep_io(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate 
     }
     if (cholesky(M, ND)) return -1;
     chol_solve(M, ND, rhs);
-    double v[ND];
+    double v[NDT];
     for (int i = 0; i < ND; ++i) v[i] = s->vel[i] + h * rhs[i];
+    for (int i = ND; i < NDT; ++i) v[i] = 0.0;
+    if (ball) { /* free flight of the ball: gravity + the aerodynamic force held over this simulate() call */
+        if (p->solver_type != 0) return -2; /* the ball rows are stated for PGS only */
+        for (int i = 0; i < 3; ++i) {
+            v[ND + i] = ball->vel[i] + h * ((i == 2 ? p->gravity_z : 0.0) + (ball_force ? ball_force[i] / bp->mass : 0.0));
+            v[ND + 3 + i] = ball->angvel[i];
+        }
+    }
 
     /* contacts */
     if (contact_force) memset(contact_force, 0, sizeof(double) * NB * 3);
+    if (ball_contact) memset(ball_contact, 0, sizeof(double) * 6);
     if (contact_ids) for (int i = 0; i < NB * 4; ++i) contact_ids[i] = -1;
     if (p->enable_contact) {
         contacts_t cs;
         gen_contacts(m, p, &k, &cs, io);
-        int nrow = cs.n * 3;
-        /* one heap block per substep for the row matrices (up to 2 x 288 x 75 doubles) */
-        double *Jr = calloc((size_t)(nrow > 0 ? nrow : 1) * (2 * ND + 3), sizeof(double));
-        double *Tr = Jr + (size_t)(nrow > 0 ? nrow : 1) * ND;
-        double *wii = Tr + (size_t)(nrow > 0 ? nrow : 1) * ND;
+        /* row list in Gauss-Seidel order: bodies ascending with their hull points in slot order; the ball-racket points right after the
+         * hull points of the racket's link; the ball-ground point last */
+        crow_t rows[NB * MAXC_BODY + 3];
+        int nc = 0, ci = 0;
+        for (int b = 0; b < NB; ++b) {
+            for (; ci < cs.n && cs.body[ci] == b; ++ci) {
+                crow_t *r = &rows[nc++];
+                r->kind = 0; r->body = b; r->vert = cs.vert[ci];
+                memcpy(r->pos, cs.pos[ci], sizeof(double) * 3);
+                r->n[0] = 0; r->n[1] = 0; r->n[2] = 1; r->t1[0] = 1; r->t1[1] = 0; r->t1[2] = 0; r->t2[0] = 0; r->t2[1] = 1; r->t2[2] = 0;
+                r->gap = cs.pos[ci][2]; r->mu = p->mu; r->rest = 0.0;
+            }
+            if (ball && b == bp->racket_link)
+                for (int j = 0; j < bp->ncyl; ++j) {
+                    double cw[3], aw[3], pt[3], n[3];
+                    matvec(k.R[b], bp->cyl[j].center, cw);
+                    matvec(k.R[b], bp->cyl[j].axis, aw);
+                    for (int i = 0; i < 3; ++i) cw[i] += k.x[b][i];
+                    double dist = cyl_closest(cw, aw, bp->cyl[j].half_len, bp->cyl[j].radius, ball->pos, pt, n) - bp->radius;
+                    /* speculative margin: a 50 m/s ball covers 0.4 m per substep, the head is 4 cm thick.  The point becomes a contact
+                     * when the ball can reach it within this substep at the closing speed of the start of the substep; the row's
+                     * gap / h bias then lets it approach exactly up to the surface */
+                    double rl[3] = {pt[0] - k.x[b][0], pt[1] - k.x[b][1], pt[2] - k.x[b][2]}, wr[3];
+                    cross(k.w[b], rl, wr);
+                    double vrel = 0;
+                    for (int i = 0; i < 3; ++i) vrel += (ball->vel[i] - k.xd[b][i] - wr[i]) * n[i];
+                    if (dist < p->contact_offset + h * fmax(0.0, -vrel)) {
+                        crow_t *r = &rows[nc++];
+                        r->kind = 1; r->body = b; r->vert = j;
+                        memcpy(r->pos, pt, sizeof(pt)); memcpy(r->n, n, sizeof(n));
+                        tangent_basis(n, r->t1, r->t2);
+                        r->gap = dist; r->mu = bp->fric_racket; r->rest = bp->rest_racket;
+                    }
+                }
+        }
+        if (ball && ball->pos[2] - bp->radius < p->contact_offset + h * fmax(0.0, -ball->vel[2])) {
+            crow_t *r = &rows[nc++];
+            r->kind = 2; r->body = -1; r->vert = 0;
+            r->pos[0] = ball->pos[0]; r->pos[1] = ball->pos[1]; r->pos[2] = ball->pos[2] - bp->radius;
+            r->n[0] = 0; r->n[1] = 0; r->n[2] = 1; r->t1[0] = 1; r->t1[1] = 0; r->t1[2] = 0; r->t2[0] = 0; r->t2[1] = 1; r->t2[2] = 0;
+            r->gap = ball->pos[2] - bp->radius; r->mu = bp->fric_ground; r->rest = bp->rest_ground;
+        }
+        int nrow = nc * 3;
+        /* one heap block per substep for the row matrices */
+        double *Jr = calloc((size_t)(nrow > 0 ? nrow : 1) * (2 * NDT + 3), sizeof(double));
+        double *Tr = Jr + (size_t)(nrow > 0 ? nrow : 1) * NDT;
+        double *wii = Tr + (size_t)(nrow > 0 ? nrow : 1) * NDT;
         double *lam = wii + (nrow > 0 ? nrow : 1);
         double *bias = lam + (nrow > 0 ? nrow : 1);
-        double gap[NB * MAXC_BODY];
-        const double dirs[3][3] = {{0, 0, 1}, {1, 0, 0}, {0, 1, 0}};
+        double gap[NB * MAXC_BODY + 3];
         int slot_in_body[NB];
         memset(slot_in_body, 0, sizeof(slot_in_body));
-        for (int c = 0; c < cs.n; ++c) {
-            int b = cs.body[c];
-            if (contact_ids) contact_ids[b * 4 + slot_in_body[b]] = b * 64 + cs.vert[c];
-            slot_in_body[b]++;
-            body_jacobian(m, &k, b, J);
-            double r[3] = {cs.pos[c][0] - k.x[b][0], cs.pos[c][1] - k.x[b][1], cs.pos[c][2] - k.x[b][2]};
+        for (int c = 0; c < nc; ++c) {
+            const crow_t *r = &rows[c];
+            const double *dirs[3] = {r->n, r->t1, r->t2};
+            if (r->kind == 0) {
+                if (contact_ids) contact_ids[r->body * 4 + slot_in_body[r->body]] = r->body * 64 + r->vert;
+                slot_in_body[r->body]++;
+            }
+            if (r->body >= 0) body_jacobian(m, &k, r->body, J);
             for (int a = 0; a < 3; ++a) {
                 int row = 3 * c + a;
-                double rxn[3];
-                cross(r, dirs[a], rxn); /* point velocity . n = n.xdot + (r x n).w */
-                for (int col = 0; col < ND; ++col) {
-                    double sum = 0;
-                    for (int l = 0; l < 3; ++l) sum += J[l * ND + col] * rxn[l] + J[(3 + l) * ND + col] * dirs[a][l];
-                    Jr[row * ND + col] = sum;
-                    Tr[row * ND + col] = sum;
+                double *jr = &Jr[row * NDT], *tr = &Tr[row * NDT];
+                /* velocity of the contact point of body B relative to body A along dir, A = ground (kind 0, 2) or the racket's link (kind 1) */
+                if (r->kind == 0) { /* B = the link */
+                    double rl[3] = {r->pos[0] - k.x[r->body][0], r->pos[1] - k.x[r->body][1], r->pos[2] - k.x[r->body][2]}, rxn[3];
+                    cross(rl, dirs[a], rxn); /* point velocity . n = n.xdot + (r x n).w */
+                    for (int col = 0; col < ND; ++col) {
+                        double sum = 0;
+                        for (int l = 0; l < 3; ++l) sum += J[l * ND + col] * rxn[l] + J[(3 + l) * ND + col] * dirs[a][l];
+                        jr[col] = sum;
+                    }
+                } else { /* B = the ball */
+                    double rb[3] = {r->pos[0] - ball->pos[0], r->pos[1] - ball->pos[1], r->pos[2] - ball->pos[2]}, rxn[3];
+                    if (r->kind == 1) for (int i = 0; i < 3; ++i) rb[i] = -bp->radius * r->n[i]; /* the ball's own contact point */
+                    cross(rb, dirs[a], rxn);
+                    for (int l = 0; l < 3; ++l) { jr[ND + l] = dirs[a][l]; jr[ND + 3 + l] = rxn[l]; }
+                    if (r->kind == 1) { /* minus the racket point */
+                        double rl[3] = {r->pos[0] - k.x[r->body][0], r->pos[1] - k.x[r->body][1], r->pos[2] - k.x[r->body][2]};
+                        cross(rl, dirs[a], rxn);
+                        for (int col = 0; col < ND; ++col) {
+                            double sum = 0;
+                            for (int l = 0; l < 3; ++l) sum += J[l * ND + col] * rxn[l] + J[(3 + l) * ND + col] * dirs[a][l];
+                            jr[col] = -sum;
+                        }
+                    }
                 }
-                chol_solve(M, ND, &Tr[row * ND]);
+                memcpy(tr, jr, sizeof(double) * NDT);
+                chol_solve(M, ND, tr);
+                if (ball) for (int l = 0; l < 3; ++l) { tr[ND + l] /= bp->mass; tr[ND + 3 + l] /= bp->inertia; }
                 double sum = 0;
-                for (int col = 0; col < ND; ++col) sum += Jr[row * ND + col] * Tr[row * ND + col];
+                for (int col = 0; col < NDT; ++col) sum += jr[col] * tr[col];
                 wii[row] = sum;
             }
-            double d = cs.pos[c][2];
+            double d = r->gap;
             gap[c] = d;
             bias[3 * c] = d >= 0 ? d / h : fmax(p->erp * d / h, -p->max_depen_vel);
+            if (r->kind != 0) { /* restitution (Newton): an approach faster than the bounce threshold that closes the gap within this substep
+                                 * leaves with rest x the approach speed */
+                double vn0 = 0;
+                for (int col = 0; col < NDT; ++col) vn0 += Jr[3 * c * NDT + col] * v[col];
+                if (vn0 < -bp->bounce_threshold && d / h + vn0 < 0) bias[3 * c] = fmin(bias[3 * c], r->rest * vn0);
+            }
         }
         /* solver_type 0, PGS: n_iter sweeps against the biases of the start of the substep.
          * solver_type 1, TGS (temporal Gauss-Seidel, the PhysX solver amass_im.yaml:41 selects; Macklin et al. 2019, "Small steps in
@@ -508,35 +640,39 @@ int v2p_oracle_substep_io(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate 
         for (int it = 0; it < p->n_iter; ++it) {
             if (p->solver_type == 1) {
                 double hs = h / p->n_iter;
-                for (int c = 0; c < cs.n; ++c) {
+                for (int c = 0; c < nc; ++c) {
                     if (it > 0) {
                         double vn = 0;
-                        for (int col = 0; col < ND; ++col) vn += Jr[3 * c * ND + col] * v[col];
+                        for (int col = 0; col < NDT; ++col) vn += Jr[3 * c * NDT + col] * v[col];
                         gap[c] += hs * vn;
                     }
                     bias[3 * c] = gap[c] >= 0 ? gap[c] / (h - it * hs) : fmax(p->erp * gap[c] / hs, -p->max_depen_vel);
                 }
             }
-            for (int c = 0; c < cs.n; ++c)
+            for (int c = 0; c < nc; ++c)
                 for (int a = 0; a < 3; ++a) {
                     int row = 3 * c + a;
                     double rel = bias[row];
-                    for (int col = 0; col < ND; ++col) rel += Jr[row * ND + col] * v[col];
+                    for (int col = 0; col < NDT; ++col) rel += Jr[row * NDT + col] * v[col];
                     double nl = lam[row] - rel / wii[row];
                     if (a == 0) { if (nl < 0) nl = 0; }
-                    else { double lim = p->mu * lam[3 * c]; if (nl > lim) nl = lim; if (nl < -lim) nl = -lim; }
+                    else { double lim = rows[c].mu * lam[3 * c]; if (nl > lim) nl = lim; if (nl < -lim) nl = -lim; }
                     double dl = nl - lam[row];
                     lam[row] = nl;
-                    for (int col = 0; col < ND; ++col) v[col] += Tr[row * ND + col] * dl;
+                    for (int col = 0; col < NDT; ++col) v[col] += Tr[row * NDT + col] * dl;
                 }
         }
-        if (contact_force)
-            for (int c = 0; c < cs.n; ++c) {
-                int b = cs.body[c];
-                contact_force[3 * b + 2] += lam[3 * c] / h;
-                contact_force[3 * b + 0] += lam[3 * c + 1] / h;
-                contact_force[3 * b + 1] += lam[3 * c + 2] / h;
+        for (int c = 0; c < nc; ++c) {
+            const crow_t *r = &rows[c];
+            double f[3];
+            for (int i = 0; i < 3; ++i) f[i] = (lam[3 * c] * r->n[i] + lam[3 * c + 1] * r->t1[i] + lam[3 * c + 2] * r->t2[i]) / h;
+            if (r->kind == 0 && contact_force) for (int i = 0; i < 3; ++i) contact_force[3 * r->body + i] += f[i];
+            if (r->kind == 1) { /* on the ball +f, on the racket's link -f */
+                if (ball_contact) for (int i = 0; i < 3; ++i) ball_contact[i] += f[i];
+                if (contact_force) for (int i = 0; i < 3; ++i) contact_force[3 * r->body + i] -= f[i];
             }
+            if (r->kind == 2 && ball_contact) for (int i = 0; i < 3; ++i) ball_contact[3 + i] += f[i];
+        }
         free(Jr);
     }
 
@@ -555,7 +691,7 @@ int v2p_oracle_substep_io(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate 
         double n = sqrt(dot3(w, w));
         if (n > p->max_ang_vel) { double f = p->max_ang_vel / n; w[0] *= f; w[1] *= f; w[2] *= f; }
     }
-    memcpy(s->vel, v, sizeof(v));
+    memcpy(s->vel, v, sizeof(double) * ND);
     for (int i = 0; i < 3; ++i) s->root_pos[i] += h * v[i];
     double dq[4], rv[3], nq[4];
     for (int i = 0; i < 3; ++i) rv[i] = h * v[3 + i];
@@ -570,8 +706,73 @@ int v2p_oracle_substep_io(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate 
         qnormalize(nq);
         memcpy(s->jquat[b - 1], nq, sizeof(nq));
     }
+    if (ball) {
+        double scb = 1.0 / (1.0 + h * bp->ang_damp);
+        double *bw = &v[ND + 3];
+        for (int i = 0; i < 3; ++i) bw[i] *= scb;
+        double nw = sqrt(dot3(bw, bw));
+        if (nw > bp->max_ang_vel) for (int i = 0; i < 3; ++i) bw[i] *= bp->max_ang_vel / nw;
+        for (int i = 0; i < 3; ++i) { ball->vel[i] = v[ND + i]; ball->angvel[i] = bw[i]; ball->pos[i] += h * v[ND + i]; rv[i] = h * bw[i]; }
+        rotvec2quat(rv, dq);
+        qmul(dq, ball->quat, nq);
+        qnormalize(nq);
+        memcpy(ball->quat, nq, sizeof(nq));
+    }
     return 0;
 }
+
+int v2p_oracle_substep_io(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s, const double *pd_target, const double *ext_force,
+                          const double *ext_torque, double *contact_force, double *dof_force, int *contact_ids, const v2p_osub_io *io) {
+    return substep_impl(m, p, s, pd_target, ext_force, ext_torque, contact_force, dof_force, contact_ids, io, 0, 0, 0, 0);
+}
+
+/* aerodynamic force on the ball as humanoid_smpl_im_mvae.py:711-739 evaluates it before every simulate() call (drag with a constant
+ * coefficient, Magnus lift whose direction depends on the velocity only and whose size on the spin RATE; vid2player/utils/tennis_ball.py) */
+void v2p_oracle_ball_aero(const v2p_oball *ball, double spin_scale, double force[3]) {
+    const double PI = 3.14159265358979323846, R = 0.032, rho = 1.21, kf = rho * PI * R * R / 2.0, cd = 0.55;
+    double sp = sqrt(dot3(ball->vel, ball->vel));
+    double vs = sp == 0.0 ? 1.0 : sp; /* "avoid divide by 0" */
+    double vn[3] = {ball->vel[0] / vs, ball->vel[1] / vs, ball->vel[2] / vs};
+    const double g[3] = {0, 0, -1};
+    double vt[3], lt[3];
+    cross(vn, g, vt);
+    double vspin = sqrt(dot3(ball->angvel, ball->angvel)) / (2.0 * PI);
+    double cl = 1.0 / (2.0 + fabs(vs / (vspin * spin_scale + 1e-6)));
+    cl *= vspin > 0 ? -1.0 : 1.0;
+    cross(vt, vn, lt);
+    for (int i = 0; i < 3; ++i) force[i] = -kf * cd * vs * ball->vel[i] - kf * cl * vs * vs * lt[i];
+}
+
+/* one control step with racket + ball: `nsub` substeps in simulate() calls of `sub_per_sim` substeps; the aerodynamic force is
+ * re-evaluated at the start of every simulate() call.  ball_per_sim [nsim][13] (pos quat vel angvel after each call),
+ * racket_hit_per_sim [nsim] (1 when the racket-ball contact force was non-zero in the call's last substep, as the reference polls the
+ * net contact force tensor after each call), ball_contact [6] of the last substep. */
+int v2p_oracle_step_ball(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s, const double *pd_target, const double *ext_force,
+                         const double *ext_torque, int nsub, int hold, int sub_per_sim, double *contact_force, double *dof_force, int *contact_ids,
+                         const v2p_oball_params *bp, v2p_oball *ball, double spin_scale, double *ball_per_sim, int *racket_hit_per_sim,
+                         double *ball_contact) {
+    double f[3] = {0, 0, 0}, bc[6];
+    for (int i = 0; i < nsub; ++i) {
+        if (i % sub_per_sim == 0) v2p_oracle_ball_aero(ball, spin_scale, f);
+        int on = i < hold;
+        int rc = substep_impl(m, p, s, pd_target, on ? ext_force : 0, on ? ext_torque : 0, contact_force, dof_force, contact_ids, 0, bp, ball, f, bc);
+        if (rc) return rc;
+        if (i % sub_per_sim == sub_per_sim - 1) {
+            int k = i / sub_per_sim;
+            if (ball_per_sim) {
+                double *o = ball_per_sim + 13 * k;
+                memcpy(o, ball->pos, sizeof(double) * 3); memcpy(o + 3, ball->quat, sizeof(double) * 4);
+                memcpy(o + 7, ball->vel, sizeof(double) * 3); memcpy(o + 10, ball->angvel, sizeof(double) * 3);
+            }
+            if (racket_hit_per_sim) racket_hit_per_sim[k] = (bc[0] != 0.0 || bc[1] != 0.0 || bc[2] != 0.0);
+        }
+    }
+    if (ball_contact) memcpy(ball_contact, bc, sizeof(bc));
+    return 0;
+}
+
+int v2p_oracle_sizeof_ball_params(void) { return (int)sizeof(v2p_oball_params); }
+int v2p_oracle_sizeof_ball(void) { return (int)sizeof(v2p_oball); }
 
 /* ------------------------------------------------------------------ state <-> Isaac-Gym-style tensors */
 /* root[13] = pos3 quat4 linvel3 angvel3 (humanoid_smpl.py:66-113), dof_pos = exp-map, dof_vel = joint-frame rate */

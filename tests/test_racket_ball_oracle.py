@@ -1,0 +1,128 @@
+"""Racket + ball in the C oracle: physical invariants of the restatement (PhysX is closed: parity unpinned) - free
+flight with drag and Magnus lift, bounce height, friction spin-up, racket hit - and the composite body model with the welded racket."""
+import numpy as np
+import pytest
+
+from oracle.phys_oracle import PhysOracle, default_params
+from vid2player3d_amd import racket as R
+from vid2player3d_amd.model import load_baked_model
+
+BASE = [0.5, 0.5, 0.5, 0.5]
+
+
+@pytest.fixture(scope="module")
+def models():
+    base = load_baked_model()
+    return base, R.with_racket(base)
+
+
+def far_humanoid(o):
+    root = np.zeros(13)
+    root[0:3] = [50.0, 50.0, 5.0]
+    root[3:7] = BASE
+    o.set_state(root, np.zeros(69), np.zeros(69))
+
+
+def test_racket_is_folded_into_the_wrist(models):
+    base, (m, geom) = models
+    b = base.body_index("R_Wrist")
+    assert geom["racket_link"] == b == 22
+    handle = 500 * np.pi * 0.016 ** 2 * 0.35
+    head = 150 * np.pi * 0.15 ** 2 * np.linalg.norm([0.03, 0.03])
+    assert abs(geom["racket_mass"] - (handle + head)) < 1e-12 and abs(m.mass[b] - base.mass[b] - handle - head) < 1e-12
+    assert m.com[b][0] < base.com[b][0] - 0.2  # the centre of mass moves out along the racket (-x of the wrist frame)
+    assert np.all(np.linalg.eigvalsh(m.inertia[b]) > 0) and np.linalg.eigvalsh(m.inertia[b]).max() > 20 * np.linalg.eigvalsh(base.inertia[b]).max()
+    assert np.array_equal(np.delete(m.mass, b), np.delete(base.mass, b))
+    n = np.diff(m.hull_offsets)
+    assert n[b] <= 64 and np.array_equal(np.delete(n, b), np.delete(np.diff(base.hull_offsets), b))
+    cyl = geom["cylinders"]
+    assert np.allclose(cyl[0]["center"], [-0.175, 0, 0]) and abs(cyl[0]["half_len"] - 0.175) < 1e-12
+    assert np.allclose(cyl[1]["center"], [-0.5, 0, 0]) and np.allclose(cyl[1]["axis"], np.array([0, 1, 1]) / np.sqrt(2))
+
+
+def test_free_flight_drag_and_magnus(models):
+    _, (m, geom) = models
+    o = PhysOracle(m, default_params())
+    far_humanoid(o)
+    o.attach_ball(geom)
+    # no spin: the force is pure drag, opposite to the velocity, kf cd |v|^2
+    ball = np.zeros(13); ball[0:3] = [0, 0, 3]; ball[6] = 1; ball[7:10] = [30.0, 0, 0]
+    o.set_ball(ball)
+    o.step_ball(nsub=2, hold=0, sub_per_sim=2)
+    v = o.get_ball()[7:10]
+    kf = 1.21 * np.pi * 0.032 ** 2 / 2
+    ax = -(kf * 0.55 * 30.0 ** 2) / 0.057
+    assert abs((v[0] - 30.0) / (2 / 120) - ax) < 0.02 * abs(ax) and abs((v[2]) / (2 / 120) + 9.81) < 1e-4 and v[1] == 0  # (cl(v, 0) = 1 / (2 + v / 1e-6) is tiny, not zero)
+    # with spin the lift points DOWN for a ball flying horizontally whatever the spin axis (the reference's formula uses the rate only)
+    for spin in ([0, 200.0, 0], [0, -200.0, 0], [0, 0, 200.0]):
+        ball[10:13] = spin
+        o.set_ball(ball)
+        o.step_ball(nsub=2, hold=0, sub_per_sim=2)
+        az = o.get_ball()[9] / (2 / 120)
+        cl = 1.0 / (2 + 30.0 / (200.0 / (2 * np.pi)))
+        assert az < -9.81 and abs(az + 9.81 + kf * cl * 900.0 / 0.057) < 0.03 * abs(az)
+
+
+def test_bounce_height_and_friction(models):
+    _, (m, geom) = models
+    o = PhysOracle(m, default_params())
+    far_humanoid(o)
+    o.attach_ball(geom)
+    ball = np.zeros(13); ball[0:3] = [0, 0, 1.0]; ball[6] = 1
+    o.set_ball(ball)
+    zs, vzs = [], []
+    for _ in range(60):
+        o.step_ball(nsub=4, hold=0, sub_per_sim=2)
+        b = o.get_ball()
+        zs.append(b[2]); vzs.append(b[9])
+    zs = np.array(zs)
+    assert zs.min() > 0.032 - 0.021  # never deeper than the contact offset below touching
+    vzs = np.array(vzs)
+    k = int(np.argmax(vzs > 0))            # first control step after the first bounce
+    k2 = k + int(np.argmax(vzs[k:] < 0))   # apex of the rebound
+    rebound = zs[k:k2 + 1].max() - 0.032
+    # restitution 0.5 against the ground: rebound height = e^2 x drop height (drag is ~1 % over 1 m)
+    assert abs(rebound / (1.0 - 0.032) - 0.25) < 0.05, rebound  # (+- one substep of travel: the speculative contact turns the ball around up to 3.5 cm early)
+    # a ball that lands with horizontal speed and no spin picks up forward spin from friction and loses horizontal speed
+    ball[7:10] = [5.0, 0, 0]
+    o.set_ball(ball)
+    for _ in range(20):
+        o.step_ball(nsub=4, hold=0, sub_per_sim=2)
+    b = o.get_ball()
+    assert b[7] < 5.0 - 0.3 and b[11] > 10.0  # rolling forward about +y
+
+
+def test_racket_hit_exchanges_momentum(models):
+    """A ball thrown at the face of the racket of a floating, limp humanoid (no gravity, no drives): it comes back (restitution 1), the
+    total linear momentum of humanoid + ball is conserved, the hit is reported for that simulate() call only."""
+    _, (m, geom) = models
+    zeros = np.zeros(69)
+    o = PhysOracle(m, default_params(gravity_z=0.0, ang_damp=0.0), kp=zeros, kd=zeros)
+    root = np.zeros(13); root[2] = 3.0; root[3:7] = BASE
+    o.set_state(root, zeros, zeros)
+    o.attach_ball(geom, material={"ang_damp": 0.0})
+    rb = o.get_state()[3]
+    wrist_pos, wrist_q = rb[22, 0:3], rb[22, 3:7]
+    from scipy.spatial.transform import Rotation
+
+    Rw = Rotation.from_quat(wrist_q).as_matrix()
+    centre = wrist_pos + Rw @ geom["cylinders"][1]["center"]
+    normal = Rw @ geom["cylinders"][1]["axis"]
+    ball = np.zeros(13); ball[6] = 1
+    ball[0:3] = centre + 0.14 * normal
+    ball[7:10] = -6.0 * normal  # (slow enough for the drag impulse over the test, ~5e-3 N s, not to mask the momentum balance)
+    o.set_ball(ball)
+    p0 = o.diagnostics()["P"] + 0.057 * ball[7:10]
+    hits = []
+    for _ in range(4):
+        *_, per_sim, hit, bc = o.step_ball(nsub=4, hold=0, sub_per_sim=2)
+        hits += hit.tolist()
+    b = o.get_ball()
+    vn = b[7:10] @ normal
+    assert sum(hits) >= 1 and hits[-1] == 0  # polled after each simulate() on its LAST substep, like the net contact force tensor: the hit lands on one
+    assert 1.5 < vn < 6.0  # bounced back; slower than it came because the 0.6 kg racket on a limp arm recoils
+    p1 = o.diagnostics()["P"] + 0.057 * b[7:10]
+    # of 0.34 N s: what is missing is the drag on the ball and the first-order-in-h momentum drift of the limp, now tumbling arm chain
+    # (test_phys_oracle.py::test_free_flight_conserves_momentum_and_energy quantifies that drift)
+    assert np.abs(p1 - p0).max() < 2e-2
+    assert np.linalg.norm(o.get_state()[3][22, 7:10]) > 0.05  # the wrist was pushed
