@@ -73,8 +73,8 @@ def self_launch(gpus, argv, stub):
 
 
 # ---------------------------------------------------------------------------------------------- the workload
-def build_task(num_envs, device_id, seed, contact=True, per_clip_shapes=False, djokovic=False, freeze=False, solver="pgs"):
-    from vid2player3d_amd.tasks import HumanoidSMPLIM, default_cfg
+def build_task(num_envs, device_id, seed, contact=True, per_clip_shapes=False, djokovic=False, freeze=False, solver="pgs", racket_ball=False):
+    from vid2player3d_amd.tasks import HumanoidSMPLIM, HumanoidSMPLIMRacketBall, default_cfg
 
     cfg = default_cfg(num_envs, synthetic_motions={"seed": 7, "num_clips": 64, "min_frames": 90, "max_frames": 300},
                       enable_contact=contact, contact_solver=solver)
@@ -89,6 +89,23 @@ def build_task(num_envs, device_id, seed, contact=True, per_clip_shapes=False, d
 
         cfg["env"]["body_model"] = body_shapes.synthetic_shape_family(load_baked_model(), 64, seed=7)
     torch.manual_seed(seed)
+    if racket_ball:  # BASELINE config 4 as it is worded: racket welded to the wrist + free ball in every env
+        task = HumanoidSMPLIMRacketBall(cfg, device_type="cuda", device_id=device_id)
+        inner_reset = task.reset
+
+        def reset_with_serve(env_ids=None):  # every epoch a ball is served at the player from 8 m (so that ground bounces and some racket hits occur)
+            inner_reset(env_ids)
+            n, dev = task.num_envs, task.device
+            root = task._humanoid_root_states[:, 0:3]
+            g = torch.Generator(device=dev)
+            g.manual_seed(seed + int(task.progress_buf.sum().item()) % 7)
+            jitter = torch.rand((n, 3), device=dev, generator=g)
+            pos = root + torch.tensor([8.0, 0.0, 0.3], device=dev) + jitter * torch.tensor([1.0, 1.0, 1.0], device=dev)
+            vel = torch.tensor([-22.0, 0.0, 4.0], device=dev) + (jitter - 0.5) * torch.tensor([6.0, 3.0, 3.0], device=dev)
+            task.reset_balls(torch.arange(n, device=dev), pos, vel, torch.tensor([0.0, -150.0, 0.0], device=dev).expand(n, 3))
+
+        task.reset = reset_with_serve
+        return task
     return HumanoidSMPLIM(cfg, device_type="cuda", device_id=device_id)
 
 
@@ -256,6 +273,7 @@ def main():
     ap.add_argument("--solver", choices=["pgs", "tgs"], default="pgs")
     ap.add_argument("--freeze-terminated", action="store_true", help="opt-in engine feature: terminated envs are not simulated until the epoch reset (not reference behaviour)")
     ap.add_argument("--djokovic", action="store_true", help="BASELINE config 4 (djokovic_im.yaml: terminationHeadHeight -0.5, faster clips)")
+    ap.add_argument("--racket-ball", action="store_true", help="BASELINE config 4 as worded: racket welded to the wrist + free ball with drag / Magnus lift, ball-ground and ball-racket contacts (implies --djokovic)")
     ap.add_argument("--per-clip-shapes", action="store_true", help="one body shape per clip (64 scaled bodies) instead of one shape for all envs")
     ap.add_argument("--ppo", action="store_true", help="BASELINE config 5 loop: device-resident rollout (play_steps) + GAE + PPO update per epoch; prints the reference's fps step / fps total")
     ap.add_argument("--ppo-epochs", type=int, default=4, help="timed PPO epochs (after one untimed warm-up epoch)")
@@ -298,8 +316,8 @@ def main():
             build.build()  # no-op when the in-tree .so is current; one rank per node compiles otherwise
         if dist is not None:
             dist.barrier()
-        task = build_task(n, local_rank, seed=7 + rank, contact=not args.no_contact, per_clip_shapes=args.per_clip_shapes, djokovic=args.djokovic,
-                          freeze=args.freeze_terminated, solver=args.solver)  # per-rank seed like run.py:37
+        task = build_task(n, local_rank, seed=7 + rank, contact=not args.no_contact, per_clip_shapes=args.per_clip_shapes, djokovic=args.djokovic or args.racket_ball,
+                          freeze=args.freeze_terminated, solver=args.solver, racket_ball=args.racket_ball)  # per-rank seed like run.py:37
     if args.ppo:
         return run_ppo(args, task, dist, world, rank)
     dev = task.device
@@ -363,7 +381,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "amass_im num_envs=%d per GPU, %s, imitation reward, per-epoch reset+context every %d steps, 64 synthetic clips, action noise %.3g%s"
                                    % (n, "PD control only (no contact solve)" if args.no_contact else "full contact %s (4 substeps x 4 iterations)" % args.solver.upper(), HORIZON,
-                                      args.action_noise, (", one NON-UNIFORM body shape per clip (64 shapes from vertex clouds)" if args.per_clip_shapes else "") + (", djokovic_im variant" if args.djokovic else "") +
+                                      args.action_noise, (", one NON-UNIFORM body shape per clip (64 shapes from vertex clouds)" if args.per_clip_shapes else "") + (", djokovic_im variant" if args.djokovic or args.racket_ball else "") + (", RACKET + BALL in every env (reported separately)" if args.racket_ball else "") +
                                       (", TERMINATED ENVS FROZEN (not reference behaviour)" if args.freeze_terminated else "") + (", STUB TASK (launch-logic test, not a measurement)" if stub else "")),
                        "num_envs_per_gpu": n, "global_envs": world * n, "parallelism": "env-sharded x%d, no data-path collective" % world,
                        "world_size_seen": world_seen, "backend": None if dist is None else ("gloo" if stub else "nccl(rccl)"),

@@ -34,7 +34,7 @@ extern "C" {
 #define V2P_NUM_OBS 461
 #define V2P_MOTION_STATE_DIM 331  /* root_pos3 root_rot4 dof_pos69 root_vel3 root_ang_vel3 dof_vel69 key_pos12 rb_pos72 rb_rot96 */
 #define V2P_CONTEXT_DIM 378       /* body_pos72 body_rot96 dof_pos69 body_pos_gt72 dof_pos_gt69 (humanoid_smpl_im.py:202) */
-#define V2P_ABI_VERSION 3
+#define V2P_ABI_VERSION 4
 
 typedef enum {
     V2P_OK = 0,
@@ -254,6 +254,35 @@ int v2p_env_debug_contacts_substeps(v2p_env* e, int32_t* out, void* stream);
 /* diagnostics for tests: the wave-slot -> env order used by the last physics launch (`perm`, [N] int32; envs are handed to
  * waves in descending order of their contact load, see DESIGN.md "pairing") and the load key it was built from (`key`, [N]) */
 int v2p_env_debug_pairing(v2p_env* e, int32_t* perm, int32_t* key, void* stream);
+
+/* ---- racket + ball (vid2player/env/tasks/humanoid_smpl_im_mvae.py:367-442 actors, :711-783 physics step; data/assets/
+ * smpl_mesh_humanoid_djokovic.xml:188-190, tennis_ball.urdf).  The racket is welded to a link: its mass belongs to that link of the
+ * body model handed to v2p_model_create (vid2player3d_amd/racket.py builds it), its two solid cylinders are given here in the link's
+ * frame for the ball contacts.  The ball is a free sphere simulated alongside the humanoid (same substeps): gravity, the reference's
+ * drag + Magnus force re-evaluated before every simulate() call (apply_external_force_to_ball), ball x ground and ball x racket
+ * contacts with restitution and friction (material values combined by averaging, PhysX's default).  Ball x humanoid-hull contacts
+ * are not modelled.  Link-per-lane schedule, contacts on, PGS. */
+typedef struct {
+    float radius, mass, inertia;                     /* 0.032, 0.057, 4e-5 */
+    float restitution_ground, friction_ground;       /* 0.5, 0.9 */
+    float restitution_racket, friction_racket;       /* 1.0, 0.8 */
+    float bounce_threshold_velocity;                 /* 0.2 (sim.physx) */
+    float angular_damping, max_angular_velocity;     /* gymapi.AssetOptions defaults: 0.5, 64 */
+    float spin_scale;                                /* cfg_v2p spin_scale, 1.0 */
+    int32_t racket_link;                             /* 22 = R_Wrist */
+    int32_t num_cylinders;                           /* <= 2 */
+    float cylinders[2][8];                           /* centre 3, unit axis 3, half length, radius; racket_link's frame */
+    float racket_offset[3];                          /* origin of the racket rigid body (index 24 of the reference's tensor) in that frame */
+} v2p_ball_cfg;
+typedef struct {                  /* caller-owned DEVICE buffers */
+    float* ball_state;            /* [N,13] the ball actor's root state (pos quat linvel angvel): read at the start of every step, written at
+                                   * its end - edit it in place to launch a ball (set_actor_root_state_tensor_indexed) */
+    float* racket_state;          /* [N,13] rigid-body state of the racket */
+    float* ball_per_sim;          /* [N,control_freq_inv,13] ball state after each simulate() call (what refresh_actor_root_state_tensor shows) */
+    int32_t* racket_hit_per_sim;  /* [N,control_freq_inv] racket-ball contact force non-zero after the call (the reference's poll, :773-779) */
+    float* ball_contact;          /* [N,2,3] contact force on the ball from the racket / from the ground after the last call */
+} v2p_ball_buffers;
+int v2p_env_attach_ball(v2p_env* e, const v2p_ball_cfg* cfg, const v2p_ball_buffers* buffers);
 
 /* measurement: HIP events around every launch of the physics kernel (the dominant kernel of the step), recorded on the launch stream
  * by v2p_env_step / v2p_env_physics between _begin and _end (at most max_launches of them).  _end synchronises the events and returns

@@ -1,0 +1,150 @@
+"""Racket + ball on the GPU: the HIP kernel against the C oracle on every env - ball in free flight with drag and
+Magnus lift, bouncing on the ground, hit by the racket of a moving humanoid - plus the flags the reference derives per simulate() call."""
+import numpy as np
+import pytest
+import torch
+from scipy.spatial.transform import Rotation
+
+from oracle import task_oracle as O
+from oracle.phys_oracle import PhysOracle, default_params
+from tests.gpu_util import DEV, N, T, close, synth_tables
+
+pytestmark = pytest.mark.gpu
+
+
+def make_rb_task(n, lib, **env):
+    from vid2player3d_amd.tasks import HumanoidSMPLIMRacketBall, default_cfg
+
+    env.setdefault("debug_contacts", 1)
+    env.setdefault("body_shape_mismatch", "ignore")
+    cfg = default_cfg(n, motion_lib=lib, sample_first_motions=True, **env)
+    return HumanoidSMPLIMRacketBall(cfg, device_type="cuda", device_id=0)
+
+
+@pytest.fixture(scope="module")
+def mlib():
+    from vid2player3d_amd.motion_lib import MotionLib
+
+    return MotionLib(synth_tables(seed=5, num_clips=8, min_frames=60, max_frames=120), DEV)
+
+
+def _launch(task, rng, mode):
+    """Ball states [n,13] for the scenario `mode`; 'hit': aimed at the face of each env's racket head."""
+    n = task.num_envs
+    ball = np.zeros((n, 13), np.float32)
+    ball[:, 6] = 1
+    rb = N(task._rigid_body_state).reshape(n, 24, 13)
+    if mode == "flight":
+        ball[:, 0:3] = rb[:, 0, 0:3] + rng.uniform(-3, 3, (n, 3)) + [0, 0, 4]
+        ball[:, 7:10] = rng.normal(0, 15, (n, 3))
+        ball[:, 10:13] = rng.normal(0, 150, (n, 3))
+    elif mode == "ground":
+        ball[:, 0:2] = rb[:, 0, 0:2] + rng.uniform(3, 5, (n, 2))
+        ball[:, 2] = rng.uniform(0.03, 0.25, n)
+        ball[:, 7:10] = np.stack([rng.normal(0, 6, n), rng.normal(0, 6, n), rng.uniform(-12, 1, n)], 1)
+        ball[:, 10:13] = rng.normal(0, 60, (n, 3))
+    else:
+        geom = task.racket_geometry
+        for e in range(n):
+            Rw = Rotation.from_quat(rb[e, 22, 3:7]).as_matrix()
+            centre = rb[e, 22, 0:3] + Rw @ geom["cylinders"][1]["center"]
+            normal = Rw @ geom["cylinders"][1]["axis"] * (1 if e % 2 else -1)
+            side = np.cross(normal, [0.3, 0.5, 0.8])
+            side /= np.linalg.norm(side)
+            speed = rng.uniform(4, 30)
+            ball[e, 0:3] = centre + rng.uniform(0.06, 0.25) * normal + rng.uniform(0, 0.11) * side
+            ball[e, 7:10] = -speed * normal + rng.normal(0, 2, 3)
+            ball[e, 10:13] = rng.normal(0, 80, 3)
+    return ball
+
+
+@pytest.mark.parametrize("mode,lift", [("flight", 0.0), ("ground", 0.0), ("hit", 0.4), ("hit", 0.0)])
+def test_ball_step_matches_oracle(mlib, mode, lift):
+    n = 32
+    rng = np.random.default_rng({"flight": 1, "ground": 2, "hit": 3}[mode] + int(10 * lift))
+    task = make_rb_task(n, mlib)
+    task.reset_with_times(None, T(rng.uniform(0.1, 1.0, size=n)))
+    root = N(task._humanoid_root_states).copy()
+    root[:, 2] += lift
+    root[:, 7:13] += rng.normal(0, 0.5, (n, 6)).astype(np.float32)
+    dpos = N(task._dof_pos).copy() + rng.normal(0, 0.05, (n, 69)).astype(np.float32)
+    dvel = N(task._dof_vel).copy() + rng.normal(0, 1.0, (n, 69)).astype(np.float32)
+    task._humanoid_root_states[:] = T(root)
+    task._dof_pos[:] = T(dpos)
+    task._dof_vel[:] = T(dvel)
+    task._reset_env_tensors(None)
+    # one physics-free refresh of the rigid-body state for the launch geometry: FK of the pushed state through the oracle
+    bm = task.body_model
+    oracles = []
+    for e in range(n):
+        o = PhysOracle(bm, default_params(), kp=bm.kp.astype(np.float32), kd=bm.kd.astype(np.float32))
+        o.set_state(root[e], dpos[e], dvel[e])
+        o.attach_ball(task.racket_geometry)
+        oracles.append(o)
+    task._rigid_body_state[:] = T(np.stack([o.get_state()[3] for o in oracles]).reshape(n * 24, 13))
+    ball = _launch(task, rng, mode)
+    task._ball_root_states[:] = T(ball)
+    hits_total, ground_total = 0, 0
+    for step in range(2):
+        act = np.concatenate([N(task._target_dof_pos) + rng.normal(0, 0.17, (n, 69)), rng.normal(0, 0.17, (n, 6))], axis=1).astype(np.float32)
+        rb0 = N(task._rigid_body_state).reshape(n, 24, 13).copy()
+        dpos_before = N(task._dof_pos).copy()
+        ball_before = N(task._ball_root_states).copy()
+        a = T(act)
+        task.pre_physics_step(a)
+        task._physics_step()
+        torch.cuda.synchronize()
+        _, pd, _, force, torque = O.pre_physics(act, N(task.reset_buf), dpos_before, rb0[:, 0, 3:7], bm.kp.astype(np.float32))
+        per_sim, hit, bc, rbs, ids, cf = [], [], [], [], [], []
+        for e in range(n):
+            oracles[e].set_ball(ball_before[e])
+            c, _, i, ps, h, b = oracles[e].step_ball(pd_target=pd[e], ext_force=force[e], ext_torque=torque[e], nsub=4, hold=2, sub_per_sim=2)
+            per_sim.append(ps); hit.append(h); bc.append(b); rbs.append(oracles[e].get_state()[3]); ids.append(i); cf.append(c)
+        per_sim, hit, bc, rbs, ids, cf = map(np.stack, (per_sim, hit, bc, rbs, ids, cf))
+        assert np.array_equal(N(task.debug_contacts()), ids), "hull contact vertices differ"
+        got_ps = N(task._ball_states_per_sim)
+        close(got_ps[..., 0:3], per_sim[..., 0:3], 2e-5, "%s ball pos (step %d)" % (mode, step))
+        qs = np.sign(np.sum(got_ps[..., 3:7] * per_sim[..., 3:7], -1, keepdims=True))
+        close(got_ps[..., 3:7] * qs, per_sim[..., 3:7], 1e-4, "ball quat")
+        close(got_ps[..., 7:10], per_sim[..., 7:10], 5e-4, "%s ball vel (step %d)" % (mode, step))
+        close(got_ps[..., 10:13], per_sim[..., 10:13], 5e-4, "%s ball spin (step %d)" % (mode, step))
+        assert np.array_equal(N(task._ball_root_states), got_ps[:, -1])
+        assert np.array_equal(N(task._racket_ball_contact_per_sim), hit), "racket hit flags"
+        close(N(task._ball_contact_forces), bc, 2e-2, "contact forces on the ball")
+        rb = N(task._rigid_body_state).reshape(n, 24, 13)
+        close(rb[..., 0:3], rbs[..., 0:3], 2e-5, "rb pos")
+        close(rb[..., 7:13], rbs[..., 7:13], 1e-3, "rb vel")
+        close(N(task._contact_forces), cf, 2e-2, "net contact forces (the racket's link carries the reaction of the ball)")
+        # the racket rigid body = the wrist frame moved by the weld offset
+        Rw = Rotation.from_quat(rbs[:, 22, 3:7]).as_matrix()
+        off = np.einsum("nij,j->ni", Rw, task.racket_geometry["racket_offset"])
+        close(N(task._racket_rb_state)[:, 0:3], rbs[:, 22, 0:3] + off, 2e-5, "racket pos")
+        close(N(task._racket_rb_state)[:, 7:10], rbs[:, 22, 7:10] + np.cross(rbs[:, 22, 10:13], off), 1e-3, "racket vel")
+        hits_total += int(hit.sum())
+        ground_total += int(((ball_before[:, 9] < -0.5) & (got_ps[:, -1, 9] > 0)).sum())  # balls that bounced within this control step
+        task.post_physics_step()
+    if mode == "hit":
+        assert hits_total >= n // 4, "the fixture must produce racket hits (%d)" % hits_total
+    if mode == "ground":
+        assert ground_total >= n // 4, ground_total
+    task.close()
+
+
+def test_bounce_and_hit_flags(mlib):
+    """The reference's per-simulate() bookkeeping (humanoid_smpl_im_mvae.py:731-737, 773-779) on top of the engine's outputs."""
+    n = 8
+    task = make_rb_task(n, mlib)
+    task.reset_with_times(None, torch.full((n,), 0.3, device=DEV))
+    pos = torch.tensor([[5.0, 5.0, 0.5]], device=DEV).repeat(n, 1)
+    task.reset_balls(torch.arange(n), pos, torch.tensor([[1.0, 0.0, -6.0]], device=DEV).repeat(n, 1), torch.zeros((n, 3), device=DEV))
+    a = torch.cat([task._target_dof_pos.clone(), torch.zeros((n, 6), device=DEV)], dim=1).contiguous()
+    seen = []
+    for _ in range(6):
+        task.step(a.clone())
+        seen.append((task._has_bounce_now.clone(), task._ball_root_states[:, 2].clone()))
+    torch.cuda.synchronize()
+    assert task._has_bounce.all() and sum(int(s[0].any()) for s in seen) == 1  # flagged once, when the ball first comes within 4 R of the ground
+    assert (task._bounce_pos[:, 2] <= 4 * 0.032 + 1e-6).all() and (task._bounce_pos[:, 2] > 0).all()
+    assert not task._has_racket_ball_contact.any()
+    assert task._ball_root_states[:, 2].min() > 0.0  # the ball did not tunnel
+    task.close()

@@ -39,7 +39,7 @@ def test_binding_covers_the_header():
 def test_abi_version_and_error_string(lib):
     lib.v2p_abi_version.restype = ctypes.c_int
     lib.v2p_last_error.restype = ctypes.c_char_p
-    assert lib.v2p_abi_version() == 3
+    assert lib.v2p_abi_version() == 4
     assert isinstance(lib.v2p_last_error(), bytes)
 
 
@@ -53,7 +53,7 @@ def test_struct_sizes_match_the_header():
     prog = r'''
 #include <stdio.h>
 #include "v2p_rollout.h"
-int main(void){ printf("%zu %zu %zu %zu\n", sizeof(v2p_model_desc), sizeof(v2p_motion_tables), sizeof(v2p_sim_cfg), sizeof(v2p_env_buffers)); return 0; }
+int main(void){ printf("%zu %zu %zu %zu %zu %zu\n", sizeof(v2p_model_desc), sizeof(v2p_motion_tables), sizeof(v2p_sim_cfg), sizeof(v2p_env_buffers), sizeof(v2p_ball_cfg), sizeof(v2p_ball_buffers)); return 0; }
 '''
     with tempfile.TemporaryDirectory() as d:
         src = os.path.join(d, "s.c")
@@ -61,7 +61,8 @@ int main(void){ printf("%zu %zu %zu %zu\n", sizeof(v2p_model_desc), sizeof(v2p_m
         exe = os.path.join(d, "s")
         subprocess.check_call(["gcc", "-I", os.path.join(REPO, "include"), src, "-o", exe])
         sizes = [int(x) for x in subprocess.check_output([exe]).split()]
-    assert sizes == [ctypes.sizeof(_lib.ModelDesc), ctypes.sizeof(_lib.MotionTables), ctypes.sizeof(_lib.SimCfg), ctypes.sizeof(_lib.EnvBuffers)]
+    assert sizes == [ctypes.sizeof(_lib.ModelDesc), ctypes.sizeof(_lib.MotionTables), ctypes.sizeof(_lib.SimCfg), ctypes.sizeof(_lib.EnvBuffers),
+                     ctypes.sizeof(_lib.BallCfg), ctypes.sizeof(_lib.BallBuffers)]
 
 
 def test_bad_arguments_are_rejected_without_a_gpu(lib):

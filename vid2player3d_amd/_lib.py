@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "libv2p_rollout.so")
 
 NUM_BODIES, NUM_DOF, NUM_ACTIONS, NUM_OBS = 24, 69, 75, 461
 MOTION_STATE_DIM, CONTEXT_DIM = 331, 378
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_f = C.POINTER(C.c_float)
 c_i32 = C.POINTER(C.c_int32)
@@ -47,6 +47,17 @@ class EnvBuffers(C.Structure):
     _fields_ = [("root_states", vp), ("dof_state", vp), ("rb_state", vp), ("contact_force", vp), ("dof_force", vp), ("pd_target", vp),
                 ("obs", vp), ("rew", vp), ("sub_rewards", vp), ("reset", vp), ("terminate", vp), ("progress", vp), ("cur_time", vp),
                 ("reset_time", vp), ("target", vp * 2), ("context_feat", vp), ("context_mask", vp)]
+
+
+class BallCfg(C.Structure):
+    _fields_ = [("radius", C.c_float), ("mass", C.c_float), ("inertia", C.c_float), ("restitution_ground", C.c_float), ("friction_ground", C.c_float),
+                ("restitution_racket", C.c_float), ("friction_racket", C.c_float), ("bounce_threshold_velocity", C.c_float),
+                ("angular_damping", C.c_float), ("max_angular_velocity", C.c_float), ("spin_scale", C.c_float), ("racket_link", C.c_int32),
+                ("num_cylinders", C.c_int32), ("cylinders", (C.c_float * 8) * 2), ("racket_offset", C.c_float * 3)]
+
+
+class BallBuffers(C.Structure):
+    _fields_ = [("ball_state", vp), ("racket_state", vp), ("ball_per_sim", vp), ("racket_hit_per_sim", vp), ("ball_contact", vp)]
 
 
 _lib = None
@@ -93,6 +104,7 @@ def load():
         "v2p_env_debug_contacts": [vp, vp, vp],
         "v2p_env_debug_contacts_substeps": [vp, vp, vp],
         "v2p_env_debug_pairing": [vp, vp, vp, vp],
+        "v2p_env_attach_ball": [vp, C.POINTER(BallCfg), C.POINTER(BallBuffers)],
         "v2p_env_profile_begin": [vp, C.c_int64],
         "v2p_env_profile_end": [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)],
     }
@@ -111,7 +123,7 @@ def load():
 EXPORTED_SYMBOLS = (
     "v2p_model_create", "v2p_model_destroy", "v2p_mlib_create", "v2p_mlib_destroy", "v2p_motion_state", "v2p_reward", "v2p_reset_flags",
     "v2p_obs_imitation", "v2p_obs_imitation_packed", "v2p_gae", "v2p_env_create", "v2p_env_create_shapes", "v2p_env_destroy", "v2p_env_reset", "v2p_env_step", "v2p_env_pre_physics", "v2p_env_physics", "v2p_env_export",
-    "v2p_env_post_physics", "v2p_env_push_state", "v2p_env_target_index", "v2p_env_set_schedule", "v2p_env_debug_contacts", "v2p_env_debug_contacts_substeps", "v2p_env_debug_pairing", "v2p_env_profile_begin", "v2p_env_profile_end", "v2p_last_error", "v2p_abi_version",
+    "v2p_env_post_physics", "v2p_env_push_state", "v2p_env_target_index", "v2p_env_set_schedule", "v2p_env_debug_contacts", "v2p_env_debug_contacts_substeps", "v2p_env_debug_pairing", "v2p_env_attach_ball", "v2p_env_profile_begin", "v2p_env_profile_end", "v2p_last_error", "v2p_abi_version",
 )
 
 

@@ -302,6 +302,7 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
     EnvParams& p = e->p;
     p.h = c->sim_dt / (float)c->substeps;
     p.nsub = c->substeps * c->control_freq_inv;
+    e->substeps_per_sim = c->substeps;
     p.hold_sub = c->residual_hold_sims * c->substeps;
     p.n_iter = c->num_solver_iterations;
     p.enable_contact = c->enable_contact;
@@ -454,6 +455,31 @@ int v2p_env_physics(v2p_env* e, void* stream) {
     DeviceGuard g(e->device);
     if (e->schedule != 0) { int rc = ensure_env_per_lane_buffers(e); if (rc != V2P_OK) return rc; }
     return physics_launch(e, (hipStream_t)stream, nullptr);
+}
+
+int v2p_env_attach_ball(v2p_env* e, const v2p_ball_cfg* c, const v2p_ball_buffers* b) {
+    if (!e || !c || !b) { set_error("v2p_env_attach_ball: null argument"); return V2P_ERR_INVALID; }
+    if (!b->ball_state || !b->racket_state || !b->ball_per_sim || !b->racket_hit_per_sim || !b->ball_contact) { set_error("v2p_env_attach_ball: a buffer is null"); return V2P_ERR_INVALID; }
+    if (c->racket_link < 1 || c->racket_link >= NB || c->num_cylinders < 0 || c->num_cylinders > 2 || !(c->radius > 0.f) || !(c->mass > 0.f) || !(c->inertia > 0.f)) {
+        set_error("v2p_env_attach_ball: bad ball parameters");
+        return V2P_ERR_INVALID;
+    }
+    if (e->schedule != 0 || !e->p.enable_contact || e->p.solver_type != 0) {
+        set_error("v2p_env_attach_ball: racket + ball needs the link-per-lane schedule, contacts on and the PGS solver");
+        return V2P_ERR_UNSUPPORTED;
+    }
+    if (!e->ball) e->ball = new (std::nothrow) BallDev();
+    if (!e->ball) { set_error("v2p_env_attach_ball: out of host memory"); return V2P_ERR_NOMEM; }
+    BallDev& d = *e->ball;
+    d.radius = c->radius; d.mass = c->mass; d.inv_mass = 1.f / c->mass; d.inv_inertia = 1.f / c->inertia;
+    d.rest_ground = c->restitution_ground; d.fric_ground = c->friction_ground; d.rest_racket = c->restitution_racket; d.fric_racket = c->friction_racket;
+    d.bounce_thr = c->bounce_threshold_velocity; d.ang_damp = c->angular_damping; d.max_ang_vel = c->max_angular_velocity; d.spin_scale = c->spin_scale;
+    d.racket_link = c->racket_link; d.ncyl = c->num_cylinders; d.enabled = 1;
+    d.sub_per_sim = e->substeps_per_sim;
+    memcpy(d.cyl, c->cylinders, sizeof(d.cyl));
+    memcpy(d.racket_off, c->racket_offset, sizeof(d.racket_off));
+    d.state = b->ball_state; d.racket_state = b->racket_state; d.per_sim = b->ball_per_sim; d.hit_per_sim = b->racket_hit_per_sim; d.contact = b->ball_contact;
+    return V2P_OK;
 }
 
 static void profile_free(v2p_env* e) {

@@ -17,6 +17,19 @@ constexpr int LINK_SLOTS = 50;
 constexpr int WS_SLOTS = LINK_SLOTS * NB;
 
 
+// racket + ball (v2p_env_attach_ball): parameters by value, buffers borrowed from the caller
+struct BallDev {
+    float radius, mass, inv_mass, inv_inertia, rest_ground, fric_ground, rest_racket, fric_racket, bounce_thr, ang_damp, max_ang_vel, spin_scale;
+    int32_t racket_link, ncyl, sub_per_sim, enabled;
+    float cyl[2][8];       // centre 3, unit axis 3, half length, radius; in the racket link's frame
+    float racket_off[3];   // origin of the exported racket rigid body in the link's frame
+    float* state;          // [N,13] ball root state (pos quat vel angvel), read at the start of a step, written at its end
+    float* racket_state;   // [N,13] rigid-body state of the racket (rigid body 24 of the reference's tensor)
+    float* per_sim;        // [N,nsim,13] ball state after each simulate() call
+    int32_t* hit_per_sim;  // [N,nsim] racket-ball contact force non-zero in the call's last substep
+    float* contact;        // [N,2,3] force on the ball from the racket / from the ground, last substep
+};
+
 struct PhysArgs {
     const DevModel* __restrict__ model;
     float* __restrict__ state;
@@ -50,6 +63,7 @@ struct PhysArgs {
     unsigned long long ord_pack[2];  // impulse sweep decode them with scalar ALU ops instead of dependent scalar loads
     int64_t n;
     EnvParams p;
+    BallDev ball;
 };
 
 

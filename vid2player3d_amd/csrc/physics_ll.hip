@@ -146,11 +146,18 @@ __device__ __forceinline__ void grp_argmax(float& v, int& k) {
 #endif
 constexpr int LL_WPB = V2P_LL_WPB;
 constexpr int PARK_TAR = 0, PARK_W0 = 3, PARK_XD0 = 6, PARK_Q = 9, PARK_X = 13, PARK_SLOTS = 16;  // LDS parking slots (dwords per lane)
+// ball block (64 floats per env, after the parking area of the wave): state 13 | aero force 3 | ground contact: active gap bias lambda3 |
+// racket point j at BL_RK + 16 j: active gap bias rl3 n3 lambda3
+constexpr int BL_POS = 0, BL_QUAT = 3, BL_VEL = 7, BL_ANG = 10, BL_F = 13, BL_GA = 16, BL_GGAP = 17, BL_GBIAS = 18, BL_GLAM = 19, BL_RK = 24,
+              RK_A = 0, RK_GAP = 1, RK_BIAS = 2, RK_RL = 3, RK_N = 6, RK_LAM = 9, BL_SLOTS = 64;
+constexpr int LDS_FLOATS_PER_WAVE = PARK_SLOTS * 64 + 2 * BL_SLOTS;
 // TGS: temporal Gauss-Seidel with frozen Jacobians (v2p_sim_cfg.solver_type 1; the model is stated in oracle/phys/v2p_phys_oracle.c):
 // cbias[] then holds the GAP of each point, advanced after every sweep, and the row bias is evaluated where it is used.
 // DIAG: the per-phase cycle counters (V2P_PHASE_TIMING) and per-wave timeline stamps (V2P_WAVE_TIMES) are compiled into a separate
 // instantiation: in the production kernel they cost registers (spills) and ~2 scalar instructions per probe inside the sweep loops.
-template <bool CONTACT, bool MULTI, bool TGS, bool DIAG>
+// BALL: racket + ball: the first idle lane of an env (lb == 24) simulates the free ball, its state and the ball contact
+// records live in a 64-float LDS block per env; the ball-racket rows are solved inside the block update of the racket's link.
+template <bool CONTACT, bool MULTI, bool TGS, bool DIAG, bool BALL>
 __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(PhysArgs a) {
     const int64_t N = a.n;
     const int lane = threadIdx.x & 63;
@@ -182,7 +189,8 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
     // the velocities at the start of the sweep).  Holding them in registers made the allocator spill them (or something else) to
     // scratch - private memory that ends up as HBM write traffic; 9 dwords x 64 lanes of LDS per wave cost nothing.
     extern __shared__ float park_all[];
-    float* const park = park_all + (threadIdx.x >> 6) * (PARK_SLOTS * 64) + lane;  // slot k of this lane: park[k * 64]
+    float* const park = park_all + (threadIdx.x >> 6) * LDS_FLOATS_PER_WAVE + lane;  // slot k of this lane: park[k * 64]
+    volatile float* const bl = park_all + (threadIdx.x >> 6) * LDS_FLOATS_PER_WAVE + PARK_SLOTS * 64 + half * BL_SLOTS;  // this env's ball block
     auto park_put3 = [&](int slot, V3 v) { park[slot * 64] = v.x; park[(slot + 1) * 64] = v.y; park[(slot + 2) * 64] = v.z; };
     auto park_get3 = [&](int slot) -> V3 { return V3{park[slot * 64], park[(slot + 1) * 64], park[(slot + 2) * 64]}; };
 
@@ -249,6 +257,14 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
     }
 
     park_put3(PARK_TAR, tar);  // constant for the whole launch
+    const BallDev& BP = a.ball;
+    const bool ball_lane = BALL && lb == NB;  // the first idle lane of the env carries the ball
+    if (ball_lane) {
+#pragma unroll
+        for (int k = 0; k < 13; ++k) bl[k] = BP.state[e * 13 + k];
+#pragma unroll
+        for (int k = 13; k < BL_SLOTS; ++k) bl[k] = 0.f;
+    }
     long long tprev = DIAG && a.prof ? clock64() : 0;
     const long long wt0 = DIAG && a.wave_times ? wall_clock64() : 0;
     const int key_pred = DIAG && a.wave_times ? a.pair_key[e] : 0;  // what the launch order was built from (diagnostics)
@@ -324,6 +340,69 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
         // pose of the link: next used by contact generation, then by the integration
         park[PARK_Q * 64] = q.x; park[(PARK_Q + 1) * 64] = q.y; park[(PARK_Q + 2) * 64] = q.z; park[(PARK_Q + 3) * 64] = q.w;
         park_put3(PARK_X, x);
+        if (BALL) {
+            // pose and (start-of-substep) velocity of the racket's link, handed to the ball lane of the same env
+            const int src = base + BP.racket_link;
+            const Q4 wq = pull(q, src);
+            const V3 wx = pull(x, src), ww = pull(w, src), wxd = pull(xd, src);
+            if (ball_lane) {
+                const V3 bp{bl[BL_POS], bl[BL_POS + 1], bl[BL_POS + 2]}, bv{bl[BL_VEL], bl[BL_VEL + 1], bl[BL_VEL + 2]}, bw{bl[BL_ANG], bl[BL_ANG + 1], bl[BL_ANG + 2]};
+                if (sub % BP.sub_per_sim == 0) {
+                    // aerodynamic force, re-evaluated before every simulate() call (humanoid_smpl_im_mvae.py:711-739, utils/tennis_ball.py)
+                    const float kf = 1.21f * 3.14159265358979f * 0.032f * 0.032f * 0.5f, cd = 0.55f;
+                    const float sp = PHYS_SQRT(dot(bv, bv)), vs = sp == 0.f ? 1.f : sp;
+                    const V3 vn = PHYS_RCP(vs) * bv;
+                    const V3 vt = cross(vn, V3{0.f, 0.f, -1.f}), lt = cross(vt, vn);
+                    const float vspin = PHYS_SQRT(dot(bw, bw)) * (1.f / 6.28318530717959f);
+                    float cl = PHYS_RCP(2.f + fabsf(vs * PHYS_RCP(vspin * BP.spin_scale + 1e-6f)));
+                    cl = vspin > 0.f ? -cl : cl;
+                    const V3 F = (-kf * cd * vs) * bv - (kf * cl * vs * vs) * lt;
+                    bl[BL_F] = F.x; bl[BL_F + 1] = F.y; bl[BL_F + 2] = F.z;
+                }
+                const V3 F{bl[BL_F], bl[BL_F + 1], bl[BL_F + 2]};
+                const V3 bvs = bv + h * (V3{0.f, 0.f, P.gravity_z} + BP.inv_mass * F);  // free flight: v*
+                bl[BL_VEL] = bvs.x; bl[BL_VEL + 1] = bvs.y; bl[BL_VEL + 2] = bvs.z;
+                const float ih = PHYS_RCP(h), coff = P.contact_offset;
+                // ---- ball x ground (speculative margin: the distance the ball can close within this substep)
+                {
+                    const float gap = bp.z - BP.radius;
+                    const bool on = CONTACT && gap < coff + h * fmaxf(0.f, -bv.z);
+                    float bias = gap >= 0.f ? gap * ih : fmaxf(P.erp * gap * ih, -P.max_depen);
+                    if (bvs.z < -BP.bounce_thr && gap * ih + bvs.z < 0.f) bias = fminf(bias, BP.rest_ground * bvs.z);  // restitution
+                    bl[BL_GA] = on ? 1.f : 0.f; bl[BL_GGAP] = gap; bl[BL_GBIAS] = bias;
+                    bl[BL_GLAM] = 0.f; bl[BL_GLAM + 1] = 0.f; bl[BL_GLAM + 2] = 0.f;
+                }
+                // ---- ball x the racket's solid cylinders: closest point, normal from the cylinder to the ball
+                const M3 Rw = q2mat(wq);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    volatile float* rk = bl + BL_RK + 16 * j;
+                    bool on = false;
+                    if (CONTACT && j < BP.ncyl) {
+                        const V3 cw = wx + mul(Rw, V3{BP.cyl[j][0], BP.cyl[j][1], BP.cyl[j][2]}), aw = mul(Rw, V3{BP.cyl[j][3], BP.cyl[j][4], BP.cyl[j][5]});
+                        const float hl = BP.cyl[j][6], rc = BP.cyl[j][7];
+                        const V3 d = bp - cw;
+                        const float t = dot(d, aw);
+                        const V3 qv = d - t * aw;
+                        const float rho = PHYS_SQRT(dot(qv, qv));
+                        const float tc = fminf(fmaxf(t, -hl), hl), kq = rho > rc ? rc * PHYS_RCP(rho) : 1.f;
+                        const V3 pt = cw + tc * aw + kq * qv;
+                        const V3 ev = bp - pt;
+                        const float dist = PHYS_SQRT(dot(ev, ev));
+                        const V3 n = dist > 1e-9f ? PHYS_RCP(dist) * ev : (t >= 0.f ? aw : -aw);
+                        const V3 rl = pt - wx;
+                        const float vrel = dot(bv - wxd - cross(ww, rl), n);
+                        const float gap = dist - BP.radius;
+                        on = gap < coff + h * fmaxf(0.f, -vrel);
+                        rk[RK_GAP] = gap;
+                        rk[RK_RL] = rl.x; rk[RK_RL + 1] = rl.y; rk[RK_RL + 2] = rl.z;
+                        rk[RK_N] = n.x; rk[RK_N + 1] = n.y; rk[RK_N + 2] = n.z;
+                    }
+                    rk[RK_A] = on ? 1.f : 0.f;
+                    rk[RK_LAM] = 0.f; rk[RK_LAM + 1] = 0.f; rk[RK_LAM + 2] = 0.f;
+                }
+            }
+        }
         LLPH(1);
         // ================================================================ pass 2: articulated inertia, leaves -> root by level
         Sym3 Di{1.f, 0.f, 0.f, 1.f, 0.f, 1.f};
@@ -624,7 +703,10 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
             }
 
             LLSUB(18);
-            const unsigned long long tb = __ballot(valid && cnt > 0);
+            // (with a ball: the racket's link joins the touched links while the ball is in contact with a cylinder)
+            const bool ballhit = BALL && valid && lb == BP.racket_link && (bl[BL_RK + RK_A] != 0.f || bl[BL_RK + 16 + RK_A] != 0.f);
+            const bool ballground = BALL && ball_lane && bl[BL_GA] != 0.f;
+            const unsigned long long tb = __ballot(valid && (cnt > 0 || ballhit));
             const unsigned m0 = (unsigned)tb, m1 = (unsigned)(tb >> 32);
             if (DIAG && a.wave_times) { const int tt = __popc(half ? m1 : m0); tsum += tt; tmaxs = tt > tmaxs ? tt : tmaxs; }
             if (last) {
@@ -634,7 +716,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                 for (unsigned t = mine; t; t &= t - 1) { const int dd = M.depth[__ffs(t) - 1]; kdep = dd > kdep ? dd : kdep; }
             }
             if (DIAG && a.prof && (blockIdx.x & 63) == 0 && lane == 0) { atomicAdd((unsigned long long*)&a.prof[9], (unsigned long long)(__popc(m0) + __popc(m1))); atomicAdd((unsigned long long*)&a.prof[10], 1ull); }
-            if ((m0 | m1) && P.n_iter > 0) {
+            if (((m0 | m1) || (BALL && __any(ballground))) && P.n_iter > 0) {
                 // deepest touched link of either env: links below it are never read during the sweep, so Lambda and the
                 // per-update propagation stop there; their velocities catch up once at the end (the propagation is linear)
                 // (each env stops at ITS deepest touched link, so its arithmetic does not depend on which env shares the wave)
@@ -706,6 +788,31 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                     }
                 }
 
+                // direction a = 0, 1, 2 of a ball x racket point: its normal and the tangent basis t1 = normalize(n x z) (n x x when n is
+                // within 1e-3 of +-z), t2 = n x t1 - the oracle's rule
+                auto ball_dirs = [&](V3 n, V3& t1, V3& t2) {
+                    t1 = cross(n, V3{0.f, 0.f, 1.f});
+                    if (dot(t1, t1) < 1e-6f) t1 = cross(n, V3{1.f, 0.f, 0.f});
+                    t1 = rsqrtf(dot(t1, t1)) * t1;
+                    t2 = cross(n, t1);
+                };
+                if (BALL && ballhit) {
+                    // row biases of the ball x racket points from the velocities before the sweep (restitution: Newton, against the approach speed)
+                    const V3 bv{bl[BL_VEL], bl[BL_VEL + 1], bl[BL_VEL + 2]}, bw{bl[BL_ANG], bl[BL_ANG + 1], bl[BL_ANG + 2]};
+                    const float ih = PHYS_RCP(h);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        volatile float* rk = bl + BL_RK + 16 * j;
+                        if (rk[RK_A] != 0.f) {
+                            const V3 n{rk[RK_N], rk[RK_N + 1], rk[RK_N + 2]}, rl{rk[RK_RL], rk[RK_RL + 1], rk[RK_RL + 2]};
+                            const float gap = rk[RK_GAP];
+                            const float vn0 = dot(bv + cross(bw, -BP.radius * n) - xd - cross(w, rl), n);
+                            float bias = gap >= 0.f ? gap * ih : fmaxf(P.erp * gap * ih, -P.max_depen);
+                            if (vn0 < -BP.bounce_thr && gap * ih + vn0 < 0.f) bias = fminf(bias, BP.rest_racket * vn0);
+                            rk[RK_BIAS] = bias;
+                        }
+                    }
+                }
                 LLPH(5);
                 park_put3(PARK_W0, w);  // the sweep's total delta-velocity of a link = its velocity at the end - these
                 park_put3(PARK_XD0, xd);
@@ -799,6 +906,45 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                                     }
                                     clam[c] = V3{ln, l1, l2};
                                 }
+                                if (BALL && ballhit) {
+                                    // ---- ball x racket points: two-body rows (ball point velocity minus racket point velocity); the ball side is
+                                    // a free sphere (1/m, 1/I), the link side goes through Lambda_b like every row of this block
+                                    V3 bv{bl[BL_VEL], bl[BL_VEL + 1], bl[BL_VEL + 2]}, bw{bl[BL_ANG], bl[BL_ANG + 1], bl[BL_ANG + 2]};
+#pragma unroll 1
+                                    for (int j = 0; j < 2; ++j) {
+                                        volatile float* rk = bl + BL_RK + 16 * j;
+                                        if (rk[RK_A] == 0.f) continue;
+                                        const V3 n{rk[RK_N], rk[RK_N + 1], rk[RK_N + 2]}, rl{rk[RK_RL], rk[RK_RL + 1], rk[RK_RL + 2]};
+                                        V3 t1, t2;
+                                        ball_dirs(n, t1, t2);
+                                        const V3 rb = -BP.radius * n;
+                                        float lamn = rk[RK_LAM];
+#pragma unroll 1
+                                        for (int ax = 0; ax < 3; ++ax) {
+                                            const V3 dir = ax == 0 ? n : (ax == 1 ? t1 : t2);
+                                            const V3 jn = cross(rl, dir), jb = cross(rb, dir);
+                                            const V3 yw = mul(Lam.A, jn) + mul(Lam.B, dir);
+                                            const V3 yv = V3{dot(col(Lam.B, 0), jn), dot(col(Lam.B, 1), jn), dot(col(Lam.B, 2), jn)} + mul(Lam.C, dir);
+                                            const float wii = dot(jn, yw) + dot(dir, yv) + BP.inv_mass + BP.inv_inertia * dot(jb, jb);
+                                            const float rel = dot(dir, bv) + dot(jb, bw) - dot(jn, wl) - dot(dir, xl) + (ax == 0 ? rk[RK_BIAS] : 0.f);
+                                            const float old = rk[RK_LAM + ax];
+                                            float nl = old - rel * __builtin_amdgcn_rcpf(wii);
+                                            if (ax == 0) nl = fmaxf(nl, 0.f);
+                                            else { const float lim = BP.fric_racket * lamn; nl = fminf(fmaxf(nl, -lim), lim); }
+                                            const float dl = nl - old;
+                                            rk[RK_LAM + ax] = nl;
+                                            if (ax == 0) lamn = nl;
+                                            bv = bv + (dl * BP.inv_mass) * dir;      // +impulse on the ball
+                                            bw = bw + (dl * BP.inv_inertia) * jb;
+                                            wl = wl - dl * yw;                        // -impulse on the racket's link
+                                            xl = xl - dl * yv;
+                                            un = un - dl * jn;
+                                            uf = uf - dl * dir;
+                                        }
+                                    }
+                                    bl[BL_VEL] = bv.x; bl[BL_VEL + 1] = bv.y; bl[BL_VEL + 2] = bv.z;
+                                    bl[BL_ANG] = bw.x; bl[BL_ANG + 1] = bw.y; bl[BL_ANG + 2] = bw.z;
+                                }
                                 Dw = wl - w;  // = tw + Lambda (un, uf): what this link's child (if it is next) starts from
                                 Dv = xl - xd;
                             }
@@ -865,6 +1011,35 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                         }
                         LLSUB(14);
                     }
+                    if (BALL) {
+                        // ---- ball x ground: the last rows of the iteration (point at -R z of the centre; rows n = z, t1 = x, t2 = y)
+                        bool bmoved = false;
+                        if (ballground) {
+                            V3 bv{bl[BL_VEL], bl[BL_VEL + 1], bl[BL_VEL + 2]}, bw{bl[BL_ANG], bl[BL_ANG + 1], bl[BL_ANG + 2]};
+                            const V3 rb{0.f, 0.f, -BP.radius};
+                            float lamn = bl[BL_GLAM];
+#pragma unroll
+                            for (int ax = 0; ax < 3; ++ax) {
+                                const V3 dir = ax == 0 ? V3{0.f, 0.f, 1.f} : (ax == 1 ? V3{1.f, 0.f, 0.f} : V3{0.f, 1.f, 0.f});
+                                const V3 jb = cross(rb, dir);
+                                const float wii = BP.inv_mass + BP.inv_inertia * dot(jb, jb);
+                                const float rel = dot(dir, bv) + dot(jb, bw) + (ax == 0 ? bl[BL_GBIAS] : 0.f);
+                                const float old = bl[BL_GLAM + ax];
+                                float nl = old - rel * __builtin_amdgcn_rcpf(wii);
+                                if (ax == 0) nl = fmaxf(nl, 0.f);
+                                else { const float lim = BP.fric_ground * lamn; nl = fminf(fmaxf(nl, -lim), lim); }
+                                const float dl = nl - old;
+                                bl[BL_GLAM + ax] = nl;
+                                if (ax == 0) lamn = nl;
+                                bv = bv + (dl * BP.inv_mass) * dir;
+                                bw = bw + (dl * BP.inv_inertia) * jb;
+                                bmoved = bmoved || dl != 0.f;
+                            }
+                            bl[BL_VEL] = bv.x; bl[BL_VEL + 1] = bv.y; bl[BL_VEL + 2] = bv.z;
+                            bl[BL_ANG] = bw.x; bl[BL_ANG + 1] = bw.y; bl[BL_ANG + 2] = bw.z;
+                        }
+                        if (__any(bmoved)) moved = true;
+                    }
                     if (!TGS && !moved) break;  // a whole iteration without any change: the remaining ones would repeat it (PGS: fixed biases)
                 }
                 // links below the deepest touched one: one catch-up pass with the accumulated motion of their parents
@@ -915,6 +1090,56 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                 q = qnormalize(qmul(rotvec_to_quat(h * w0), q));  // world-frame rate: left multiply
             }
         }
+        if (BALL) {
+            // force on the ball from the racket in this substep (sum over the two cylinders), world axes
+            V3 frk{0.f, 0.f, 0.f};
+            if (ball_lane || (valid && lb == BP.racket_link)) {
+                const float ih = PHYS_RCP(h);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    volatile float* rk = bl + BL_RK + 16 * j;
+                    if (rk[RK_A] != 0.f) {
+                        const V3 n{rk[RK_N], rk[RK_N + 1], rk[RK_N + 2]};
+                        V3 t1, t2;
+                        t1 = cross(n, V3{0.f, 0.f, 1.f});
+                        if (dot(t1, t1) < 1e-6f) t1 = cross(n, V3{1.f, 0.f, 0.f});
+                        t1 = rsqrtf(dot(t1, t1)) * t1;
+                        t2 = cross(n, t1);
+                        frk = frk + ih * (rk[RK_LAM] * n + rk[RK_LAM + 1] * t1 + rk[RK_LAM + 2] * t2);
+                    }
+                }
+            }
+            if (ball_lane) {
+                // ---- the ball: angular damping, clamp, integrate; outputs after the last substep of every simulate() call
+                V3 bp{bl[BL_POS], bl[BL_POS + 1], bl[BL_POS + 2]}, bv{bl[BL_VEL], bl[BL_VEL + 1], bl[BL_VEL + 2]}, bw{bl[BL_ANG], bl[BL_ANG + 1], bl[BL_ANG + 2]};
+                Q4 bq{bl[BL_QUAT], bl[BL_QUAT + 1], bl[BL_QUAT + 2], bl[BL_QUAT + 3]};
+                bw = PHYS_RCP(1.f + h * BP.ang_damp) * bw;
+                const float n2 = dot(bw, bw);
+                if (n2 > BP.max_ang_vel * BP.max_ang_vel) bw = (BP.max_ang_vel * rsqrtf(n2)) * bw;
+                bp = bp + h * bv;
+                bq = qnormalize(qmul(rotvec_to_quat(h * bw), bq));
+                bl[BL_POS] = bp.x; bl[BL_POS + 1] = bp.y; bl[BL_POS + 2] = bp.z;
+                bl[BL_QUAT] = bq.x; bl[BL_QUAT + 1] = bq.y; bl[BL_QUAT + 2] = bq.z; bl[BL_QUAT + 3] = bq.w;
+                bl[BL_ANG] = bw.x; bl[BL_ANG + 1] = bw.y; bl[BL_ANG + 2] = bw.z;
+                if (live_env && sub % BP.sub_per_sim == BP.sub_per_sim - 1) {
+                    const int ks = sub / BP.sub_per_sim, nsim = nsub / BP.sub_per_sim;
+                    float* o = BP.per_sim + (e * nsim + ks) * 13;
+                    o[0] = bp.x; o[1] = bp.y; o[2] = bp.z; o[3] = bq.x; o[4] = bq.y; o[5] = bq.z; o[6] = bq.w;
+                    o[7] = bv.x; o[8] = bv.y; o[9] = bv.z; o[10] = bw.x; o[11] = bw.y; o[12] = bw.z;
+                    BP.hit_per_sim[e * nsim + ks] = (frk.x != 0.f || frk.y != 0.f || frk.z != 0.f) ? 1 : 0;
+                }
+                if (last && live_env) {
+                    const float ih = PHYS_RCP(h);
+                    float* oc = BP.contact + e * 6;
+                    oc[0] = frk.x; oc[1] = frk.y; oc[2] = frk.z;
+                    oc[3] = bl[BL_GA] != 0.f ? bl[BL_GLAM + 1] * ih : 0.f; oc[4] = bl[BL_GA] != 0.f ? bl[BL_GLAM + 2] * ih : 0.f;
+                    oc[5] = bl[BL_GA] != 0.f ? bl[BL_GLAM] * ih : 0.f;
+                }
+            }
+            if (last && valid && live_env && !frozen && lb == BP.racket_link) {  // the reaction on the racket's link enters its net contact force below
+                park[PARK_W0 * 64] = frk.x; park[(PARK_W0 + 1) * 64] = frk.y; park[(PARK_W0 + 2) * 64] = frk.z;
+            }
+        }
         if (last && valid && live_env && !frozen) {
             // net contact force per body = sum of impulses / h  (refresh_net_contact_force_tensor)
             V3 cforce{0.f, 0.f, 0.f};
@@ -923,6 +1148,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
                     if (c < cnt) { cforce.z += clam[c].x * ih; cforce.x += clam[c].y * ih; cforce.y += clam[c].z * ih; }
+                if (BALL && lb == BP.racket_link) cforce = cforce - park_get3(PARK_W0);
             }
             float* oc = a.x_contact + (e * NB + b) * 3;
             oc[0] = cforce.x; oc[1] = cforce.y; oc[2] = cforce.z;
@@ -1027,11 +1253,24 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
             orr[10] = w.x; orr[11] = w.y; orr[12] = w.z;
         }
     }
+    if (BALL && live_env) {
+        if (ball_lane) {
+#pragma unroll
+            for (int k = 0; k < 13; ++k) BP.state[e * 13 + k] = bl[k];
+        }
+        if (valid && lb == BP.racket_link) {  // rigid body 24 of the reference's tensor: the racket frame, welded to this link
+            const V3 off = mul(q2mat(q), V3{BP.racket_off[0], BP.racket_off[1], BP.racket_off[2]});
+            const V3 rx = x + off, rv = xd + cross(w, off);
+            float* o = BP.racket_state + e * 13;
+            o[0] = rx.x; o[1] = rx.y; o[2] = rx.z; o[3] = q.x; o[4] = q.y; o[5] = q.z; o[6] = q.w;
+            o[7] = rv.x; o[8] = rv.y; o[9] = rv.z; o[10] = w.x; o[11] = w.y; o[12] = w.z;
+        }
+    }
     // rigid-body state [24][13] of the env: a lane's row is 13 dwords at a 52-byte stride, which as 13 scalar stores per lane left the
     // L2 with partial lines from two XCDs' worth of neighbours (PMC WRITE_SIZE 1.7x the bytes).  The rows are staged through the
     // (now idle) LDS parking area and leave as 78 contiguous 16-byte stores per env: full lines.
     {
-        float* const stage = park_all + (threadIdx.x >> 6) * (PARK_SLOTS * 64) + half * (NB * 13);
+        float* const stage = park_all + (threadIdx.x >> 6) * LDS_FLOATS_PER_WAVE + half * (NB * 13);
         if (valid) {
             float* o = stage + b * 13;
             o[0] = x.x; o[1] = x.y; o[2] = x.z;
@@ -1159,20 +1398,27 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s, float* actions) {
     a.shape_aug = env->shape_aug_dev;
     const bool multi = env->num_shapes > 1;  // per-env shapes: hull vertices come from the shape tables instead of the LDS copy
     const dim3 grid(blocks), block(64 * LL_WPB);
-    const size_t lds = sizeof(float) * PARK_SLOTS * 64 * LL_WPB;
+    const size_t lds = sizeof(float) * LDS_FLOATS_PER_WAVE * LL_WPB;
     const bool tgs = env->p.solver_type == 1;
     const bool diag = a.prof || a.wave_times;
-    if (diag && env->p.enable_contact && !tgs && !multi) {  // the instrumented build exists for the headline configuration only
-        hipLaunchKernelGGL((physics_ll_kernel<true, false, false, true>), grid, block, lds, s, a);
+    if (env->ball) a.ball = *env->ball;
+    if (env->ball && env->p.enable_contact && !tgs) {  // racket + ball: its own instantiation (PGS, with contacts)
+        if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, false, false, true>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((physics_ll_kernel<true, false, false, false, true>), grid, block, lds, s, a);
+    } else if (env->ball) {
+        set_error("physics: racket + ball runs with contacts on and the PGS solver");
+        return V2P_ERR_UNSUPPORTED;
+    } else if (diag && env->p.enable_contact && !tgs && !multi) {  // the instrumented build exists for the headline configuration only
+        hipLaunchKernelGGL((physics_ll_kernel<true, false, false, true, false>), grid, block, lds, s, a);
     } else if (env->p.enable_contact && tgs) {
-        if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, true, false>), grid, block, lds, s, a);
-        else hipLaunchKernelGGL((physics_ll_kernel<true, false, true, false>), grid, block, lds, s, a);
+        if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, true, false, false>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((physics_ll_kernel<true, false, true, false, false>), grid, block, lds, s, a);
     } else if (env->p.enable_contact) {
-        if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, false, false>), grid, block, lds, s, a);
-        else hipLaunchKernelGGL((physics_ll_kernel<true, false, false, false>), grid, block, lds, s, a);
+        if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, false, false, false>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((physics_ll_kernel<true, false, false, false, false>), grid, block, lds, s, a);
     } else {
-        if (multi) hipLaunchKernelGGL((physics_ll_kernel<false, true, false, false>), grid, block, lds, s, a);
-        else hipLaunchKernelGGL((physics_ll_kernel<false, false, false, false>), grid, block, lds, s, a);
+        if (multi) hipLaunchKernelGGL((physics_ll_kernel<false, true, false, false, false>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((physics_ll_kernel<false, false, false, false, false>), grid, block, lds, s, a);
     }
     env->pair_have = paired ? 1 : 0;
     return check_hip(hipGetLastError(), "physics_ll_kernel");

@@ -102,6 +102,8 @@ struct EnvParams {
 
 }  // namespace v2p
 
+namespace v2p { struct BallDev; }
+
 struct v2p_env {
     const v2p_model* model;   // shape 0 (the tree tables of every shape are identical)
     int num_shapes;           // > 1: per-env body shapes
@@ -132,6 +134,8 @@ struct v2p_env {
     int32_t* pair_done;
     int32_t* perm;            // [N] wave slot -> env for the next physics launch
     int pair_period;          // 0 = pairing off (v2p_sim_cfg.pair_envs_by_load = 0), else on
+    int substeps_per_sim;     // substeps of one simulate() call
+    v2p::BallDev* ball;       // racket + ball attached (v2p_env_attach_ball), else NULL
     hipEvent_t* prof_ev;      // 2 events per measured physics launch (v2p_env_profile_begin), else NULL
     int64_t prof_cap, prof_n;
     int pair_have;            // the last physics launch left (key, pos, start) that have not been scattered into perm yet

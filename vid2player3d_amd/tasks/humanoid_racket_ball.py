@@ -1,0 +1,118 @@
+"""The imitation task with vid2player's racket and ball in the simulation (BASELINE config 4's "racket+ball contacts").
+
+`vid2player/env/tasks/humanoid_smpl_im_mvae.py` puts two actors in every env: the SMPL humanoid with a racket welded to the right
+wrist (`smpl_mesh_humanoid_djokovic.xml:188-190`) and a free tennis ball (`tennis_ball.urdf`), applies the aerodynamic force of
+`apply_external_force_to_ball` (:711-739) before every `simulate()` call and polls the net contact forces after it (:752-783).  What
+this class takes from it is that PHYSICS: the observation / reward / MVAE machinery of the vid2player task is out of scope,
+the task logic stays the imitation task's (`HumanoidSMPLIM`).  Exposed like the reference's tensors:
+
+    _ball_root_states [N,13]     the ball actor's root state; write it (+ nothing else) to launch a ball, as `_reset_balls` does (:503-522)
+    _racket_rb_state  [N,13]     rigid body 24
+    _ball_states_per_sim [N,2,13], _racket_ball_contact_per_sim [N,2]   what the reference sees after each of the 2 simulate() calls
+    _has_bounce / _has_bounce_now / _bounce_pos, _has_racket_ball_contact(_now)   the flags of :731-737 and :773-779, same rules
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _lib, racket
+from ..model import load_baked_model
+from .humanoid_smpl_im import HumanoidSMPLIM
+
+BALL_R = racket.BALL["radius"]
+
+
+class HumanoidSMPLIMRacketBall(HumanoidSMPLIM):
+    def __init__(self, cfg, sim_params=None, physics_engine=None, device_type="cuda", device_id=0, headless=True):
+        env = cfg["env"]
+        base = env.get("body_model") or load_baked_model(default_humanoid_mass=env.get("default_humanoid_mass", 90.0), kp_scale=env.get("kp_scale", 1.0),
+                                                         kd_scale=env.get("kd_scale", env.get("kp_scale", 1.0)))
+        if isinstance(base, (list, tuple)):
+            raise NotImplementedError("racket + ball with per-clip body shapes is not built")
+        model, self.racket_geometry = racket.with_racket(base)
+        env["body_model"] = model
+        self.cfg_v2p = dict(cfg.get("v2p") or {})
+        super().__init__(cfg, sim_params, physics_engine, device_type, device_id, headless)
+        n, dev = self.num_envs, self.device
+        nsim = self.control_freq_inv
+        f = dict(dtype=torch.float32, device=dev)
+        self._ball_root_states = torch.zeros((n, 13), **f)
+        self._ball_root_states[:, 2] = 1.0   # start_pose of the ball actor (:430-431)
+        self._ball_root_states[:, 6] = 1.0
+        self._racket_rb_state = torch.zeros((n, 13), **f)
+        self._ball_states_per_sim = torch.zeros((n, nsim, 13), **f)
+        self._racket_ball_contact_per_sim = torch.zeros((n, nsim), dtype=torch.int32, device=dev)
+        self._ball_contact_forces = torch.zeros((n, 2, 3), **f)
+        self._has_bounce = torch.zeros(n, dtype=torch.bool, device=dev)
+        self._has_bounce_now = torch.zeros(n, dtype=torch.bool, device=dev)
+        self._bounce_pos = torch.zeros((n, 3), **f)
+        self._has_racket_ball_contact = torch.zeros(n, dtype=torch.bool, device=dev)
+        self._has_racket_ball_contact_now = torch.zeros(n, dtype=torch.bool, device=dev)
+        mat = dict(racket.BALL_MATERIAL)
+        if "restitution" in self.cfg_v2p:  # cfg_v2p.restitution sets ball AND racket head (:414, :436); the plane keeps 0
+            mat["rest_ground"], mat["rest_racket"] = 0.5 * self.cfg_v2p["restitution"], self.cfg_v2p["restitution"]
+        if "ball_friction" in self.cfg_v2p or "racket_friction" in self.cfg_v2p:
+            bf, rf = self.cfg_v2p.get("ball_friction", 0.8), self.cfg_v2p.get("racket_friction", 0.8)
+            mat["fric_ground"], mat["fric_racket"] = 0.5 * (bf + 1.0), 0.5 * (bf + rf)
+        g = self.racket_geometry
+        c = _lib.BallCfg(radius=racket.BALL["radius"], mass=racket.BALL["mass"], inertia=racket.BALL["inertia"],
+                         restitution_ground=mat["rest_ground"], friction_ground=mat["fric_ground"], restitution_racket=mat["rest_racket"],
+                         friction_racket=mat["fric_racket"], bounce_threshold_velocity=self.sim_params.physx.bounce_threshold_velocity,
+                         angular_damping=mat["ang_damp"], max_angular_velocity=mat["max_ang_vel"], spin_scale=self.cfg_v2p.get("spin_scale", 1.0),
+                         racket_link=g["racket_link"], num_cylinders=len(g["cylinders"]))
+        for k, cy in enumerate(g["cylinders"]):
+            c.cylinders[k][:] = [float(x) for x in list(cy["center"]) + list(cy["axis"]) + [cy["half_len"], cy["radius"]]]
+        c.racket_offset[:] = [float(x) for x in g["racket_offset"]]
+        b = _lib.BallBuffers(ball_state=self._ball_root_states.data_ptr(), racket_state=self._racket_rb_state.data_ptr(),
+                             ball_per_sim=self._ball_states_per_sim.data_ptr(), racket_hit_per_sim=self._racket_ball_contact_per_sim.data_ptr(),
+                             ball_contact=self._ball_contact_forces.data_ptr())
+        _lib.check(self._lib.v2p_env_attach_ball(self._h_env, C.byref(c), C.byref(b)), "v2p_env_attach_ball")
+        self.ball_material = mat
+
+    # ------------------------------------------------------------------ the reference's flag bookkeeping around the physics step
+    def reset_balls(self, env_ids, launch_pos, launch_vel, launch_ang_vel):
+        """`_reset_balls` (:503-522) with the launch state given by the caller (the reference draws it from its trajectory generator)."""
+        ids = torch.as_tensor(env_ids, device=self.device, dtype=torch.long)
+        self._ball_root_states[ids, 0:3] = launch_pos
+        self._ball_root_states[ids, 3:7] = torch.tensor([0.0, 0.0, 0.0, 1.0], device=self.device)
+        self._ball_root_states[ids, 7:10] = launch_vel
+        self._ball_root_states[ids, 10:13] = launch_ang_vel
+        self._has_bounce[ids] = False
+        self._bounce_pos[ids] = 0
+        self._has_racket_ball_contact[ids] = False
+
+    def _ball_flags_before(self):
+        self._ball_start = self._ball_root_states.clone()
+        self._has_bounce_now[:] = False
+        self._has_racket_ball_contact_now[:] = False
+
+    def _ball_flags_after(self):
+        """apply_external_force_to_ball's bounce test on the ball position at the START of each simulate() call (:731-737) and the
+        contact-force poll after it (:773-779)."""
+        thresh = BALL_R * (6 if self.sim_params.substeps > 2 else 4)
+        starts = [self._ball_start] + [self._ball_states_per_sim[:, k] for k in range(self.control_freq_inv - 1)]
+        for k, st in enumerate(starts):
+            now = ~self._has_bounce & (st[:, 2] <= thresh)
+            self._has_bounce_now |= now
+            self._has_bounce |= now
+            self._bounce_pos[now] = st[now, 0:3]
+            if self.sim_params.substeps <= 2:
+                hit = ~self._has_racket_ball_contact & (self._racket_ball_contact_per_sim[:, k] != 0)
+                self._has_racket_ball_contact_now |= hit
+                self._has_racket_ball_contact |= hit
+
+    def step(self, actions):
+        self._ball_flags_before()
+        super().step(actions)
+        self._ball_flags_after()
+
+    def step_fused(self, actions):
+        self._ball_flags_before()
+        super().step_fused(actions)
+        self._ball_flags_after()
+
+    def _physics_step(self):
+        if not hasattr(self, "_ball_start"):
+            self._ball_flags_before()
+        super()._physics_step()
