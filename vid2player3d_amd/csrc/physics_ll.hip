@@ -61,6 +61,10 @@ __device__ __forceinline__ V3 residual_wrench(const float* root_rot, float a0, f
 
 constexpr int LPE = 32;  // lanes per environment
 
+// wave-wide "any lane": a compare of the ballot in scalar registers (HIP's __any materialises the predicate as a 0/1 VGPR first:
+// 2 VALU instructions per use, and the sweep loops use it ~20 times per block update)
+__device__ __forceinline__ bool any64(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
 __device__ __forceinline__ float pull(float v, int src_lane) {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
 }
@@ -89,20 +93,47 @@ __device__ __forceinline__ M3 from_next(const M3& a) {
     for (int i = 0; i < 9; ++i) r.m[i] = from_next(a.m[i]);
     return r;
 }
-// value held by the parent lane (ds_bpermute); the level flag is kept in the signature for schedule experiments
+// lane i <- lane i-1 through the DPP network (wave_shr:1): the parent of a link that directly follows it
+__device__ __forceinline__ float from_prev(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138, 0xf, 0xf, false)); }
+#ifndef V2P_LL_DPP_PARENT
+#define V2P_LL_DPP_PARENT 0
+#endif
+// value held by the parent lane.  `nonchain` = some link of the level being processed does not directly follow its parent: then the
+// pull goes through ds_bpermute (an LDS round trip, ~100+ cycles of exposed latency per level for a wave whose partner is stalled
+// too); on chain-only levels (V2P_LL_DPP_PARENT) it is a DPP shift, a VALU-speed move.  The branch is wave-uniform.
 struct ParentPull {
     int plane;
     bool chain;
-    __device__ __forceinline__ float operator()(float v, bool) const { return pull(v, plane); }
-    __device__ __forceinline__ V3 operator()(V3 v, bool l) const { return V3{(*this)(v.x, l), (*this)(v.y, l), (*this)(v.z, l)}; }
-    __device__ __forceinline__ Q4 operator()(Q4 q, bool l) const { return Q4{(*this)(q.x, l), (*this)(q.y, l), (*this)(q.z, l), (*this)(q.w, l)}; }
-    __device__ __forceinline__ Sym3 operator()(const Sym3& a, bool l) const {
-        return Sym3{(*this)(a.xx, l), (*this)(a.xy, l), (*this)(a.xz, l), (*this)(a.yy, l), (*this)(a.yz, l), (*this)(a.zz, l)};
-    }
-    __device__ __forceinline__ M3 operator()(const M3& a, bool l) const {
-        M3 r;
+    template <typename F>
+    __device__ __forceinline__ static void each(float* dst, const float* src, int n, F f) {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) r.m[i] = (*this)(a.m[i], l);
+        for (int i = 0; i < n; ++i) dst[i] = f(src[i]);
+    }
+    __device__ __forceinline__ float operator()(float v, bool nonchain) const {
+        if (V2P_LL_DPP_PARENT && !nonchain) return from_prev(v);
+        return pull(v, plane);
+    }
+    __device__ __forceinline__ V3 operator()(V3 v, bool nonchain) const {
+        if (V2P_LL_DPP_PARENT && !nonchain) return V3{from_prev(v.x), from_prev(v.y), from_prev(v.z)};
+        return V3{pull(v.x, plane), pull(v.y, plane), pull(v.z, plane)};
+    }
+    __device__ __forceinline__ Q4 operator()(Q4 q, bool nonchain) const {
+        if (V2P_LL_DPP_PARENT && !nonchain) return Q4{from_prev(q.x), from_prev(q.y), from_prev(q.z), from_prev(q.w)};
+        return Q4{pull(q.x, plane), pull(q.y, plane), pull(q.z, plane), pull(q.w, plane)};
+    }
+    __device__ __forceinline__ Sym3 operator()(const Sym3& a, bool nonchain) const {
+        if (V2P_LL_DPP_PARENT && !nonchain) return Sym3{from_prev(a.xx), from_prev(a.xy), from_prev(a.xz), from_prev(a.yy), from_prev(a.yz), from_prev(a.zz)};
+        return Sym3{pull(a.xx, plane), pull(a.xy, plane), pull(a.xz, plane), pull(a.yy, plane), pull(a.yz, plane), pull(a.zz, plane)};
+    }
+    __device__ __forceinline__ M3 operator()(const M3& a, bool nonchain) const {
+        M3 r;
+        if (V2P_LL_DPP_PARENT && !nonchain) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) r.m[i] = from_prev(a.m[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) r.m[i] = pull(a.m[i], plane);
+        }
         return r;
     }
 };
@@ -145,12 +176,56 @@ __device__ __forceinline__ void grp_argmax(float& v, int& k) {
 #define V2P_LL_WPS 2   // waves per SIMD the register budget is set for
 #endif
 constexpr int LL_WPB = V2P_LL_WPB;
-constexpr int PARK_TAR = 0, PARK_W0 = 3, PARK_XD0 = 6, PARK_Q = 9, PARK_X = 13, PARK_SLOTS = 16;  // LDS parking slots (dwords per lane)
+// V2P_LL_PARK2: phase-scoped parking of values that a phase does not touch (link velocities during pass 2 / contact generation / the
+// Lambda recursion, Lambda of the root during contact generation, the contact records during the Lambda recursion): lowers the
+// register peak of those phases so that nothing long-lived is spilled ACROSS the sweep loops when the kernel is built for 3 waves/SIMD.
+#ifndef V2P_LL_PARK2
+#define V2P_LL_PARK2 0
+#endif
+constexpr bool PARK2 = V2P_LL_PARK2 != 0;
+// V2P_LL_PARK3: the contact records of a link (4 x offset, bias / gap, 3 impulses = 28 floats) live in the lane's LDS column instead of
+// registers: they are touched once per block update (by the one lane being solved), not inside the per-level loops, and leave their
+// 28 registers to the values those loops use.
+#ifndef V2P_LL_PARK3
+#define V2P_LL_PARK3 0
+#endif
+constexpr bool PARK3 = V2P_LL_PARK3 != 0;
+constexpr int PARK_TAR = 0, PARK_W0 = 3, PARK_XD0 = 6, PARK_Q = 9, PARK_X = 13, PARK_CR = 16, PARK_CB = 28, PARK_CL = 32,
+              PARK_SLOTS = PARK3 ? 44 : 16;  // LDS parking slots (dwords per lane)
+constexpr int ROOTLAM_FLOATS = 2 * 24;  // (PARK2) Lambda of the two root links while the contacts are generated
 // ball block (64 floats per env, after the parking area of the wave): state 13 | aero force 3 | ground contact: active gap bias lambda3 |
 // racket point j at BL_RK + 16 j: active gap bias rl3 n3 lambda3
 constexpr int BL_POS = 0, BL_QUAT = 3, BL_VEL = 7, BL_ANG = 10, BL_F = 13, BL_GA = 16, BL_GGAP = 17, BL_GBIAS = 18, BL_GLAM = 19, BL_RK = 24,
               RK_A = 0, RK_GAP = 1, RK_BIAS = 2, RK_RL = 3, RK_N = 6, RK_LAM = 9, BL_SLOTS = 64;
-constexpr int LDS_FLOATS_PER_WAVE = PARK_SLOTS * 64 + 2 * BL_SLOTS;
+constexpr int LDS_FLOATS_PER_WAVE = PARK_SLOTS * 64 + 2 * BL_SLOTS + ROOTLAM_FLOATS;
+// contact records of this lane's link: registers, or (PARK3) the lane's LDS column
+template <bool LDS>
+struct ContactStore;
+template <>
+struct ContactStore<false> {
+    V3 r_[4];
+    float b_[4];
+    V3 l_[4];
+    __device__ __forceinline__ explicit ContactStore(float*) {}
+    __device__ __forceinline__ V3 cr(int c) const { return r_[c]; }
+    __device__ __forceinline__ void set_cr(int c, V3 v) { r_[c] = v; }
+    __device__ __forceinline__ float bias(int c) const { return b_[c]; }
+    __device__ __forceinline__ void set_bias(int c, float v) { b_[c] = v; }
+    __device__ __forceinline__ V3 lam(int c) const { return l_[c]; }
+    __device__ __forceinline__ void set_lam(int c, V3 v) { l_[c] = v; }
+};
+template <>
+struct ContactStore<true> {
+    float* p;  // slot 0 of this lane's column
+    __device__ __forceinline__ explicit ContactStore(float* park) : p(park) {}
+    __device__ __forceinline__ V3 cr(int c) const { return V3{p[(PARK_CR + 3 * c) * 64], p[(PARK_CR + 3 * c + 1) * 64], p[(PARK_CR + 3 * c + 2) * 64]}; }
+    __device__ __forceinline__ void set_cr(int c, V3 v) { p[(PARK_CR + 3 * c) * 64] = v.x; p[(PARK_CR + 3 * c + 1) * 64] = v.y; p[(PARK_CR + 3 * c + 2) * 64] = v.z; }
+    __device__ __forceinline__ float bias(int c) const { return p[(PARK_CB + c) * 64]; }
+    __device__ __forceinline__ void set_bias(int c, float v) { p[(PARK_CB + c) * 64] = v; }
+    __device__ __forceinline__ V3 lam(int c) const { return V3{p[(PARK_CL + 3 * c) * 64], p[(PARK_CL + 3 * c + 1) * 64], p[(PARK_CL + 3 * c + 2) * 64]}; }
+    __device__ __forceinline__ void set_lam(int c, V3 v) { p[(PARK_CL + 3 * c) * 64] = v.x; p[(PARK_CL + 3 * c + 1) * 64] = v.y; p[(PARK_CL + 3 * c + 2) * 64] = v.z; }
+};
+
 // TGS: temporal Gauss-Seidel with frozen Jacobians (v2p_sim_cfg.solver_type 1; the model is stated in oracle/phys/v2p_phys_oracle.c):
 // cbias[] then holds the GAP of each point, advanced after every sweep, and the row bias is evaluated where it is used.
 // DIAG: the per-phase cycle counters (V2P_PHASE_TIMING) and per-wave timeline stamps (V2P_WAVE_TIMES) are compiled into a separate
@@ -193,6 +268,9 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
     volatile float* const bl = park_all + (threadIdx.x >> 6) * LDS_FLOATS_PER_WAVE + PARK_SLOTS * 64 + half * BL_SLOTS;  // this env's ball block
     auto park_put3 = [&](int slot, V3 v) { park[slot * 64] = v.x; park[(slot + 1) * 64] = v.y; park[(slot + 2) * 64] = v.z; };
     auto park_get3 = [&](int slot) -> V3 { return V3{park[slot * 64], park[(slot + 1) * 64], park[(slot + 2) * 64]}; };
+    // (PARK2) the link velocities leave the registers for the phases that do not touch them; the W0 / XD0 slots are free outside the sweep
+    auto park_vel = [&](const V3& w_, const V3& xd_) { if (PARK2) { park_put3(PARK_W0, w_); park_put3(PARK_XD0, xd_); } };
+    auto unpark_vel = [&](V3& w_, V3& xd_) { if (PARK2) { w_ = park_get3(PARK_W0); xd_ = park_get3(PARK_XD0); } };
 
     // ---- per-lane model constants
     const int par = b ? M.parents[b] : 0;
@@ -208,7 +286,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
     // opt-in (v2p_sim_cfg.freeze_terminated_envs): an env whose reset flag is set keeps its state; a wave whose two envs are frozen
     // skips the substeps altogether (frozen envs sort to the end of the launch order, so they share waves)
     const bool frozen = P.freeze_terminated && a.reset[e] == 1;
-    const int nsub = (P.freeze_terminated && !__any(!frozen)) ? 0 : P.nsub;
+    const int nsub = (P.freeze_terminated && !any64(!frozen)) ? 0 : P.nsub;
 
     // ---- state: the root lane carries the root pose/velocity, every other lane its joint
     Q4 q{0.f, 0.f, 0.f, 1.f}, jq{0.f, 0.f, 0.f, 1.f};
@@ -404,6 +482,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
             }
         }
         LLPH(1);
+        park_vel(w, xd);
         // ================================================================ pass 2: articulated inertia, leaves -> root by level
         Sym3 Di{1.f, 0.f, 0.f, 1.f, 0.f, 1.f};
         M3 E;
@@ -483,6 +562,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
         }
 
         LLPH(2);
+        unpark_vel(w, xd);
         // ================================================================ root: 6x6 solve (lane 0 of each env)
         Blocks Lam;  // operational-space inverse inertia of this lane's link (root: inverse articulated inertia)
         Lam.A = Lam.C = Sym3{1.f, 0.f, 0.f, 1.f, 0.f, 1.f};
@@ -530,14 +610,25 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
         }
 
         LLPH(3);
+        if (CONTACT) park_vel(w, xd);
+        float* const rootlam = park_all + (threadIdx.x >> 6) * LDS_FLOATS_PER_WAVE + PARK_SLOTS * 64 + 2 * BL_SLOTS + half * 24;
+        if (PARK2 && CONTACT && lb == 0) {  // only the root's Lambda exists yet: 21 floats per env, out of the way while contacts are generated
+            const float lv[21] = {Lam.A.xx, Lam.A.xy, Lam.A.xz, Lam.A.yy, Lam.A.yz, Lam.A.zz, Lam.B.m[0], Lam.B.m[1], Lam.B.m[2], Lam.B.m[3], Lam.B.m[4], Lam.B.m[5],
+                                  Lam.B.m[6], Lam.B.m[7], Lam.B.m[8], Lam.C.xx, Lam.C.xy, Lam.C.xz, Lam.C.yy, Lam.C.yz, Lam.C.zz};
+#pragma unroll
+            for (int k = 0; k < 21; ++k) rootlam[k] = lv[k];
+        }
+        if (PARK2 && CONTACT) {  // (the other lanes' values are placeholders until the recursion writes them)
+            Lam.A = Lam.C = Sym3{1.f, 0.f, 0.f, 1.f, 0.f, 1.f};
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Lam.B.m[i] = 0.f;
+        }
         q = Q4{park[PARK_Q * 64], park[(PARK_Q + 1) * 64], park[(PARK_Q + 2) * 64], park[(PARK_Q + 3) * 64]};
         x = park_get3(PARK_X);
         int cnt = 0;
-        V3 cr[4];
-        float cbias[4];
-        V3 clam[4];
+        ContactStore<PARK3> CS(park);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { cr[c] = V3{0.f, 0.f, 0.f}; cbias[c] = 0.f; clam[c] = V3{0.f, 0.f, 0.f}; }
+        for (int c = 0; c < 4; ++c) { CS.set_cr(c, V3{0.f, 0.f, 0.f}); CS.set_bias(c, 0.f); CS.set_lam(c, V3{0.f, 0.f, 0.f}); }
         if (CONTACT) {
             // ============================================================ contact generation: every lane scans its own hull
             // pass A marks the candidate vertices (z < contact_offset) in a per-lane 64-bit mask; the manifold reduction then
@@ -621,7 +712,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                     int s3 = t ? __ffsll((long long)t) - 1 : -1;
                     int ns = cntg < 4 ? cntg : 4;
                     const bool big = gon && cntg > 4;
-                    if (__any(big)) {
+                    if (any64(big)) {
                         if (DIAG && a.prof && (blockIdx.x & 63) == 0 && lane == 0) atomicAdd((unsigned long long*)&a.prof[15], 1ull);
                         // manifold reduction: deepest, farthest from it, extreme on either side of that line
                         const int k0s = k0 < 0 ? 0 : k0;
@@ -682,15 +773,16 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                 sel4[c] = sv == 0x7f ? -1 : sv;
             }
             cnt = (pack >> 28) & 7;
-            if (__any(cnt > 0)) {
+            if (any64(cnt > 0)) {
                 const M3 R = q2mat(q);
                 const float ih = 1.f / h;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const float4 uu = hullv(v0 + (sel4[c] < 0 ? 0 : sel4[c]));
-                    cr[c] = mul(R, V3{uu.x, uu.y, uu.z});
-                    float dz = x.z + cr[c].z;
-                    cbias[c] = TGS ? dz : (dz >= 0.f ? dz * ih : fmaxf(P.erp * dz * ih, -P.max_depen));
+                    const V3 crc = mul(R, V3{uu.x, uu.y, uu.z});
+                    CS.set_cr(c, crc);
+                    float dz = x.z + crc.z;
+                    CS.set_bias(c, TGS ? dz : (dz >= 0.f ? dz * ih : fmaxf(P.erp * dz * ih, -P.max_depen)));
                 }
             }
             if (a.contact_ids && last && valid && live_env && !frozen) {  // diagnostics (v2p_sim_cfg.debug_contacts)
@@ -703,6 +795,15 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
             }
 
             LLSUB(18);
+            if (PARK2 && lb == 0) {  // Lambda of the root back from its block
+                float lv[21];
+#pragma unroll
+                for (int k = 0; k < 21; ++k) lv[k] = rootlam[k];
+                Lam.A = Sym3{lv[0], lv[1], lv[2], lv[3], lv[4], lv[5]};
+#pragma unroll
+                for (int k = 0; k < 9; ++k) Lam.B.m[k] = lv[6 + k];
+                Lam.C = Sym3{lv[15], lv[16], lv[17], lv[18], lv[19], lv[20]};
+            }
             // (with a ball: the racket's link joins the touched links while the ball is in contact with a cylinder)
             const bool ballhit = BALL && valid && lb == BP.racket_link && (bl[BL_RK + RK_A] != 0.f || bl[BL_RK + 16 + RK_A] != 0.f);
             const bool ballground = BALL && ball_lane && bl[BL_GA] != 0.f;
@@ -716,7 +817,9 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                 for (unsigned t = mine; t; t &= t - 1) { const int dd = M.depth[__ffs(t) - 1]; kdep = dd > kdep ? dd : kdep; }
             }
             if (DIAG && a.prof && (blockIdx.x & 63) == 0 && lane == 0) { atomicAdd((unsigned long long*)&a.prof[9], (unsigned long long)(__popc(m0) + __popc(m1))); atomicAdd((unsigned long long*)&a.prof[10], 1ull); }
-            if (((m0 | m1) || (BALL && __any(ballground))) && P.n_iter > 0) {
+            const bool sweep_on = ((m0 | m1) || (BALL && any64(ballground))) && P.n_iter > 0;
+            if (PARK2 && !sweep_on) unpark_vel(w, xd);
+            if (sweep_on) {
                 // deepest touched link of either env: links below it are never read during the sweep, so Lambda and the
                 // per-update propagation stop there; their velocities catch up once at the end (the propagation is linear)
                 // (each env stops at ITS deepest touched link, so its arithmetic does not depend on which env shares the wave)
@@ -796,6 +899,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                     t1 = rsqrtf(dot(t1, t1)) * t1;
                     t2 = cross(n, t1);
                 };
+                if (PARK2) unpark_vel(w, xd);
                 if (BALL && ballhit) {
                     // row biases of the ball x racket points from the velocities before the sweep (restitution: Newton, against the approach speed)
                     const V3 bv{bl[BL_VEL], bl[BL_VEL + 1], bl[BL_VEL + 2]}, bw{bl[BL_ANG], bl[BL_ANG + 1], bl[BL_ANG + 2]};
@@ -814,8 +918,10 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                     }
                 }
                 LLPH(5);
-                park_put3(PARK_W0, w);  // the sweep's total delta-velocity of a link = its velocity at the end - these
-                park_put3(PARK_XD0, xd);
+                if (!PARK2) {
+                    park_put3(PARK_W0, w);  // the sweep's total delta-velocity of a link = its velocity at the end - these
+                    park_put3(PARK_XD0, xd);
+                }
                 // touched links whose parent is the touched link right before them (ascending): they continue a group (below)
                 unsigned chain0 = 0u, chain1 = 0u;
                 {
@@ -843,7 +949,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                     if (TGS && it > 0) {
                         // gaps advance with the normal velocity the points have after the previous sweep (touched links are current)
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) cbias[c] += hs * (cr[c].y * w.x - cr[c].x * w.y + xd.z);
+                        for (int c = 0; c < 4; ++c) { const V3 rc = CS.cr(c); CS.set_bias(c, CS.bias(c) + hs * (rc.y * w.x - rc.x * w.y + xd.z)); }
                         tgs_irem = 1.f / (h - (float)it * hs);
                     }
                     while (t0 | t1) {
@@ -876,15 +982,16 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
 #pragma unroll
                                 for (int c = 0; c < 4; ++c) {
                                     const bool active = c < cnt;
-                                    if (!__any(active)) break;  // uniform over the (at most two) touched links solved here
-                                    V3 rr = cr[c];
-                                    float ln = clam[c].x, l1 = clam[c].y, l2 = clam[c].z;
+                                    if (!any64(active)) break;  // uniform over the (at most two) touched links solved here
+                                    V3 rr = CS.cr(c);
+                                    const V3 lam0 = CS.lam(c);
+                                    float ln = lam0.x, l1 = lam0.y, l2 = lam0.z;
                                     // a point without normal impulse (hence without friction impulses: they are clamped to mu x normal)
                                     // that is separating stays as it is: its three rows would change nothing
                                     // (masked per lane as well, so that an env's numbers do not depend on what its wave partner does)
-                                    const float bias_c = rowbias(cbias[c]);
+                                    const float bias_c = rowbias(CS.bias(c));
                                     const bool act = active && !(ln == 0.f && rr.y * wl.x - rr.x * wl.y + xl.z + bias_c >= 0.f);
-                                    if (!__any(act)) continue;
+                                    if (!any64(act)) continue;
 #pragma unroll
                                     for (int ax = 0; ax < 3; ++ax) {
                                         V3 dir = ax == 0 ? V3{0.f, 0.f, 1.f} : (ax == 1 ? V3{1.f, 0.f, 0.f} : V3{0.f, 1.f, 0.f});
@@ -904,7 +1011,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                                         un = un + dl * jn;
                                         uf = uf + dl * dir;
                                     }
-                                    clam[c] = V3{ln, l1, l2};
+                                    CS.set_lam(c, V3{ln, l1, l2});
                                 }
                                 if (BALL && ballhit) {
                                     // ---- ball x racket points: two-body rows (ball point velocity minus racket point velocity); the ball side is
@@ -961,7 +1068,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                         const bool onpath = valid && blast >= 0 && ((desc >> blast) & 1);  // the group's deepest link or one of its ancestors
                         LLSUB(11);
                         // an update that changed no impulse (separated or saturated points) moves nothing: skip the propagation
-                        if (!__any(un.x != 0.f || un.y != 0.f || un.z != 0.f || uf.x != 0.f || uf.y != 0.f || uf.z != 0.f)) {
+                        if (!any64(un.x != 0.f || un.y != 0.f || un.z != 0.f || uf.x != 0.f || uf.y != 0.f || uf.z != 0.f)) {
                             if (DIAG && a.prof && (blockIdx.x & 63) == 0 && lane == 0) atomicAdd((unsigned long long*)&a.prof[19], 1ull);
                             continue;
                         }
@@ -969,7 +1076,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                         // ---- net impulse (un, uf) at the touched link: leaf -> root along the path, level by level
                         // (after its own level a path link's un is final: it is the joint-space impulse the way down needs)
                         for (int d = dneed; d >= 1; --d) {
-                            if (!__any(onpath && dep == d)) continue;  // nothing to hand up from this level
+                            if (!any64(onpath && dep == d)) continue;  // nothing to hand up from this level
                             V3 cn{0.f, 0.f, 0.f}, cf{0.f, 0.f, 0.f};
                             if (dep == d && onpath) {
                                 V3 na = aug * mul(Di, un);
@@ -984,7 +1091,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                                 un = un + from_next(cn);
                                 uf = uf + from_next(cf);
                             }
-                            if (((multi >> d) & 1) && __any(dep == d && onpath && !firstchild)) {  // path enters its parent through child 1 or 2
+                            if (((multi >> d) & 1) && any64(dep == d && onpath && !firstchild)) {  // path enters its parent through child 1 or 2
                                 un = un + mask(has1, pull(cn, cl1)) + mask(has2, pull(cn, cl2));
                                 uf = uf + mask(has1, pull(cf, cl1)) + mask(has2, pull(cf, cl2));
                             }
@@ -1038,7 +1145,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                             bl[BL_VEL] = bv.x; bl[BL_VEL + 1] = bv.y; bl[BL_VEL + 2] = bv.z;
                             bl[BL_ANG] = bw.x; bl[BL_ANG + 1] = bw.y; bl[BL_ANG + 2] = bw.z;
                         }
-                        if (__any(bmoved)) moved = true;
+                        if (any64(bmoved)) moved = true;
                     }
                     if (!TGS && !moved) break;  // a whole iteration without any change: the remaining ones would repeat it (PGS: fixed biases)
                 }
@@ -1147,7 +1254,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
                 const float ih = 1.f / h;
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
-                    if (c < cnt) { cforce.z += clam[c].x * ih; cforce.x += clam[c].y * ih; cforce.y += clam[c].z * ih; }
+                    if (c < cnt) { const V3 lc = CS.lam(c); cforce.z += lc.x * ih; cforce.x += lc.y * ih; cforce.y += lc.z * ih; }
                 if (BALL && lb == BP.racket_link) cforce = cforce - park_get3(PARK_W0);
             }
             float* oc = a.x_contact + (e * NB + b) * 3;
