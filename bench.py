@@ -73,11 +73,11 @@ def self_launch(gpus, argv, stub):
 
 
 # ---------------------------------------------------------------------------------------------- the workload
-def build_task(num_envs, device_id, seed, contact=True, per_clip_shapes=False, djokovic=False, freeze=False, solver="pgs", racket_ball=False):
+def build_task(num_envs, device_id, seed, contact=True, per_clip_shapes=False, djokovic=False, freeze=False, solver="pgs", racket_ball=False, substep_jobs=False):
     from vid2player3d_amd.tasks import HumanoidSMPLIM, HumanoidSMPLIMRacketBall, default_cfg
 
     cfg = default_cfg(num_envs, synthetic_motions={"seed": 7, "num_clips": 64, "min_frames": 90, "max_frames": 300},
-                      enable_contact=contact, contact_solver=solver)
+                      enable_contact=contact, contact_solver=solver, substep_jobs=substep_jobs)
     if freeze:  # NOT the reference's behaviour (it keeps simulating terminated envs as ragdolls): reported separately, never as `value` of the default run
         cfg["env"]["freeze_terminated_envs"] = True
     if djokovic:  # BASELINE config 4 = cfg/djokovic_im.yaml: same task class, head termination height -0.5, faster (tennis-like) clips
@@ -273,6 +273,7 @@ def main():
     ap.add_argument("--solver", choices=["pgs", "tgs"], default="pgs")
     ap.add_argument("--freeze-terminated", action="store_true", help="opt-in engine feature: terminated envs are not simulated until the epoch reset (not reference behaviour)")
     ap.add_argument("--djokovic", action="store_true", help="BASELINE config 4 (djokovic_im.yaml: terminationHeadHeight -0.5, faster clips)")
+    ap.add_argument("--substep-jobs", type=int, default=1, help="1: physics launch cut into (substep, env pair) jobs (v2p_sim_cfg.substep_jobs); same results, finer load balancing")
     ap.add_argument("--racket-ball", action="store_true", help="BASELINE config 4 as worded: racket welded to the wrist + free ball with drag / Magnus lift, ball-ground and ball-racket contacts (implies --djokovic)")
     ap.add_argument("--per-clip-shapes", action="store_true", help="one body shape per clip (64 scaled bodies) instead of one shape for all envs")
     ap.add_argument("--ppo", action="store_true", help="BASELINE config 5 loop: device-resident rollout (play_steps) + GAE + PPO update per epoch; prints the reference's fps step / fps total")
@@ -317,7 +318,7 @@ def main():
         if dist is not None:
             dist.barrier()
         task = build_task(n, local_rank, seed=7 + rank, contact=not args.no_contact, per_clip_shapes=args.per_clip_shapes, djokovic=args.djokovic or args.racket_ball,
-                          freeze=args.freeze_terminated, solver=args.solver, racket_ball=args.racket_ball)  # per-rank seed like run.py:37
+                          freeze=args.freeze_terminated, solver=args.solver, racket_ball=args.racket_ball, substep_jobs=bool(args.substep_jobs) and not args.racket_ball)  # per-rank seed like run.py:37
     if args.ppo:
         return run_ppo(args, task, dist, world, rank)
     dev = task.device
@@ -349,6 +350,8 @@ def main():
     barrier()
     elapsed_local = time.perf_counter() - t0
     phys_ms_total, launches = task.profile_end()
+    if hasattr(task, "check"):
+        task.check()  # device-side errors (a substep job that timed out) fail the run instead of producing a number
     phys_ms = phys_ms_total / max(launches, 1)
     alive = float((task.reset_buf == 0).float().mean().item())
     elapsed, per_rank = elapsed_local, [n * args.steps / elapsed_local]
@@ -385,7 +388,7 @@ def main():
                                       (", TERMINATED ENVS FROZEN (not reference behaviour)" if args.freeze_terminated else "") + (", STUB TASK (launch-logic test, not a measurement)" if stub else "")),
                        "num_envs_per_gpu": n, "global_envs": world * n, "parallelism": "env-sharded x%d, no data-path collective" % world,
                        "world_size_seen": world_seen, "backend": None if dist is None else ("gloo" if stub else "nccl(rccl)"),
-                       "per_rank_env_steps_per_s": per_rank, "alive_fraction_at_end": alive},
+                       "per_rank_env_steps_per_s": per_rank, "alive_fraction_at_end": alive, "substep_jobs": bool(args.substep_jobs)},
             "roofline": roof,
         }
         if not stub:

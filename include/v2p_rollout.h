@@ -34,7 +34,7 @@ extern "C" {
 #define V2P_NUM_OBS 461
 #define V2P_MOTION_STATE_DIM 331  /* root_pos3 root_rot4 dof_pos69 root_vel3 root_ang_vel3 dof_vel69 key_pos12 rb_pos72 rb_rot96 */
 #define V2P_CONTEXT_DIM 378       /* body_pos72 body_rot96 dof_pos69 body_pos_gt72 dof_pos_gt69 (humanoid_smpl_im.py:202) */
-#define V2P_ABI_VERSION 4
+#define V2P_ABI_VERSION 5
 
 typedef enum {
     V2P_OK = 0,
@@ -175,6 +175,9 @@ typedef struct {
     int32_t solver_type;        /* contact solver: 0 = projected Gauss-Seidel (default), 1 = temporal Gauss-Seidel with frozen Jacobians
                                  * (sim.physx.solver_type of amass_im.yaml:41 is 1 = TGS in PhysX; see oracle/phys/v2p_phys_oracle.c for
                                  * what either means here).  Link-per-lane schedule only. */
+    int32_t substep_jobs;       /* 1: the physics launch of the link-per-lane schedule is cut into (substep, env pair) jobs that hand the
+                                 * state over through memory - 4x finer load balancing of the launch; results are bit-identical to 0
+                                 * (one workgroup per env pair runs all substeps).  PGS, contacts on, no ball. */
     int32_t debug_contacts;     /* diagnostics, off (0) by default: 1 = keep the contact vertex ids of the last substep
                                  * (v2p_env_debug_contacts; 384 B of extra stores per env-step), 2 = of EVERY substep as well
                                  * (v2p_env_debug_contacts_substeps) */
@@ -290,6 +293,10 @@ int v2p_env_attach_ball(v2p_env* e, const v2p_ball_cfg* cfg, const v2p_ball_buff
  * the very steps it times. */
 int v2p_env_profile_begin(v2p_env* e, int64_t max_launches);
 int v2p_env_profile_end(v2p_env* e, double* physics_ms_total, int64_t* launches);
+
+/* synchronises the stream and reports errors detected on the device since the last check (a substep job that waited too long for
+ * its predecessor: V2P_ERR_HIP).  Cheap enough for once per epoch; not needed for correctness of normal runs. */
+int v2p_env_check(v2p_env* e, void* stream);
 
 const char* v2p_last_error(void);
 int v2p_abi_version(void);

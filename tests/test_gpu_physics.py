@@ -341,6 +341,35 @@ def test_env_pairing_is_invisible(mlib):
         assert np.array_equal(x, y), (k, float(np.abs(x.astype(np.float64) - y).max()), int((x != y).sum()), x.size)
 
 
+@pytest.mark.parametrize("n", [3, 257, 8192])
+def test_substep_jobs_are_invisible(mlib, n):
+    """v2p_sim_cfg.substep_jobs: the physics launch cut into (substep, env pair) jobs that hand the state over through memory
+    (system-scope stores / loads + a progress word per pair) must give bit-identical results to one workgroup per pair, step
+    after step, under load (8192 envs = 16384 jobs on ~2048 wave slots: most hand-offs cross workgroups, CUs and XCDs)."""
+    outs = []
+    for jobs in (False, True):
+        task = make_task(n, mlib, substep_jobs=jobs)
+        g = torch.Generator(device=DEV)
+        g.manual_seed(17)
+        task.reset_with_times(None, torch.rand(n, device=DEV, generator=g) * 0.8)
+        snaps = []
+        for k in range(12):
+            a = torch.cat([task._target_dof_pos + 0.4 * torch.randn((n, 69), device=DEV, generator=g), 0.3 * torch.randn((n, 6), device=DEV, generator=g)], dim=1).contiguous()
+            if k % 3 == 2:
+                task.pre_physics_step(a); task._physics_step(); task.post_physics_step()  # the staged API takes the same path
+            else:
+                task.step(a)
+            snaps.append([N(task._rigid_body_state).copy(), N(task._dof_state).copy(), N(task._contact_forces).copy(), N(task.dof_force_tensor).copy(),
+                          N(task.rew_buf).copy(), N(task.reset_buf).copy(), N(task.debug_contacts()).copy()])
+        task.check()
+        outs.append(snaps)
+        task.close()
+    assert (outs[0][-1][6] >= 0).any()
+    for k, (sa, sb) in enumerate(zip(*outs)):
+        for j, (x, y) in enumerate(zip(sa, sb)):
+            assert np.array_equal(x, y), "step %d, tensor %d: %d of %d values differ (max %.3e)" % (k, j, int((x != y).sum()), x.size, float(np.abs(x.astype(np.float64) - y).max()))
+
+
 @pytest.mark.parametrize("n", [2, 3, 1000, 8195])
 def test_pairing_order_is_a_descending_permutation(mlib, n):
     """The wave order for the next launch is a permutation of the envs with non-increasing contact-load keys (counting sort

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "libv2p_rollout.so")
 
 NUM_BODIES, NUM_DOF, NUM_ACTIONS, NUM_OBS = 24, 69, 75, 461
 MOTION_STATE_DIM, CONTEXT_DIM = 331, 378
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_f = C.POINTER(C.c_float)
 c_i32 = C.POINTER(C.c_int32)
@@ -40,7 +40,7 @@ class SimCfg(C.Structure):
                 ("max_episode_length", C.c_float), ("enable_early_termination", C.c_int32), ("context_length", C.c_int32),
                 ("context_padding", C.c_int32), ("term_heights", C.c_float * 24), ("body_pos_weights", C.c_float * 24),
                 ("reward_specs", C.c_float * 8), ("freeze_terminated_envs", C.c_int32), ("schedule", C.c_int32), ("pair_envs_by_load", C.c_int32),
-                ("solver_type", C.c_int32), ("debug_contacts", C.c_int32)]
+                ("solver_type", C.c_int32), ("substep_jobs", C.c_int32), ("debug_contacts", C.c_int32)]
 
 
 class EnvBuffers(C.Structure):
@@ -104,6 +104,7 @@ def load():
         "v2p_env_debug_contacts": [vp, vp, vp],
         "v2p_env_debug_contacts_substeps": [vp, vp, vp],
         "v2p_env_debug_pairing": [vp, vp, vp, vp],
+        "v2p_env_check": [vp, vp],
         "v2p_env_attach_ball": [vp, C.POINTER(BallCfg), C.POINTER(BallBuffers)],
         "v2p_env_profile_begin": [vp, C.c_int64],
         "v2p_env_profile_end": [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)],
@@ -123,7 +124,7 @@ def load():
 EXPORTED_SYMBOLS = (
     "v2p_model_create", "v2p_model_destroy", "v2p_mlib_create", "v2p_mlib_destroy", "v2p_motion_state", "v2p_reward", "v2p_reset_flags",
     "v2p_obs_imitation", "v2p_obs_imitation_packed", "v2p_gae", "v2p_env_create", "v2p_env_create_shapes", "v2p_env_destroy", "v2p_env_reset", "v2p_env_step", "v2p_env_pre_physics", "v2p_env_physics", "v2p_env_export",
-    "v2p_env_post_physics", "v2p_env_push_state", "v2p_env_target_index", "v2p_env_set_schedule", "v2p_env_debug_contacts", "v2p_env_debug_contacts_substeps", "v2p_env_debug_pairing", "v2p_env_attach_ball", "v2p_env_profile_begin", "v2p_env_profile_end", "v2p_last_error", "v2p_abi_version",
+    "v2p_env_post_physics", "v2p_env_push_state", "v2p_env_target_index", "v2p_env_set_schedule", "v2p_env_debug_contacts", "v2p_env_debug_contacts_substeps", "v2p_env_debug_pairing", "v2p_env_attach_ball", "v2p_env_check", "v2p_env_profile_begin", "v2p_env_profile_end", "v2p_last_error", "v2p_abi_version",
 )
 
 

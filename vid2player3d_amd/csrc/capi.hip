@@ -350,6 +350,12 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
         if (rc == V2P_OK) e->schedule = 0;  // the env-per-lane cross-check kernel is single-shape
     }
     e->pair_period = c->pair_envs_by_load ? 1 : 0;
+    e->substep_jobs = c->substep_jobs ? 1 : 0;
+    if (rc == V2P_OK && e->substep_jobs) {
+        const size_t words = (N + 1) / 2 + 2;
+        rc = check_hip(hipMalloc((void**)&e->job_progress, sizeof(int32_t) * words), "hipMalloc(job_progress)");
+        if (rc == V2P_OK) rc = check_hip(hipMemset(e->job_progress, 0, sizeof(int32_t) * words), "hipMemset(job_progress)");
+    }
     if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->pair_key, sizeof(int32_t) * N), "hipMalloc(pair_key)");
     if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->pair_pos, sizeof(int32_t) * N), "hipMalloc(pair_pos)");
     if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->perm, sizeof(int32_t) * N), "hipMalloc(perm)");
@@ -399,6 +405,7 @@ void v2p_env_destroy(v2p_env* e) {
     if (e->ws) (void)hipFree(e->ws);
     if (e->contact_ids) (void)hipFree(e->contact_ids);
     if (e->contact_ids_sub) (void)hipFree(e->contact_ids_sub);
+    if (e->job_progress) (void)hipFree(e->job_progress);
     profile_free(e);
     if (e->shapes_dev) (void)hipFree(e->shapes_dev);
     if (e->shape_aug_dev) (void)hipFree(e->shape_aug_dev);
@@ -480,6 +487,22 @@ int v2p_env_attach_ball(v2p_env* e, const v2p_ball_cfg* c, const v2p_ball_buffer
     memcpy(d.racket_off, c->racket_offset, sizeof(d.racket_off));
     d.state = b->ball_state; d.racket_state = b->racket_state; d.per_sim = b->ball_per_sim; d.hit_per_sim = b->racket_hit_per_sim; d.contact = b->ball_contact;
     return V2P_OK;
+}
+
+int v2p_env_check(v2p_env* e, void* stream) {
+    if (!e) { set_error("v2p_env_check: bad argument"); return V2P_ERR_INVALID; }
+    DeviceGuard g(e->device);
+    int rc = check_hip(hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize");
+    if (rc != V2P_OK || !e->job_progress) return rc;
+    int32_t flag = 0;
+    int32_t* word = e->job_progress + (e->n + 1) / 2;
+    rc = check_hip(hipMemcpy(&flag, word, sizeof(flag), hipMemcpyDeviceToHost), "hipMemcpy(job error word)");
+    if (rc == V2P_OK && flag) {
+        (void)hipMemset(word, 0, sizeof(flag));
+        set_error("v2p_env_check: a substep job timed out waiting for its predecessor (workgroups were not dispatched in index order?)");
+        return V2P_ERR_HIP;
+    }
+    return rc;
 }
 
 static void profile_free(v2p_env* e) {

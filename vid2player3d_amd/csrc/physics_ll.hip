@@ -64,6 +64,10 @@ constexpr int LPE = 32;  // lanes per environment
 // wave-wide "any lane": a compare of the ballot in scalar registers (HIP's __any materialises the predicate as a 0/1 VGPR first:
 // 2 VALU instructions per use, and the sweep loops use it ~20 times per block update)
 __device__ __forceinline__ bool any64(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+// hand-off of a job's results to another workgroup (possibly on another XCD: per-XCD L2s are not coherent, a CU's L1 is never refreshed):
+// system-scope relaxed atomics = `sc0 sc1` loads / stores on both sides (MI355X_MICROARCH.md, inter-workgroup visibility, valid forms)
+__device__ __forceinline__ float cload(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void cstore(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
 __device__ __forceinline__ float pull(float v, int src_lane) {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
@@ -173,21 +177,21 @@ __device__ __forceinline__ void grp_argmax(float& v, int& k) {
 #define V2P_LL_WPB 1   // waves per workgroup (they share the LDS hull copy)
 #endif
 #ifndef V2P_LL_WPS
-#define V2P_LL_WPS 2   // waves per SIMD the register budget is set for
+#define V2P_LL_WPS 3   // waves per SIMD the register budget is set for (168 VGPRs; 2 = 256 VGPRs with everything in registers)
 #endif
 constexpr int LL_WPB = V2P_LL_WPB;
 // V2P_LL_PARK2: phase-scoped parking of values that a phase does not touch (link velocities during pass 2 / contact generation / the
 // Lambda recursion, Lambda of the root during contact generation, the contact records during the Lambda recursion): lowers the
 // register peak of those phases so that nothing long-lived is spilled ACROSS the sweep loops when the kernel is built for 3 waves/SIMD.
 #ifndef V2P_LL_PARK2
-#define V2P_LL_PARK2 0
+#define V2P_LL_PARK2 1
 #endif
 constexpr bool PARK2 = V2P_LL_PARK2 != 0;
 // V2P_LL_PARK3: the contact records of a link (4 x offset, bias / gap, 3 impulses = 28 floats) live in the lane's LDS column instead of
 // registers: they are touched once per block update (by the one lane being solved), not inside the per-level loops, and leave their
 // 28 registers to the values those loops use.
 #ifndef V2P_LL_PARK3
-#define V2P_LL_PARK3 0
+#define V2P_LL_PARK3 1
 #endif
 constexpr bool PARK3 = V2P_LL_PARK3 != 0;
 constexpr int PARK_TAR = 0, PARK_W0 = 3, PARK_XD0 = 6, PARK_Q = 9, PARK_X = 13, PARK_CR = 16, PARK_CB = 28, PARK_CL = 32,
@@ -232,8 +236,13 @@ struct ContactStore<true> {
 // instantiation: in the production kernel they cost registers (spills) and ~2 scalar instructions per probe inside the sweep loops.
 // BALL: racket + ball: the first idle lane of an env (lb == 24) simulates the free ball, its state and the ball contact
 // records live in a 64-float LDS block per env; the ball-racket rows are solved inside the block update of the racket's link.
-template <bool CONTACT, bool MULTI, bool TGS, bool DIAG, bool BALL>
-__global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(PhysArgs a) {
+// JOBS: one launch = substeps x waves JOBS.  Job (s, p) runs substep s of wave p's env pair and hands the state over to job (s+1, p)
+// through global memory (system-scope stores / loads + a progress word per pair).  With whole control steps as jobs, 8192 envs are
+// 4096 indivisible jobs of 0.14-0.65 ms on 2048-3072 wave slots and the launch is as long as its worst slot (82 % utilisation,
+// profiles/r02*_wave_times.txt); quarter-size jobs pack 4x finer.  Jobs are dispatched in index order (substep-major, heavy pairs
+// first), so a job only ever waits for one that was dispatched before it.
+template <bool CONTACT, bool MULTI, bool TGS, bool DIAG, bool BALL, bool JOBS>
+__global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG) ? 2 : V2P_LL_WPS) void physics_ll_kernel(PhysArgs a) {
     const int64_t N = a.n;
     const int lane = threadIdx.x & 63;
     const int half = lane >> 5;
@@ -241,7 +250,10 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
     const bool valid = lb < NB;
     const int b = valid ? lb : 0;  // idle lanes shadow link 0 and never commit anything
     const int base = lane & LPE;
-    const int64_t slot = ((int64_t)blockIdx.x * LL_WPB + (threadIdx.x >> 6)) * 2 + half;
+    const int nblk = JOBS ? a.job_blocks : (int)gridDim.x;                 // workgroups per substep (JOBS) / of the launch
+    const int sjob = JOBS ? (int)(blockIdx.x / (unsigned)nblk) : 0;        // the substep this job runs
+    const int bid = JOBS ? (int)(blockIdx.x % (unsigned)nblk) : (int)blockIdx.x;
+    const int64_t slot = ((int64_t)bid * LL_WPB + (threadIdx.x >> 6)) * 2 + half;
     const bool live_env = slot < N;
     int64_t e = live_env ? slot : N - 1;
     if (a.perm) e = a.perm[e];
@@ -287,22 +299,55 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
     // skips the substeps altogether (frozen envs sort to the end of the launch order, so they share waves)
     const bool frozen = P.freeze_terminated && a.reset[e] == 1;
     const int nsub = (P.freeze_terminated && !any64(!frozen)) ? 0 : P.nsub;
+#if defined(V2P_LL_PRIO)
+    {   // issue priority by predicted load: the heaviest pairs are the critical path of the launch, light waves fill the gaps they leave
+        const int k0 = a.pair_key ? a.pair_key[e] : 0;
+        const int kmax = __builtin_amdgcn_readfirstlane(max(k0, __shfl_xor(k0, 32)));
+        if (kmax >= 96) __builtin_amdgcn_s_setprio(3);
+        else if (kmax >= 64) __builtin_amdgcn_s_setprio(2);
+        else if (kmax >= 40) __builtin_amdgcn_s_setprio(1);
+    }
+#endif
+    const int sub0 = JOBS ? sjob : 0, sub1 = JOBS ? (nsub ? sjob + 1 : 0) : nsub;  // substeps of this job
+    const bool first_job = !JOBS || sjob == 0, last_job = !JOBS || sjob == P.nsub - 1;
+    const bool handed = JOBS && sjob > 0;  // the inputs of this job were written by another workgroup of this launch
+    int* const progress = JOBS ? a.job_progress + (bid * LL_WPB + (threadIdx.x >> 6)) : nullptr;
+    if (handed) {
+        // wait for the previous substep of this env pair (dispatched before this job: it is running or done)
+        const int want = a.job_epoch * 8 + sjob;
+        if (lane == 0) {
+            int* const errword = a.job_progress + a.job_blocks * LL_WPB;
+            long spins = 0;
+            while (__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+                __builtin_amdgcn_s_sleep(16);
+                ++spins;
+                // ~0.25 s without progress, or another job has already given up: report (v2p_env_check) instead of hanging the GPU
+                if (spins > 500000l || ((spins & 1023) == 0 && __hip_atomic_load(errword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)) {
+                    __hip_atomic_store(errword, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    auto ldin = [&](const float* p) -> float { return handed ? cload(p) : *p; };
 
     // ---- state: the root lane carries the root pose/velocity, every other lane its joint
     Q4 q{0.f, 0.f, 0.f, 1.f}, jq{0.f, 0.f, 0.f, 1.f};
     V3 x{0.f, 0.f, 0.f}, w{0.f, 0.f, 0.f}, xd{0.f, 0.f, 0.f}, wt{0.f, 0.f, 0.f}, tar{0.f, 0.f, 0.f};
     if (b == 0) {
-        q = Q4{st[SIDX(ST_ROOT_QUAT + 0)], st[SIDX(ST_ROOT_QUAT + 1)], st[SIDX(ST_ROOT_QUAT + 2)], st[SIDX(ST_ROOT_QUAT + 3)]};
-        x = V3{st[SIDX(ST_ROOT_POS + 0)], st[SIDX(ST_ROOT_POS + 1)], st[SIDX(ST_ROOT_POS + 2)]};
-        xd = V3{st[SIDX(ST_VEL + 0)], st[SIDX(ST_VEL + 1)], st[SIDX(ST_VEL + 2)]};
-        w = V3{st[SIDX(ST_VEL + 3)], st[SIDX(ST_VEL + 4)], st[SIDX(ST_VEL + 5)]};
+        q = Q4{ldin(&st[SIDX(ST_ROOT_QUAT + 0)]), ldin(&st[SIDX(ST_ROOT_QUAT + 1)]), ldin(&st[SIDX(ST_ROOT_QUAT + 2)]), ldin(&st[SIDX(ST_ROOT_QUAT + 3)])};
+        x = V3{ldin(&st[SIDX(ST_ROOT_POS + 0)]), ldin(&st[SIDX(ST_ROOT_POS + 1)]), ldin(&st[SIDX(ST_ROOT_POS + 2)])};
+        xd = V3{ldin(&st[SIDX(ST_VEL + 0)]), ldin(&st[SIDX(ST_VEL + 1)]), ldin(&st[SIDX(ST_VEL + 2)])};
+        w = V3{ldin(&st[SIDX(ST_VEL + 3)]), ldin(&st[SIDX(ST_VEL + 4)]), ldin(&st[SIDX(ST_VEL + 5)])};
     } else {
         const int jb = ST_JQUAT + 4 * (b - 1), vb = ST_VEL + 6 + 3 * (b - 1), cb = CT_PD + 3 * (b - 1);
-        jq = Q4{st[SIDX(jb + 0)], st[SIDX(jb + 1)], st[SIDX(jb + 2)], st[SIDX(jb + 3)]};
-        wt = V3{st[SIDX(vb + 0)], st[SIDX(vb + 1)], st[SIDX(vb + 2)]};
-        if (!a.actions) tar = V3{a.ctrl[CIDX(cb + 0)], a.ctrl[CIDX(cb + 1)], a.ctrl[CIDX(cb + 2)]};
+        jq = Q4{ldin(&st[SIDX(jb + 0)]), ldin(&st[SIDX(jb + 1)]), ldin(&st[SIDX(jb + 2)]), ldin(&st[SIDX(jb + 3)])};
+        wt = V3{ldin(&st[SIDX(vb + 0)]), ldin(&st[SIDX(vb + 1)]), ldin(&st[SIDX(vb + 2)])};
+        if (!a.actions || handed) tar = V3{ldin(&a.ctrl[CIDX(cb + 0)]), ldin(&a.ctrl[CIDX(cb + 1)]), ldin(&a.ctrl[CIDX(cb + 2)])};
     }
-    if (a.actions && valid && live_env) {
+    auto stctl = [&](float* p, float v) { if (JOBS) cstore(p, v); else *p = v; };  // ctrl is read by the later jobs of the pair
+    if (a.actions && valid && live_env && first_job) {
         // ---- pre-physics fused in (same functions, same rounding as env_pre_kernel below): lane b owns the three action components of
         // its joint, the root lane the residual wrench; dead envs are masked in place on the caller's tensor
         const bool dead = a.reset[e] == 1;
@@ -316,7 +361,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
             float* pt = a.pd_target + e * NDOF + 3 * (b - 1);
             pt[0] = tar.x; pt[1] = tar.y; pt[2] = tar.z;
             const int cb = CT_PD + 3 * (b - 1);
-            a.ctrl[CIDX(cb + 0)] = tar.x; a.ctrl[CIDX(cb + 1)] = tar.y; a.ctrl[CIDX(cb + 2)] = tar.z;
+            stctl(&a.ctrl[CIDX(cb + 0)], tar.x); stctl(&a.ctrl[CIDX(cb + 1)], tar.y); stctl(&a.ctrl[CIDX(cb + 2)], tar.z);
         } else {
             float* ap = a.actions + e * NACT + NDOF;
             float af[6];
@@ -329,8 +374,8 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
             const float* rq4 = a.x_rb + e * NB * 13 + 3;
             const strict::V3 F = strict::residual_wrench(rq4, af[0], af[1], af[2], P.res_force_scale);
             const strict::V3 Tq = strict::residual_wrench(rq4, af[3], af[4], af[5], P.res_torque_scale);
-            a.ctrl[CIDX(CT_FORCE + 0)] = F.x; a.ctrl[CIDX(CT_FORCE + 1)] = F.y; a.ctrl[CIDX(CT_FORCE + 2)] = F.z;
-            a.ctrl[CIDX(CT_TORQUE + 0)] = Tq.x; a.ctrl[CIDX(CT_TORQUE + 1)] = Tq.y; a.ctrl[CIDX(CT_TORQUE + 2)] = Tq.z;
+            stctl(&a.ctrl[CIDX(CT_FORCE + 0)], F.x); stctl(&a.ctrl[CIDX(CT_FORCE + 1)], F.y); stctl(&a.ctrl[CIDX(CT_FORCE + 2)], F.z);
+            stctl(&a.ctrl[CIDX(CT_TORQUE + 0)], Tq.x); stctl(&a.ctrl[CIDX(CT_TORQUE + 1)], Tq.y); stctl(&a.ctrl[CIDX(CT_TORQUE + 2)], Tq.z);
         }
     }
 
@@ -350,7 +395,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
     V3 r{0.f, 0.f, 0.f};
     int ksum = 0, kdep = 0;  // contact load of this env over the launch (pairing key)
 
-    for (int sub = 0; sub < nsub; ++sub) {
+    for (int sub = sub0; sub < sub1; ++sub) {
         const bool wrench_on = sub < P.hold_sub;
         const bool last = sub == nsub - 1;
         LLPH(0);
@@ -408,8 +453,8 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
             pf = mass * (wwd - V3{0.f, 0.f, P.gravity_z});
             pn = cross(w, mul(Ic, w)) + cross(dc, pf);
             if (b == 0 && wrench_on) {
-                const V3 extF{a.ctrl[CIDX(CT_FORCE + 0)], a.ctrl[CIDX(CT_FORCE + 1)], a.ctrl[CIDX(CT_FORCE + 2)]};
-                const V3 extT{a.ctrl[CIDX(CT_TORQUE + 0)], a.ctrl[CIDX(CT_TORQUE + 1)], a.ctrl[CIDX(CT_TORQUE + 2)]};
+                const V3 extF{ldin(&a.ctrl[CIDX(CT_FORCE + 0)]), ldin(&a.ctrl[CIDX(CT_FORCE + 1)]), ldin(&a.ctrl[CIDX(CT_FORCE + 2)])};
+                const V3 extT{ldin(&a.ctrl[CIDX(CT_TORQUE + 0)]), ldin(&a.ctrl[CIDX(CT_TORQUE + 1)]), ldin(&a.ctrl[CIDX(CT_TORQUE + 2)])};
                 pn = pn - extT - cross(dc, extF);  // force acts at the root COM
                 pf = pf - extF;
             }
@@ -1276,8 +1321,9 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
         }
     }
     // ==================================================================== final kinematics -> state, rigid-body state, dof_pos
+    // (JOBS: only the job of the last substep produces the exposed tensors and the pairing keys; the others hand the state over)
     const V3 lpos{S->local_pos[b][0], S->local_pos[b][1], S->local_pos[b][2]};
-    for (int d = 1; d <= maxd; ++d) {
+    for (int d = 1; d <= (last_job ? maxd : 0); ++d) {
         const bool nc = (nonchain >> d) & 1;
         Q4 pq = pp(q, nc);
         V3 px = pp(x, nc), pw = pp(w, nc), pxd = pp(xd, nc);
@@ -1294,7 +1340,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
         wt[0] = wt0; wt[1] = wall_clock64(); wt[2] = ksum * 8 + kdep + 1024 * (long long)tsum + 1048576ll * tmaxs + 1073741824ll * key_pred;
         unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); wt[3] = hw;
     }
-    if (a.pair_hist) {
+    if (a.pair_hist && last_job) {
         // ---- pairing key of this env (touched links, then the deepest of them: what the sweep's cost follows) into its load bin;
         // the workgroup that finishes last turns the histogram into bin offsets for the scatter that builds the next launch's order
         // links about to touch (bounding box within the contact offset of the ground after one more control step at the current
@@ -1319,7 +1365,7 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
         int ticket = -1;
         if (lane == 0) ticket = atomicAdd(a.pair_done, 1);
         ticket = __builtin_amdgcn_readfirstlane(ticket);
-        if (ticket == (int)(gridDim.x * LL_WPB) - 1) {
+        if (ticket == nblk * LL_WPB - 1) {
             int c[4], mine = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) { c[k] = __hip_atomic_load(&a.pair_hist[4 * lane + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); mine += c[k]; }
@@ -1337,6 +1383,24 @@ __global__ __launch_bounds__(64 * LL_WPB, V2P_LL_WPS) void physics_ll_kernel(Phy
     asm volatile("" : "+v"(e_out));
     {
     const int64_t e = e_out;
+    if (JOBS && !last_job) {
+        // ---- hand the state over to the job of the next substep: system-scope stores, drained, then the progress word of the pair
+        if (valid && live_env) {
+            if (b == 0) {
+                cstore(&st[SIDX(ST_ROOT_QUAT + 0)], q.x); cstore(&st[SIDX(ST_ROOT_QUAT + 1)], q.y); cstore(&st[SIDX(ST_ROOT_QUAT + 2)], q.z); cstore(&st[SIDX(ST_ROOT_QUAT + 3)], q.w);
+                cstore(&st[SIDX(ST_ROOT_POS + 0)], x.x); cstore(&st[SIDX(ST_ROOT_POS + 1)], x.y); cstore(&st[SIDX(ST_ROOT_POS + 2)], x.z);
+                cstore(&st[SIDX(ST_VEL + 0)], xd.x); cstore(&st[SIDX(ST_VEL + 1)], xd.y); cstore(&st[SIDX(ST_VEL + 2)], xd.z);
+                cstore(&st[SIDX(ST_VEL + 3)], w.x); cstore(&st[SIDX(ST_VEL + 4)], w.y); cstore(&st[SIDX(ST_VEL + 5)], w.z);
+            } else {
+                const int jb = ST_JQUAT + 4 * (b - 1), vb = ST_VEL + 6 + 3 * (b - 1);
+                cstore(&st[SIDX(jb + 0)], jq.x); cstore(&st[SIDX(jb + 1)], jq.y); cstore(&st[SIDX(jb + 2)], jq.z); cstore(&st[SIDX(jb + 3)], jq.w);
+                cstore(&st[SIDX(vb + 0)], wt.x); cstore(&st[SIDX(vb + 1)], wt.y); cstore(&st[SIDX(vb + 2)], wt.z);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (inline asm: the compiler must not drop or move this drain)
+        if (lane == 0) __hip_atomic_store(progress, a.job_epoch * 8 + sjob + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
     if (valid && live_env) {
         if (b == 0) {
             st[SIDX(ST_ROOT_QUAT + 0)] = q.x; st[SIDX(ST_ROOT_QUAT + 1)] = q.y; st[SIDX(ST_ROOT_QUAT + 2)] = q.z; st[SIDX(ST_ROOT_QUAT + 3)] = q.w;
@@ -1510,22 +1574,36 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s, float* actions) {
     const bool diag = a.prof || a.wave_times;
     if (env->ball) a.ball = *env->ball;
     if (env->ball && env->p.enable_contact && !tgs) {  // racket + ball: its own instantiation (PGS, with contacts)
-        if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, false, false, true>), grid, block, lds, s, a);
-        else hipLaunchKernelGGL((physics_ll_kernel<true, false, false, false, true>), grid, block, lds, s, a);
+        if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, false, false, true, false>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((physics_ll_kernel<true, false, false, false, true, false>), grid, block, lds, s, a);
     } else if (env->ball) {
         set_error("physics: racket + ball runs with contacts on and the PGS solver");
         return V2P_ERR_UNSUPPORTED;
     } else if (diag && env->p.enable_contact && !tgs && !multi) {  // the instrumented build exists for the headline configuration only
-        hipLaunchKernelGGL((physics_ll_kernel<true, false, false, true, false>), grid, block, lds, s, a);
+        hipLaunchKernelGGL((physics_ll_kernel<true, false, false, true, false, false>), grid, block, lds, s, a);
     } else if (env->p.enable_contact && tgs) {
-        if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, true, false, false>), grid, block, lds, s, a);
-        else hipLaunchKernelGGL((physics_ll_kernel<true, false, true, false, false>), grid, block, lds, s, a);
+        if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, true, false, false, false>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((physics_ll_kernel<true, false, true, false, false, false>), grid, block, lds, s, a);
+    } else if (env->p.enable_contact && env->substep_jobs && env->job_progress && blocks > 1) {
+        // substep jobs: one launch of nsub x blocks workgroups, substep-major
+        a.job_blocks = (int)blocks;
+        a.job_progress = env->job_progress;
+        a.job_epoch = ++env->job_epoch;
+        if (env->job_epoch > (1 << 26)) env->job_epoch = 0;  // (wraps before the progress words overflow; a wrap needs them cleared)
+        if (env->job_epoch == 0) {
+            int rc0 = check_hip(hipMemsetAsync(env->job_progress, 0, sizeof(int) * (blocks * LL_WPB + 1), s), "hipMemsetAsync(job_progress)");
+            if (rc0 != V2P_OK) return rc0;
+            a.job_epoch = env->job_epoch = 1;
+        }
+        const dim3 jgrid(blocks * (unsigned)env->p.nsub);
+        if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, false, false, false, true>), jgrid, block, lds, s, a);
+        else hipLaunchKernelGGL((physics_ll_kernel<true, false, false, false, false, true>), jgrid, block, lds, s, a);
     } else if (env->p.enable_contact) {
-        if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, false, false, false>), grid, block, lds, s, a);
-        else hipLaunchKernelGGL((physics_ll_kernel<true, false, false, false, false>), grid, block, lds, s, a);
+        if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, false, false, false, false>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((physics_ll_kernel<true, false, false, false, false, false>), grid, block, lds, s, a);
     } else {
-        if (multi) hipLaunchKernelGGL((physics_ll_kernel<false, true, false, false, false>), grid, block, lds, s, a);
-        else hipLaunchKernelGGL((physics_ll_kernel<false, false, false, false, false>), grid, block, lds, s, a);
+        if (multi) hipLaunchKernelGGL((physics_ll_kernel<false, true, false, false, false, false>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((physics_ll_kernel<false, false, false, false, false, false>), grid, block, lds, s, a);
     }
     env->pair_have = paired ? 1 : 0;
     return check_hip(hipGetLastError(), "physics_ll_kernel");

@@ -135,6 +135,9 @@ struct v2p_env {
     int32_t* perm;            // [N] wave slot -> env for the next physics launch
     int pair_period;          // 0 = pairing off (v2p_sim_cfg.pair_envs_by_load = 0), else on
     int substeps_per_sim;     // substeps of one simulate() call
+    int substep_jobs;         // v2p_sim_cfg.substep_jobs: the physics launch is cut into (substep, env pair) jobs
+    int32_t* job_progress;    // [waves + 1] progress word per wave slot, last = error flag
+    int job_epoch;
     v2p::BallDev* ball;       // racket + ball attached (v2p_env_attach_ball), else NULL
     hipEvent_t* prof_ev;      // 2 events per measured physics launch (v2p_env_profile_begin), else NULL
     int64_t prof_cap, prof_n;

@@ -32,6 +32,7 @@ class HumanoidSMPLIMRacketBall(HumanoidSMPLIM):
             raise NotImplementedError("racket + ball with per-clip body shapes is not built")
         model, self.racket_geometry = racket.with_racket(base)
         env["body_model"] = model
+        env["substep_jobs"] = False  # the ball's state lives in LDS across the substeps of a step: one workgroup per env pair
         self.cfg_v2p = dict(cfg.get("v2p") or {})
         super().__init__(cfg, sim_params, physics_engine, device_type, device_id, headless)
         n, dev = self.num_envs, self.device
@@ -83,24 +84,23 @@ class HumanoidSMPLIMRacketBall(HumanoidSMPLIM):
         self._has_racket_ball_contact[ids] = False
 
     def _ball_flags_before(self):
-        self._ball_start = self._ball_root_states.clone()
-        self._has_bounce_now[:] = False
-        self._has_racket_ball_contact_now[:] = False
+        self._ball_start = self._ball_root_states[:, 0:3].clone()
 
     def _ball_flags_after(self):
         """apply_external_force_to_ball's bounce test on the ball position at the START of each simulate() call (:731-737) and the
-        contact-force poll after it (:773-779)."""
+        contact-force poll after it (:773-779), for all calls of the step at once (a handful of elementwise kernels)."""
         thresh = BALL_R * (6 if self.sim_params.substeps > 2 else 4)
-        starts = [self._ball_start] + [self._ball_states_per_sim[:, k] for k in range(self.control_freq_inv - 1)]
-        for k, st in enumerate(starts):
-            now = ~self._has_bounce & (st[:, 2] <= thresh)
-            self._has_bounce_now |= now
-            self._has_bounce |= now
-            self._bounce_pos[now] = st[now, 0:3]
-            if self.sim_params.substeps <= 2:
-                hit = ~self._has_racket_ball_contact & (self._racket_ball_contact_per_sim[:, k] != 0)
-                self._has_racket_ball_contact_now |= hit
-                self._has_racket_ball_contact |= hit
+        starts = torch.cat([self._ball_start.unsqueeze(1), self._ball_states_per_sim[:, :-1, 0:3]], dim=1)  # [N, nsim, 3]
+        low = starts[..., 2] <= thresh
+        first = low & (torch.cumsum(low.int(), dim=1) == 1)            # the first call of this step that sees the ball low
+        now = first.any(dim=1) & ~self._has_bounce
+        self._has_bounce_now = now
+        self._bounce_pos = torch.where(now.unsqueeze(-1), (starts * first.unsqueeze(-1)).sum(dim=1), self._bounce_pos)
+        self._has_bounce = self._has_bounce | now
+        if self.sim_params.substeps <= 2:
+            hit = (self._racket_ball_contact_per_sim != 0).any(dim=1) & ~self._has_racket_ball_contact
+            self._has_racket_ball_contact_now = hit
+            self._has_racket_ball_contact = self._has_racket_ball_contact | hit
 
     def step(self, actions):
         self._ball_flags_before()

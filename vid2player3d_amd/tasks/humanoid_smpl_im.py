@@ -360,6 +360,8 @@ class HumanoidSMPLIM:
         # contact solver of the engine's own physics model: "pgs" (default) or "tgs" (sim.physx.solver_type 1 of amass_im.yaml:41 names
         # PhysX's TGS; the engine's TGS restates the published algorithm with frozen Jacobians, see oracle/phys/v2p_phys_oracle.c)
         c.solver_type = {"pgs": 0, "tgs": 1}[env.get("contact_solver", "pgs")]
+        # physics launch cut into (substep, env pair) jobs: finer load balancing, bit-identical results (tests); on by default
+        c.substep_jobs = int(env.get("substep_jobs", True)) if c.solver_type == 0 and c.enable_contact and c.schedule == 0 else 0
         c.debug_contacts = int(env.get("debug_contacts", 0))  # 0 off, 1 last substep's contact vertices kept, 2 every substep's
         hold = env.get("residual_force_hold", "first_sim")
         c.residual_hold_sims = 1 if hold == "first_sim" else self.control_freq_inv
@@ -565,6 +567,10 @@ class HumanoidSMPLIM:
         out = torch.empty((self.num_envs, nsub, self.num_bodies, 4), dtype=torch.int32, device=self.device)
         _lib.check(self._lib.v2p_env_debug_contacts_substeps(self._h_env, _lib.ptr(out), self._stream()), "v2p_env_debug_contacts_substeps")
         return out
+
+    def check(self):
+        """Synchronise and raise if the device reported an error since the last check (v2p_env_check)."""
+        _lib.check(self._lib.v2p_env_check(self._h_env, self._stream()), "v2p_env_check")
 
     def profile_begin(self, max_launches):
         """HIP events around every physics-kernel launch from now on (engine side, on the launch stream)."""
