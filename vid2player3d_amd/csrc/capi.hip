@@ -351,6 +351,10 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
     }
     e->pair_period = c->pair_envs_by_load ? 1 : 0;
     e->substep_jobs = c->substep_jobs ? 1 : 0;
+    // the heaviest quarter of the env pairs keeps all substeps in one workgroup (measured best of 0 .. 75 %: profiles/r02_job_mono_sweep.txt);
+    // V2P_JOB_MONO=<permille> overrides it for such sweeps
+    e->job_mono_permille = getenv("V2P_JOB_MONO") ? atoi(getenv("V2P_JOB_MONO")) : 250;
+    if (e->job_mono_permille < 0 || e->job_mono_permille > 1000) e->job_mono_permille = 250;
     if (rc == V2P_OK && e->substep_jobs) {
         const size_t words = (N + 1) / 2 + 2;
         rc = check_hip(hipMalloc((void**)&e->job_progress, sizeof(int32_t) * words), "hipMalloc(job_progress)");

@@ -65,7 +65,7 @@ struct PhysArgs {
     EnvParams p;
     BallDev ball;
     // substep jobs (physics_ll.hip JOBS): workgroups per substep, progress word per wave slot (+1 error word), epoch of this launch
-    int32_t job_blocks, job_epoch;
+    int32_t job_blocks, job_epoch, job_mono;
     int32_t* job_progress;
 };
 

@@ -250,9 +250,14 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG) ? 2 : V2P_LL_WPS) void 
     const bool valid = lb < NB;
     const int b = valid ? lb : 0;  // idle lanes shadow link 0 and never commit anything
     const int base = lane & LPE;
-    const int nblk = JOBS ? a.job_blocks : (int)gridDim.x;                 // workgroups per substep (JOBS) / of the launch
-    const int sjob = JOBS ? (int)(blockIdx.x / (unsigned)nblk) : 0;        // the substep this job runs
-    const int bid = JOBS ? (int)(blockIdx.x % (unsigned)nblk) : (int)blockIdx.x;
+    // JOBS: the first job_mono workgroups run ALL substeps of the job_mono heaviest env pairs (their chain of substeps is the critical
+    // path of the launch: it starts at once and never waits); the other pairs are cut into one job per substep, substep-major
+    const int nblk = JOBS ? a.job_blocks : (int)gridDim.x;                 // env pairs (wave slots) of the launch
+    const bool mono = !JOBS || (int)blockIdx.x < a.job_mono;
+    const int jcut = JOBS ? nblk - a.job_mono : 1;                          // pairs that are cut into substep jobs
+    const int jrel = JOBS ? (int)blockIdx.x - a.job_mono : 0;
+    const int sjob = mono ? 0 : jrel / jcut;                               // the substep this job runs
+    const int bid = mono ? (int)blockIdx.x : a.job_mono + jrel % jcut;
     const int64_t slot = ((int64_t)bid * LL_WPB + (threadIdx.x >> 6)) * 2 + half;
     const bool live_env = slot < N;
     int64_t e = live_env ? slot : N - 1;
@@ -308,9 +313,9 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG) ? 2 : V2P_LL_WPS) void 
         else if (kmax >= 40) __builtin_amdgcn_s_setprio(1);
     }
 #endif
-    const int sub0 = JOBS ? sjob : 0, sub1 = JOBS ? (nsub ? sjob + 1 : 0) : nsub;  // substeps of this job
-    const bool first_job = !JOBS || sjob == 0, last_job = !JOBS || sjob == P.nsub - 1;
-    const bool handed = JOBS && sjob > 0;  // the inputs of this job were written by another workgroup of this launch
+    const int sub0 = mono ? 0 : sjob, sub1 = mono ? nsub : (nsub ? sjob + 1 : 0);  // substeps of this job
+    const bool first_job = mono || sjob == 0, last_job = mono || sjob == P.nsub - 1;
+    const bool handed = !mono && sjob > 0;  // the inputs of this job were written by another workgroup of this launch
     int* const progress = JOBS ? a.job_progress + (bid * LL_WPB + (threadIdx.x >> 6)) : nullptr;
     if (handed) {
         // wait for the previous substep of this env pair (dispatched before this job: it is running or done)
@@ -346,7 +351,7 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG) ? 2 : V2P_LL_WPS) void 
         wt = V3{ldin(&st[SIDX(vb + 0)]), ldin(&st[SIDX(vb + 1)]), ldin(&st[SIDX(vb + 2)])};
         if (!a.actions || handed) tar = V3{ldin(&a.ctrl[CIDX(cb + 0)]), ldin(&a.ctrl[CIDX(cb + 1)]), ldin(&a.ctrl[CIDX(cb + 2)])};
     }
-    auto stctl = [&](float* p, float v) { if (JOBS) cstore(p, v); else *p = v; };  // ctrl is read by the later jobs of the pair
+    auto stctl = [&](float* p, float v) { if (!mono) cstore(p, v); else *p = v; };  // ctrl is read by the later jobs of the pair
     if (a.actions && valid && live_env && first_job) {
         // ---- pre-physics fused in (same functions, same rounding as env_pre_kernel below): lane b owns the three action components of
         // its joint, the root lane the residual wrench; dead envs are masked in place on the caller's tensor
@@ -1595,7 +1600,8 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s, float* actions) {
             if (rc0 != V2P_OK) return rc0;
             a.job_epoch = env->job_epoch = 1;
         }
-        const dim3 jgrid(blocks * (unsigned)env->p.nsub);
+        a.job_mono = (int)(blocks * (unsigned)env->job_mono_permille / 1000u);
+        const dim3 jgrid((unsigned)a.job_mono + (blocks - (unsigned)a.job_mono) * (unsigned)env->p.nsub);
         if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, false, false, false, true>), jgrid, block, lds, s, a);
         else hipLaunchKernelGGL((physics_ll_kernel<true, false, false, false, false, true>), jgrid, block, lds, s, a);
     } else if (env->p.enable_contact) {
