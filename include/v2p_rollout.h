@@ -34,7 +34,7 @@ extern "C" {
 #define V2P_NUM_OBS 461
 #define V2P_MOTION_STATE_DIM 331  /* root_pos3 root_rot4 dof_pos69 root_vel3 root_ang_vel3 dof_vel69 key_pos12 rb_pos72 rb_rot96 */
 #define V2P_CONTEXT_DIM 378       /* body_pos72 body_rot96 dof_pos69 body_pos_gt72 dof_pos_gt69 (humanoid_smpl_im.py:202) */
-#define V2P_ABI_VERSION 5
+#define V2P_ABI_VERSION 6
 
 typedef enum {
     V2P_OK = 0,
@@ -178,6 +178,10 @@ typedef struct {
     int32_t substep_jobs;       /* 1: the physics launch of the link-per-lane schedule is cut into (substep, env pair) jobs that hand the
                                  * state over through memory - 4x finer load balancing of the launch; results are bit-identical to 0
                                  * (one workgroup per env pair runs all substeps).  PGS, contacts on, no ball. */
+    int32_t job_mono_permille;  /* substep_jobs: share of the env pairs (the heaviest) whose substeps stay in one workgroup; -1 = default (250) */
+    int32_t pair_mix_permille;  /* pair_envs_by_load: share of the envs (the heaviest) that share their wave with one of the lightest envs
+                                 * instead of with an equally heavy one (a wave costs the union of its two envs' contact structure, and the
+                                 * heaviest envs are the critical path of the launch); 0 = pairs of equals only; -1 = default (250) */
     int32_t debug_contacts;     /* diagnostics, off (0) by default: 1 = keep the contact vertex ids of the last substep
                                  * (v2p_env_debug_contacts; 384 B of extra stores per env-step), 2 = of EVERY substep as well
                                  * (v2p_env_debug_contacts_substeps) */

@@ -322,7 +322,7 @@ def test_env_pairing_is_invisible(mlib):
     n = 257
     outs = []
     for pair in (False, True):
-        task = make_task(n, mlib, pair_envs_by_load=pair)
+        task = make_task(n, mlib, pair_envs_by_load=pair, pair_mix_permille=300)
         g = torch.Generator(device=DEV)
         g.manual_seed(11)
         task.reset_with_times(None, torch.rand(n, device=DEV, generator=g) * 0.8)
@@ -370,11 +370,16 @@ def test_substep_jobs_are_invisible(mlib, n):
             assert np.array_equal(x, y), "step %d, tensor %d: %d of %d values differ (max %.3e)" % (k, j, int((x != y).sum()), x.size, float(np.abs(x.astype(np.float64) - y).max()))
 
 
-@pytest.mark.parametrize("n", [2, 3, 1000, 8195])
-def test_pairing_order_is_a_descending_permutation(mlib, n):
-    """The wave order for the next launch is a permutation of the envs with non-increasing contact-load keys (counting sort
-    spread over the physics and pre-physics kernels); also when pre-physics is not called between physics launches."""
-    task = make_task(n, mlib)
+@pytest.mark.parametrize("n,mix", [(2, 0), (3, 250), (1000, 0), (1000, 250), (8195, 250), (8195, 500)])
+def test_pairing_order_is_a_descending_permutation(mlib, n, mix):
+    """The wave order for the next launch is a permutation of the envs; read by RANK it has non-increasing contact-load keys (counting
+    sort spread over the physics and pre-physics kernels), and rank r sits in slot 2r (r < m), 2 (n-1-r) + 1 (r >= n - m), r + m
+    (otherwise), m = n x pair_mix_permille / 1000: the m heaviest envs share their waves with the m lightest, the rest pair by rank.
+    Also when pre-physics is not called between physics launches."""
+    task = make_task(n, mlib, pair_mix_permille=mix)
+    m = min(n * mix // 1000, n // 2)
+    slots = np.arange(n)
+    rank_of_slot = np.where(slots < 2 * m, np.where(slots % 2 == 0, slots // 2, n - 1 - (slots - 1) // 2), slots - m)
     g = torch.Generator(device=DEV)
     g.manual_seed(3)
     task.reset_with_times(None, torch.rand(n, device=DEV, generator=g) * 0.8)
@@ -386,8 +391,10 @@ def test_pairing_order_is_a_descending_permutation(mlib, n):
         if n <= 2:  # a single wave: no pairing
             return
         pm, kp = N(perm).astype(np.int64), N(key).astype(np.int64)
-        assert np.array_equal(np.sort(pm), np.arange(n))
-        assert np.all(np.diff(kp[pm]) <= 0)
+        assert np.array_equal(np.sort(pm), np.arange(n)) and np.array_equal(np.sort(rank_of_slot), np.arange(n))
+        by_rank = np.empty(n, np.int64)
+        by_rank[rank_of_slot] = kp[pm]
+        assert np.all(np.diff(by_rank) <= 0)
         assert n < 1000 or len(np.unique(kp)) > 3
 
     for _ in range(3):

@@ -351,10 +351,9 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
     }
     e->pair_period = c->pair_envs_by_load ? 1 : 0;
     e->substep_jobs = c->substep_jobs ? 1 : 0;
-    // the heaviest quarter of the env pairs keeps all substeps in one workgroup (measured best of 0 .. 75 %: profiles/r02_job_mono_sweep.txt);
-    // V2P_JOB_MONO=<permille> overrides it for such sweeps
-    e->job_mono_permille = getenv("V2P_JOB_MONO") ? atoi(getenv("V2P_JOB_MONO")) : 250;
-    if (e->job_mono_permille < 0 || e->job_mono_permille > 1000) e->job_mono_permille = 250;
+    e->pair_mix_permille = c->pair_mix_permille < 0 ? 250 : c->pair_mix_permille;
+    e->job_mono_permille = c->job_mono_permille < 0 ? 250 : c->job_mono_permille;  // defaults: measured best (profiles/r02_job_mono_sweep.txt)
+    if (e->pair_mix_permille > 500 || e->job_mono_permille > 1000) { set_error("v2p_env_create: pair_mix_permille <= 500, job_mono_permille <= 1000"); v2p_env_destroy(e); return V2P_ERR_INVALID; }
     if (rc == V2P_OK && e->substep_jobs) {
         const size_t words = (N + 1) / 2 + 2;
         rc = check_hip(hipMalloc((void**)&e->job_progress, sizeof(int32_t) * words), "hipMalloc(job_progress)");

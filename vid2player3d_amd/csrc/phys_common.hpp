@@ -77,7 +77,22 @@ struct PairView {
     const int32_t* pos;    // [N]
     const int32_t* start;  // [PAIR_BINS]
     int32_t* perm;         // [N], NULL = nothing to scatter
+    int32_t n, mix;        // envs; the `mix` heaviest envs are paired with the `mix` lightest ones instead of with each other
 };
-__device__ __forceinline__ void pair_scatter(const PairView& pv, int64_t e) { pv.perm[pv.start[PAIR_BINS - 1 - pv.key[e]] + pv.pos[e]] = (int32_t)e; }
+// slot of env e in the next launch.  r = rank of e by contact load, descending (first slot of its load bin + its arrival index).
+// Envs are paired by rank, (0,1), (2,3), ...: a wave costs the UNION of its two envs' group structure, pairing equals keeps that
+// union small.  Except for the `mix` heaviest: their chain of block updates is the critical path of the whole launch, and next to an
+// equally heavy but differently shaped partner it grows by the partner's irregularities - each of them shares its wave with one of
+// the `mix` lightest envs instead (rank r < mix: slot 2r; rank r >= n - mix: slot 2 (n-1-r) + 1; the rest follows in rank order).
+__device__ __forceinline__ void pair_scatter(const PairView& pv, int64_t e) {
+    const int r = pv.start[PAIR_BINS - 1 - pv.key[e]] + pv.pos[e];
+    int slot = r;
+    if (pv.mix > 0) {
+        if (r < pv.mix) slot = 2 * r;
+        else if (r >= pv.n - pv.mix) slot = 2 * (pv.n - 1 - r) + 1;
+        else slot = r + pv.mix;
+    }
+    pv.perm[slot] = (int32_t)e;
+}
 
 }  // namespace v2p

@@ -1511,7 +1511,7 @@ int launch_env_pre(v2p_env* env, float* actions, hipStream_t s) {
     a.x_rb = env->buf.rb_state;
     a.n = env->n;
     a.p = env->p;
-    PairView pv{nullptr, nullptr, nullptr, nullptr};
+    PairView pv{nullptr, nullptr, nullptr, nullptr, 0, 0};
     if (env_pairing_on(env) && env->pair_have) {  // the wave order of the next physics launch, from the keys the last one left
         pv = env_pair_view(env);
         env->pair_have = 0;
@@ -1523,7 +1523,11 @@ int launch_env_pre(v2p_env* env, float* actions, hipStream_t s) {
 
 bool env_pairing_on(const v2p_env* env) { return env->pair_period > 0 && env->schedule == 0 && env->p.enable_contact && env->n > 2; }
 
-PairView env_pair_view(const v2p_env* env) { return PairView{env->pair_key, env->pair_pos, env->pair_start, env->perm}; }
+PairView env_pair_view(const v2p_env* env) {
+    int mix = (int)(env->n * (int64_t)env->pair_mix_permille / 1000);
+    if (2 * mix > env->n) mix = (int)(env->n / 2);
+    return PairView{env->pair_key, env->pair_pos, env->pair_start, env->perm, (int32_t)env->n, mix};
+}
 
 int launch_env_pairing(v2p_env* env, hipStream_t s) {
     hipLaunchKernelGGL(pair_scatter_kernel, dim3((unsigned)((env->n + 255) / 256)), dim3(256), 0, s, env_pair_view(env), env->n);

@@ -253,7 +253,7 @@ static EnvView make_view(const v2p_env* e) {
     v.out = e->out;
     v.n = e->n;
     v.cur = e->cur_target;
-    v.pair = PairView{nullptr, nullptr, nullptr, nullptr};
+    v.pair = PairView{nullptr, nullptr, nullptr, nullptr, 0, 0};
     return v;
 }
 

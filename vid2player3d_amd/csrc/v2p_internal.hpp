@@ -138,6 +138,7 @@ struct v2p_env {
     int substep_jobs;         // v2p_sim_cfg.substep_jobs: the physics launch is cut into (substep, env pair) jobs
     int32_t* job_progress;    // [waves + 1] progress word per wave slot, last = error flag
     int job_epoch;
+    int pair_mix_permille;    // share of the envs (the heaviest) that are paired with the lightest ones instead of with each other
     int job_mono_permille;    // share of the env pairs (the heaviest) whose substeps stay in one workgroup
     v2p::BallDev* ball;       // racket + ball attached (v2p_env_attach_ball), else NULL
     hipEvent_t* prof_ev;      // 2 events per measured physics launch (v2p_env_profile_begin), else NULL

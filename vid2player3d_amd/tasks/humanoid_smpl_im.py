@@ -362,6 +362,8 @@ class HumanoidSMPLIM:
         c.solver_type = {"pgs": 0, "tgs": 1}[env.get("contact_solver", "pgs")]
         # physics launch cut into (substep, env pair) jobs: finer load balancing, bit-identical results (tests); on by default
         c.substep_jobs = int(env.get("substep_jobs", True)) if c.solver_type == 0 and c.enable_contact and c.schedule == 0 else 0
+        c.job_mono_permille = int(env.get("job_mono_permille", -1))  # -1: the engine's defaults
+        c.pair_mix_permille = int(env.get("pair_mix_permille", -1))
         c.debug_contacts = int(env.get("debug_contacts", 0))  # 0 off, 1 last substep's contact vertices kept, 2 every substep's
         hold = env.get("residual_force_hold", "first_sim")
         c.residual_hold_sims = 1 if hold == "first_sim" else self.control_freq_inv
