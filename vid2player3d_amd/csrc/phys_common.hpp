@@ -49,6 +49,7 @@ struct PhysArgs {
     const int64_t* reset;
     float* pd_target;
     long long* prof;  // optional cycle counters per phase (block 0), NULL = off
+    int prof_heavy;   // sample the first 8 workgroups (the heaviest env pairs) instead of every 64th
     long long* wave_times;  // optional [waves][4]: wall-clock start, end (100 MHz), slot key, hw id of every wave of the launch
     const DevShape* shapes;    // [num_shapes] per-env body shapes (multi-shape batches only)
     const int32_t* env_shape;  // [N] shape of each env

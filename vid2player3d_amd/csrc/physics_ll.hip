@@ -170,8 +170,8 @@ __device__ __forceinline__ void grp_argmax(float& v, int& k) {
     grp_arg_step<true>(v, k, grp_xor1); grp_arg_step<true>(v, k, grp_xor2); grp_arg_step<true>(v, k, grp_mirror);
 }
 
-#define LLSUB(k) do { if (DIAG && a.prof) { long long t_ = clock64(); if ((blockIdx.x & 63) == 0 && lane == 0) atomicAdd((unsigned long long*)&a.prof[k], (unsigned long long)(t_ - tsub)); tsub = t_; } } while (0)
-#define LLPH(k) do { if (DIAG && a.prof) { long long t_ = clock64(); if ((blockIdx.x & 63) == 0 && lane == 0) atomicAdd((unsigned long long*)&a.prof[k], (unsigned long long)(t_ - tprev)); tprev = t_; } } while (0)
+#define LLSUB(k) do { if (DIAG && a.prof) { long long t_ = clock64(); if (((a.prof_heavy ? blockIdx.x < 8u : (blockIdx.x & 63) == 0)) && lane == 0) atomicAdd((unsigned long long*)&a.prof[k], (unsigned long long)(t_ - tsub)); tsub = t_; } } while (0)
+#define LLPH(k) do { if (DIAG && a.prof) { long long t_ = clock64(); if (((a.prof_heavy ? blockIdx.x < 8u : (blockIdx.x & 63) == 0)) && lane == 0) atomicAdd((unsigned long long*)&a.prof[k], (unsigned long long)(t_ - tprev)); tprev = t_; } } while (0)
 
 #ifndef V2P_LL_WPB
 #define V2P_LL_WPB 1   // waves per workgroup (they share the LDS hull copy)
@@ -705,7 +705,7 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG) ? 2 : V2P_LL_WPS) void 
                 const int myidx = __popc(nm & ((1u << lb) - 1u));  // rank of this link among the near links of its env
                 const int grp = lb >> 3, gl = lb & 7;
                 unsigned remn = nm;
-                if (DIAG && a.prof && (blockIdx.x & 63) == 0 && lane == 0) atomicAdd((unsigned long long*)&a.prof[13], (unsigned long long)rounds);
+                if (DIAG && a.prof && ((a.prof_heavy ? blockIdx.x < 8u : (blockIdx.x & 63) == 0)) && lane == 0) atomicAdd((unsigned long long*)&a.prof[13], (unsigned long long)rounds);
                 for (int rd = 0; rd < rounds; ++rd) {
                     unsigned cb = remn;
                     if (grp >= 1) cb &= cb - 1;
@@ -763,7 +763,7 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG) ? 2 : V2P_LL_WPS) void 
                     int ns = cntg < 4 ? cntg : 4;
                     const bool big = gon && cntg > 4;
                     if (any64(big)) {
-                        if (DIAG && a.prof && (blockIdx.x & 63) == 0 && lane == 0) atomicAdd((unsigned long long*)&a.prof[15], 1ull);
+                        if (DIAG && a.prof && ((a.prof_heavy ? blockIdx.x < 8u : (blockIdx.x & 63) == 0)) && lane == 0) atomicAdd((unsigned long long*)&a.prof[15], 1ull);
                         // manifold reduction: deepest, farthest from it, extreme on either side of that line
                         const int k0s = k0 < 0 ? 0 : k0;
                         const float4 u0 = hullv(v0L + k0s);
@@ -866,7 +866,7 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG) ? 2 : V2P_LL_WPS) void 
                 kdep = 0;
                 for (unsigned t = mine; t; t &= t - 1) { const int dd = M.depth[__ffs(t) - 1]; kdep = dd > kdep ? dd : kdep; }
             }
-            if (DIAG && a.prof && (blockIdx.x & 63) == 0 && lane == 0) { atomicAdd((unsigned long long*)&a.prof[9], (unsigned long long)(__popc(m0) + __popc(m1))); atomicAdd((unsigned long long*)&a.prof[10], 1ull); }
+            if (DIAG && a.prof && ((a.prof_heavy ? blockIdx.x < 8u : (blockIdx.x & 63) == 0)) && lane == 0) { atomicAdd((unsigned long long*)&a.prof[9], (unsigned long long)(__popc(m0) + __popc(m1))); atomicAdd((unsigned long long*)&a.prof[10], 1ull); }
             const bool sweep_on = ((m0 | m1) || (BALL && any64(ballground))) && P.n_iter > 0;
             if (PARK2 && !sweep_on) unpark_vel(w, xd);
             if (sweep_on) {
@@ -1013,7 +1013,7 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG) ? 2 : V2P_LL_WPS) void 
                         t1 &= t1 - 1;
                         int last0 = b0, last1 = b1;
                         long long tsub = DIAG && a.prof ? clock64() : 0;
-                        if (DIAG && a.prof && (blockIdx.x & 63) == 0 && lane == 0) atomicAdd((unsigned long long*)&a.prof[8], 1ull);
+                        if (DIAG && a.prof && ((a.prof_heavy ? blockIdx.x < 8u : (blockIdx.x & 63) == 0)) && lane == 0) atomicAdd((unsigned long long*)&a.prof[8], 1ull);
                         V3 un{0.f, 0.f, 0.f}, uf{0.f, 0.f, 0.f};
                         V3 Dw{0.f, 0.f, 0.f}, Dv{0.f, 0.f, 0.f};  // velocity change of the link just solved due to the group's impulses so far
                         for (int step = 0;; ++step) {
@@ -1119,7 +1119,7 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG) ? 2 : V2P_LL_WPS) void 
                         LLSUB(11);
                         // an update that changed no impulse (separated or saturated points) moves nothing: skip the propagation
                         if (!any64(un.x != 0.f || un.y != 0.f || un.z != 0.f || uf.x != 0.f || uf.y != 0.f || uf.z != 0.f)) {
-                            if (DIAG && a.prof && (blockIdx.x & 63) == 0 && lane == 0) atomicAdd((unsigned long long*)&a.prof[19], 1ull);
+                            if (DIAG && a.prof && ((a.prof_heavy ? blockIdx.x < 8u : (blockIdx.x & 63) == 0)) && lane == 0) atomicAdd((unsigned long long*)&a.prof[19], 1ull);
                             continue;
                         }
                         moved = true;
@@ -1569,6 +1569,7 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s, float* actions) {
     a.x_contact = env->buf.contact_force;
     a.x_dof_force = env->buf.dof_force;
     a.prof = env->prof;
+    a.prof_heavy = getenv("V2P_PHASE_HEAVY") ? 1 : 0;  // diagnostics: sample the 8 heaviest waves instead of every 64th
     a.wave_times = env->wave_times;
     a.n = env->n;
     a.p = env->p;
