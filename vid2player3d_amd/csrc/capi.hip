@@ -351,7 +351,9 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
     }
     e->pair_period = c->pair_envs_by_load ? 1 : 0;
     e->substep_jobs = c->substep_jobs ? 1 : 0;
-    e->pair_mix_permille = c->pair_mix_permille < 0 ? 250 : c->pair_mix_permille;
+    // (mixing trades total work for a shorter critical path: it pays while the launch is as long as its heaviest pair, i.e. up to
+    // ~4 env pairs per wave slot; beyond that the launch is throughput bound and pairs of equals are cheaper)
+    e->pair_mix_permille = c->pair_mix_permille < 0 ? (n <= 12288 ? 250 : 0) : c->pair_mix_permille;
     e->job_mono_permille = c->job_mono_permille < 0 ? 250 : c->job_mono_permille;  // defaults: measured best (profiles/r02_job_mono_sweep.txt)
     if (e->pair_mix_permille > 500 || e->job_mono_permille > 1000) { set_error("v2p_env_create: pair_mix_permille <= 500, job_mono_permille <= 1000"); v2p_env_destroy(e); return V2P_ERR_INVALID; }
     if (rc == V2P_OK && e->substep_jobs) {
