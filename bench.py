@@ -73,11 +73,13 @@ def self_launch(gpus, argv, stub):
 
 
 # ---------------------------------------------------------------------------------------------- the workload
-def build_task(num_envs, device_id, seed, contact=True, per_clip_shapes=False, djokovic=False, freeze=False, solver="pgs", racket_ball=False, substep_jobs=False):
+def build_task(num_envs, device_id, seed, contact=True, per_clip_shapes=False, djokovic=False, freeze=False, solver="pgs", racket_ball=False, substep_jobs=False, joint_limits=None):
     from vid2player3d_amd.tasks import HumanoidSMPLIM, HumanoidSMPLIMRacketBall, default_cfg
 
     cfg = default_cfg(num_envs, synthetic_motions={"seed": 7, "num_clips": 64, "min_frames": 90, "max_frames": 300},
                       enable_contact=contact, contact_solver=solver, substep_jobs=substep_jobs)
+    if joint_limits is not None:
+        cfg["env"]["joint_limits"] = bool(joint_limits)
     if freeze:  # NOT the reference's behaviour (it keeps simulating terminated envs as ragdolls): reported separately, never as `value` of the default run
         cfg["env"]["freeze_terminated_envs"] = True
     if djokovic:  # BASELINE config 4 = cfg/djokovic_im.yaml: same task class, head termination height -0.5, faster (tennis-like) clips
@@ -274,6 +276,8 @@ def main():
     ap.add_argument("--freeze-terminated", action="store_true", help="opt-in engine feature: terminated envs are not simulated until the epoch reset (not reference behaviour)")
     ap.add_argument("--djokovic", action="store_true", help="BASELINE config 4 (djokovic_im.yaml: terminationHeadHeight -0.5, faster clips)")
     ap.add_argument("--substep-jobs", type=int, default=1, help="1: physics launch cut into (substep, env pair) jobs (v2p_sim_cfg.substep_jobs); same results, finer load balancing")
+    ap.add_argument("--joint-limits", type=int, default=None, choices=(0, 1),
+                    help="enforce the MJCF joint ranges as limit rows (only the racket arm of --racket-ball has any; default: on with --racket-ball, else off)")
     ap.add_argument("--racket-ball", action="store_true", help="BASELINE config 4 as worded: racket welded to the wrist + free ball with drag / Magnus lift, ball-ground and ball-racket contacts (implies --djokovic)")
     ap.add_argument("--per-clip-shapes", action="store_true", help="one body shape per clip (64 scaled bodies) instead of one shape for all envs")
     ap.add_argument("--ppo", action="store_true", help="BASELINE config 5 loop: device-resident rollout (play_steps) + GAE + PPO update per epoch; prints the reference's fps step / fps total")
@@ -318,7 +322,8 @@ def main():
         if dist is not None:
             dist.barrier()
         task = build_task(n, local_rank, seed=7 + rank, contact=not args.no_contact, per_clip_shapes=args.per_clip_shapes, djokovic=args.djokovic or args.racket_ball,
-                          freeze=args.freeze_terminated, solver=args.solver, racket_ball=args.racket_ball, substep_jobs=bool(args.substep_jobs) and not args.racket_ball)  # per-rank seed like run.py:37
+                          freeze=args.freeze_terminated, solver=args.solver, racket_ball=args.racket_ball, substep_jobs=bool(args.substep_jobs) and not args.racket_ball,
+                          joint_limits=args.joint_limits)  # per-rank seed like run.py:37
     if args.ppo:
         return run_ppo(args, task, dist, world, rank)
     dev = task.device
@@ -384,7 +389,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "amass_im num_envs=%d per GPU, %s, imitation reward, per-epoch reset+context every %d steps, 64 synthetic clips, action noise %.3g%s"
                                    % (n, "PD control only (no contact solve)" if args.no_contact else "full contact %s (4 substeps x 4 iterations)" % args.solver.upper(), HORIZON,
-                                      args.action_noise, (", one NON-UNIFORM body shape per clip (64 shapes from vertex clouds)" if args.per_clip_shapes else "") + (", djokovic_im variant" if args.djokovic or args.racket_ball else "") + (", RACKET + BALL in every env (reported separately)" if args.racket_ball else "") +
+                                      args.action_noise, (", one NON-UNIFORM body shape per clip (64 shapes from vertex clouds)" if args.per_clip_shapes else "") + (", djokovic_im variant" if args.djokovic or args.racket_ball else "") + (", RACKET + BALL in every env (reported separately)" if args.racket_ball else "") + (", joint limits on" if (args.joint_limits if args.joint_limits is not None else args.racket_ball) else "") +
                                       (", TERMINATED ENVS FROZEN (not reference behaviour)" if args.freeze_terminated else "") + (", STUB TASK (launch-logic test, not a measurement)" if stub else "")),
                        "num_envs_per_gpu": n, "global_envs": world * n, "parallelism": "env-sharded x%d, no data-path collective" % world,
                        "world_size_seen": world_seen, "backend": None if dist is None else ("gloo" if stub else "nccl(rccl)"),

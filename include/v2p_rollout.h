@@ -34,7 +34,7 @@ extern "C" {
 #define V2P_NUM_OBS 461
 #define V2P_MOTION_STATE_DIM 331  /* root_pos3 root_rot4 dof_pos69 root_vel3 root_ang_vel3 dof_vel69 key_pos12 rb_pos72 rb_rot96 */
 #define V2P_CONTEXT_DIM 378       /* body_pos72 body_rot96 dof_pos69 body_pos_gt72 dof_pos_gt69 (humanoid_smpl_im.py:202) */
-#define V2P_ABI_VERSION 6
+#define V2P_ABI_VERSION 7
 
 typedef enum {
     V2P_OK = 0,
@@ -64,6 +64,9 @@ typedef struct {
     const float* armature;       /* [D] */
     const int32_t* hull_offsets; /* [B+1] */
     const float* hull_verts;     /* [V,3] body frame */
+    /* ---- ABI 7 */
+    const float* limit_lower;    /* [D] nullable: per-DOF range of the exponential-map coordinate, radians (the MJCF `range` that */
+    const float* limit_upper;    /* [D] nullable   gym.get_actor_dof_properties reports, humanoid_smpl.py:318-337); NULL = unlimited */
 } v2p_model_desc;
 
 int v2p_model_create(const v2p_model_desc* desc, int device, v2p_model** out);
@@ -185,6 +188,10 @@ typedef struct {
     int32_t debug_contacts;     /* diagnostics, off (0) by default: 1 = keep the contact vertex ids of the last substep
                                  * (v2p_env_debug_contacts; 384 B of extra stores per env-step), 2 = of EVERY substep as well
                                  * (v2p_env_debug_contacts_substeps) */
+    /* ---- ABI 7 */
+    int32_t joint_limits;       /* 1: every DOF whose range (v2p_model_desc.limit_lower/upper) is narrower than a full turn carries a
+                                 * limit row in the contact solver (the racket arm of the player MJCFs; the amass MJCF has none).
+                                 * Link-per-lane schedule, PGS, contacts on.  0 (default): ranges are ignored. */
 } v2p_sim_cfg;
 
 /* Caller-owned DEVICE buffers the engine reads/writes; these are the tensors the reference

@@ -56,6 +56,7 @@ typedef struct {
     double kp[3 * NJ], kd[3 * NJ], armature[3 * NJ];
     int hull_offsets[NB + 1];
     const double *hull_verts; /* [V][3] body frame */
+    double limit_lo[3 * NJ], limit_hi[3 * NJ]; /* per-DOF range of the exponential-map coordinate, radians (MJCF `range`) */
 } v2p_omodel;
 
 typedef struct {
@@ -70,6 +71,7 @@ typedef struct {
     int n_iter;            /* 4 */
     int enable_contact;
     int solver_type;       /* 0 = PGS (default), 1 = TGS (see the substep) */
+    int joint_limits;      /* 1: DOFs whose range is narrower than a full turn get a limit row (see the substep) */
 } v2p_oparams;
 
 /* ---- racket + ball (vid2player/env/tasks/humanoid_smpl_im_mvae.py:367-442, 711-783; data/assets/tennis_ball.urdf,
@@ -469,7 +471,7 @@ static void tangent_basis(const double n[3], double t1[3], double t2[3]) {
 
 #define NDT (ND + 6) /* generalized velocity with the ball appended: [articulation ND | ball linear 3 | ball angular 3] */
 typedef struct {
-    int kind;     /* 0 hull vertex x ground, 1 ball x racket cylinder, 2 ball x ground */
+    int kind;     /* 0 hull vertex x ground, 1 ball x racket cylinder, 2 ball x ground, 3 joint limit (one row: DOF `vert` of joint `body`) */
     int body, vert;
     double pos[3]; /* contact point, world */
     double n[3], t1[3], t2[3];
@@ -522,14 +524,33 @@ static int substep_impl(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s
     if (contact_force) memset(contact_force, 0, sizeof(double) * NB * 3);
     if (ball_contact) memset(ball_contact, 0, sizeof(double) * 6);
     if (contact_ids) for (int i = 0; i < NB * 4; ++i) contact_ids[i] = -1;
-    if (p->enable_contact) {
+    if (p->enable_contact || p->joint_limits) {
         contacts_t cs;
-        gen_contacts(m, p, &k, &cs, io);
+        cs.n = 0;
+        if (p->enable_contact) gen_contacts(m, p, &k, &cs, io);
         /* row list in Gauss-Seidel order: bodies ascending with their hull points in slot order; the ball-racket points right after the
          * hull points of the racket's link; the ball-ground point last */
-        crow_t rows[NB * MAXC_BODY + 3];
+        /* joint limits (Isaac Gym enforces the MJCF `range` of every DOF; the three hinges of a body are one spherical joint whose DOF
+         * positions are the exponential-map components, utils/motion_lib.py:460-488): a DOF whose range is narrower than a full turn
+         * carries ONE row against the nearer of its two limits, C = min(q - lo, hi - q), on the joint rate of that DOF (body axes; equal
+         * to the rate of the exp-map component to first order), sign +1 (lower) / -1 (upper); bias like a contact's normal row
+         * (C/h separated - only an approach that would cross the limit within the substep is stopped -, erp C/h violated); impulse
+         * >= 0.  Order: the limit rows of joint b right before the hull points of body b. */
+        crow_t rows[NB * MAXC_BODY + 3 + 3 * NJ];
         int nc = 0, ci = 0;
         for (int b = 0; b < NB; ++b) {
+            if (p->joint_limits && b >= 1)
+                for (int i = 0; i < 3; ++i) {
+                    const int j = 3 * (b - 1) + i;
+                    const double lo = m->limit_lo[j], hi = m->limit_hi[j];
+                    if (hi - lo >= 6.28) continue;
+                    const double clo = q[j] - lo, chi = hi - q[j];
+                    crow_t *r = &rows[nc++];
+                    memset(r, 0, sizeof(*r));
+                    r->kind = 3; r->body = b; r->vert = i;
+                    r->n[0] = clo <= chi ? 1.0 : -1.0;
+                    r->gap = clo <= chi ? clo : chi;
+                }
             for (; ci < cs.n && cs.body[ci] == b; ++ci) {
                 crow_t *r = &rows[nc++];
                 r->kind = 0; r->body = b; r->vert = cs.vert[ci];
@@ -574,7 +595,7 @@ static int substep_impl(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s
         double *wii = Tr + (size_t)(nrow > 0 ? nrow : 1) * NDT;
         double *lam = wii + (nrow > 0 ? nrow : 1);
         double *bias = lam + (nrow > 0 ? nrow : 1);
-        double gap[NB * MAXC_BODY + 3];
+        double gap[NB * MAXC_BODY + 3 + 3 * NJ];
         int slot_in_body[NB];
         memset(slot_in_body, 0, sizeof(slot_in_body));
         for (int c = 0; c < nc; ++c) {
@@ -584,10 +605,14 @@ static int substep_impl(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s
                 if (contact_ids) contact_ids[r->body * 4 + slot_in_body[r->body]] = r->body * 64 + r->vert;
                 slot_in_body[r->body]++;
             }
-            if (r->body >= 0) body_jacobian(m, &k, r->body, J);
+            if (r->body >= 0 && r->kind != 3) body_jacobian(m, &k, r->body, J);
             for (int a = 0; a < 3; ++a) {
                 int row = 3 * c + a;
                 double *jr = &Jr[row * NDT], *tr = &Tr[row * NDT];
+                if (r->kind == 3) { /* rows 1, 2 of a limit stay empty (skipped by the sweep) */
+                    if (a > 0) { wii[row] = 1.0; continue; }
+                    jr[6 + 3 * (r->body - 1) + r->vert] = r->n[0];
+                } else
                 /* velocity of the contact point of body B relative to body A along dir, A = ground (kind 0, 2) or the racket's link (kind 1) */
                 if (r->kind == 0) { /* B = the link */
                     double rl[3] = {r->pos[0] - k.x[r->body][0], r->pos[1] - k.x[r->body][1], r->pos[2] - k.x[r->body][2]}, rxn[3];
@@ -622,7 +647,7 @@ static int substep_impl(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s
             double d = r->gap;
             gap[c] = d;
             bias[3 * c] = d >= 0 ? d / h : fmax(p->erp * d / h, -p->max_depen_vel);
-            if (r->kind != 0) { /* restitution (Newton): an approach faster than the bounce threshold that closes the gap within this substep
+            if (r->kind == 1 || r->kind == 2) { /* restitution (Newton): an approach faster than the bounce threshold that closes the gap within this substep
                                  * leaves with rest x the approach speed */
                 double vn0 = 0;
                 for (int col = 0; col < NDT; ++col) vn0 += Jr[3 * c * NDT + col] * v[col];
@@ -650,7 +675,7 @@ static int substep_impl(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s
                 }
             }
             for (int c = 0; c < nc; ++c)
-                for (int a = 0; a < 3; ++a) {
+                for (int a = 0; a < (rows[c].kind == 3 ? 1 : 3); ++a) {
                     int row = 3 * c + a;
                     double rel = bias[row];
                     for (int col = 0; col < NDT; ++col) rel += Jr[row * NDT + col] * v[col];
@@ -665,6 +690,7 @@ static int substep_impl(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s
         for (int c = 0; c < nc; ++c) {
             const crow_t *r = &rows[c];
             double f[3];
+            if (r->kind == 3) continue;
             for (int i = 0; i < 3; ++i) f[i] = (lam[3 * c] * r->n[i] + lam[3 * c + 1] * r->t1[i] + lam[3 * c + 2] * r->t2[i]) / h;
             if (r->kind == 0 && contact_force) for (int i = 0; i < 3; ++i) contact_force[3 * r->body + i] += f[i];
             if (r->kind == 1) { /* on the ball +f, on the racket's link -f */

@@ -19,12 +19,14 @@ class OModel(C.Structure):
         ("parents", C.c_int * NB), ("local_pos", C.c_double * (NB * 3)), ("mass", C.c_double * NB), ("com", C.c_double * (NB * 3)),
         ("inertia", C.c_double * (NB * 9)), ("kp", C.c_double * (3 * NJ)), ("kd", C.c_double * (3 * NJ)), ("armature", C.c_double * (3 * NJ)),
         ("hull_offsets", C.c_int * (NB + 1)), ("hull_verts", C.POINTER(C.c_double)),
+        ("limit_lo", C.c_double * (3 * NJ)), ("limit_hi", C.c_double * (3 * NJ)),
     ]
 
 
 class OParams(C.Structure):
     _fields_ = [("h", C.c_double), ("gravity_z", C.c_double), ("mu", C.c_double), ("contact_offset", C.c_double), ("max_depen_vel", C.c_double),
-                ("ang_damp", C.c_double), ("max_ang_vel", C.c_double), ("erp", C.c_double), ("n_iter", C.c_int), ("enable_contact", C.c_int), ("solver_type", C.c_int)]
+                ("ang_damp", C.c_double), ("max_ang_vel", C.c_double), ("erp", C.c_double), ("n_iter", C.c_int), ("enable_contact", C.c_int), ("solver_type", C.c_int),
+                ("joint_limits", C.c_int)]
 
 
 class OCyl(C.Structure):
@@ -64,7 +66,7 @@ def lib():
 def default_params(h=1.0 / 120.0, enable_contact=True, **kw):
     """amass_im.yaml:37-52 + humanoid_smpl_im.py:273-276."""
     p = OParams(h=h, gravity_z=-9.81, mu=1.0, contact_offset=0.02, max_depen_vel=10.0, ang_damp=0.01, max_ang_vel=100.0, erp=0.2, n_iter=4,
-                enable_contact=int(enable_contact), solver_type=0)
+                enable_contact=int(enable_contact), solver_type=0, joint_limits=0)
     for k, v in kw.items():
         setattr(p, k, v)
     return p
@@ -90,6 +92,8 @@ def _omodel(body_model, kp=None, kd=None, armature=None):
     m.kd[:] = np.asarray(body_model.kd if kd is None else kd, dtype=np.float64).tolist()
     m.armature[:] = np.asarray(body_model.armature if armature is None else armature, dtype=np.float64).tolist()
     m.hull_offsets[:] = [int(x) for x in body_model.hull_offsets]
+    m.limit_lo[:] = np.asarray(body_model.limit_lower, dtype=np.float64).tolist()
+    m.limit_hi[:] = np.asarray(body_model.limit_upper, dtype=np.float64).tolist()
     hv = np.ascontiguousarray(body_model.hull_verts, dtype=np.float64)
     m.hull_verts = _dptr(hv)
     return m, hv

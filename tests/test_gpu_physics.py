@@ -65,14 +65,16 @@ def _perturbed_task(mlib, n, contact, rng, lift, vel_sigma, hold, shapes, **env)
     return task, root, dpos, dvel
 
 
-def _run_pair(mlib, n, contact, seed, lift=0.0, vel_sigma=0.5, steps=1, hold="first_sim", shapes=None, subset=None, solver="pgs", what="", **env):
+def _run_pair(mlib, n, contact, seed, lift=0.0, vel_sigma=0.5, steps=1, hold="first_sim", shapes=None, subset=None, solver="pgs", what="", limits=False,
+              act_sigma=0.17, **env):
     """subset: env indices that get an oracle (all by default); the returned arrays are restricted to them.  Returns one
     (got, ref) per control step; ref carries the oracle's own selection ("own") and its margins next to the forced one."""
     rng = np.random.default_rng(seed)
-    task, root, dpos, dvel = _perturbed_task(mlib, n, contact, rng, lift, vel_sigma, hold, shapes, contact_solver=solver, **env)
+    task, root, dpos, dvel = _perturbed_task(mlib, n, contact, rng, lift, vel_sigma, hold, shapes, contact_solver=solver, joint_limits=limits, **env)
     ids_o = np.arange(n) if subset is None else np.asarray([int(i) for i in subset])
     par = default_params(enable_contact=contact)
     par.solver_type = {"pgs": 0, "tgs": 1}[solver]
+    par.joint_limits = int(limits)
     if shapes is None:
         oracle = BatchOracle(task.body_model, len(ids_o), par)
     else:  # the oracle of env e simulates the body shape of its clip
@@ -80,7 +82,7 @@ def _run_pair(mlib, n, contact, seed, lift=0.0, vel_sigma=0.5, steps=1, hold="fi
     oracle.set_state(root[ids_o], dpos[ids_o], dvel[ids_o])
     out = []
     for s in range(steps):
-        act = np.concatenate([N(task._target_dof_pos) + rng.normal(0, 0.17, size=(n, 69)), rng.normal(0, 0.17, size=(n, 6))], axis=1).astype(np.float32)
+        act = np.concatenate([N(task._target_dof_pos) + rng.normal(0, act_sigma, size=(n, 69)), rng.normal(0, 0.17, size=(n, 6))], axis=1).astype(np.float32)
         rb0 = N(task._rigid_body_state).reshape(n, 24, 13).copy()
         dpos_before = N(task._dof_pos).copy()
         a = T(act)
@@ -165,6 +167,25 @@ def test_tgs_option_matches_oracle(mlib):
     _compare(got, ref, "tgs")
     (got_p, _), = _run_pair(mlib, 48, contact=True, seed=2, lift=-0.1, solver="pgs", what="pgs twin")
     assert np.abs(got["rb"][..., 7:] - got_p["rb"][..., 7:]).max() > 1e-3
+
+
+def test_joint_limits_match_oracle(mlib):
+    """v2p_sim_cfg.joint_limits with the player MJCF's racket-arm ranges (R_Wrist +-10 / +-45 / +-90 deg, R_Elbow_x <= 90 deg): the
+    reference poses put the wrist beyond +-10 deg in most envs, so the rows work against violated limits (erp) and against approached
+    ones (speculative); standing and fallen fixtures, every env against its oracle; and the rows do change the result."""
+    from vid2player3d_amd.model import load_baked_model
+    from vid2player3d_amd.racket import with_racket
+
+    bm, _ = with_racket(load_baked_model())
+    jw = 3 * (bm.body_index("R_Wrist") - 1)
+    for seed, lift, sig, what, tolf in ((61, 0.0, 0.5, "limits standing", TOL_FORCE), (62, -0.75, 0.2, "limits fallen", 2e-2)):
+        pairs = _run_pair(mlib, 48, contact=True, seed=seed, lift=lift, vel_sigma=sig, steps=2, limits=True, body_model=bm, act_sigma=0.5, what=what)
+        for got, ref in pairs:
+            _compare(got, ref, what, tol_force=tolf)
+        (got0, _), = _run_pair(mlib, 48, contact=True, seed=seed, lift=lift, vel_sigma=sig, limits=False, body_model=bm, act_sigma=0.5, what=what + " off")
+        moved = np.abs(pairs[0][0]["dvel"][:, jw:jw + 3] - got0["dvel"][:, jw:jw + 3]).max(axis=1)
+        print("[limits] %s: wrist rates differ from the run without limits in %d of 48 envs (max %.2f rad/s)" % (what, (moved > 1e-2).sum(), moved.max()))
+        assert (moved > 1e-2).mean() > 0.5
 
 
 def test_multi_step_drift_is_bounded(mlib):

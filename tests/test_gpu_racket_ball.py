@@ -58,11 +58,13 @@ def _launch(task, rng, mode):
     return ball
 
 
-@pytest.mark.parametrize("mode,lift", [("flight", 0.0), ("ground", 0.0), ("hit", 0.4), ("hit", 0.0)])
-def test_ball_step_matches_oracle(mlib, mode, lift):
+@pytest.mark.parametrize("mode,lift,limits", [("flight", 0.0, False), ("ground", 0.0, False), ("hit", 0.4, False), ("hit", 0.0, False), ("hit", 0.0, True)])
+def test_ball_step_matches_oracle(mlib, mode, lift, limits):
+    """limits: with the joint ranges of the player MJCF's racket arm enforced (v2p_sim_cfg.joint_limits) - the wrist's limit rows, its
+    hull points and the ball x racket rows then all belong to the same link."""
     n = 32
     rng = np.random.default_rng({"flight": 1, "ground": 2, "hit": 3}[mode] + int(10 * lift))
-    task = make_rb_task(n, mlib)
+    task = make_rb_task(n, mlib, joint_limits=limits)
     task.reset_with_times(None, T(rng.uniform(0.1, 1.0, size=n)))
     root = N(task._humanoid_root_states).copy()
     root[:, 2] += lift
@@ -77,7 +79,7 @@ def test_ball_step_matches_oracle(mlib, mode, lift):
     bm = task.body_model
     oracles = []
     for e in range(n):
-        o = PhysOracle(bm, default_params(), kp=bm.kp.astype(np.float32), kd=bm.kd.astype(np.float32))
+        o = PhysOracle(bm, default_params(joint_limits=int(limits)), kp=bm.kp.astype(np.float32), kd=bm.kd.astype(np.float32))
         o.set_state(root[e], dpos[e], dvel[e])
         o.attach_ball(task.racket_geometry)
         oracles.append(o)

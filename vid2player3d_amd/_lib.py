@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "libv2p_rollout.so")
 
 NUM_BODIES, NUM_DOF, NUM_ACTIONS, NUM_OBS = 24, 69, 75, 461
 MOTION_STATE_DIM, CONTEXT_DIM = 331, 378
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_f = C.POINTER(C.c_float)
 c_i32 = C.POINTER(C.c_int32)
@@ -22,7 +22,8 @@ vp = C.c_void_p
 
 class ModelDesc(C.Structure):
     _fields_ = [("num_bodies", C.c_int32), ("parents", c_i32), ("local_pos", c_f), ("mass", c_f), ("com", c_f), ("inertia", c_f),
-                ("kp", c_f), ("kd", c_f), ("armature", c_f), ("hull_offsets", c_i32), ("hull_verts", c_f)]
+                ("kp", c_f), ("kd", c_f), ("armature", c_f), ("hull_offsets", c_i32), ("hull_verts", c_f),
+                ("limit_lower", c_f), ("limit_upper", c_f)]
 
 
 class MotionTables(C.Structure):
@@ -40,7 +41,8 @@ class SimCfg(C.Structure):
                 ("max_episode_length", C.c_float), ("enable_early_termination", C.c_int32), ("context_length", C.c_int32),
                 ("context_padding", C.c_int32), ("term_heights", C.c_float * 24), ("body_pos_weights", C.c_float * 24),
                 ("reward_specs", C.c_float * 8), ("freeze_terminated_envs", C.c_int32), ("schedule", C.c_int32), ("pair_envs_by_load", C.c_int32),
-                ("solver_type", C.c_int32), ("substep_jobs", C.c_int32), ("job_mono_permille", C.c_int32), ("pair_mix_permille", C.c_int32), ("debug_contacts", C.c_int32)]
+                ("solver_type", C.c_int32), ("substep_jobs", C.c_int32), ("job_mono_permille", C.c_int32), ("pair_mix_permille", C.c_int32), ("debug_contacts", C.c_int32),
+                ("joint_limits", C.c_int32)]
 
 
 class EnvBuffers(C.Structure):

@@ -98,6 +98,11 @@ int v2p_model_create(const v2p_model_desc* d, int device, v2p_model** out) {
             }
             h.shape.kp[b] = kp[0]; h.shape.kd[b] = kd[0]; h.shape.arm[b] = ar[0];
         }
+        for (int k = 0; k < 3; ++k) {
+            h.shape.limit_lo[b][k] = b > 0 && d->limit_lower ? d->limit_lower[3 * (b - 1) + k] : -3.14159265f;
+            h.shape.limit_hi[b][k] = b > 0 && d->limit_upper ? d->limit_upper[3 * (b - 1) + k] : 3.14159265f;
+            if (!(h.shape.limit_lo[b][k] <= h.shape.limit_hi[b][k])) { set_error("v2p_model_create: body %d: joint range is empty", b); delete m; return V2P_ERR_INVALID; }
+        }
     }
     {
         int off = 0;
@@ -298,6 +303,11 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
     if (c->schedule != 0 && c->schedule != 1) { set_error("v2p_env_create: schedule must be 0 or 1"); delete e; return V2P_ERR_INVALID; }
     if (c->solver_type != 0 && c->solver_type != 1) { set_error("v2p_env_create: solver_type must be 0 (PGS) or 1 (TGS)"); delete e; return V2P_ERR_INVALID; }
     if (c->solver_type == 1 && c->schedule == 1) { set_error("v2p_env_create: the env-per-lane cross-check kernel solves PGS only"); delete e; return V2P_ERR_UNSUPPORTED; }
+    if (c->joint_limits && (c->schedule == 1 || c->solver_type != 0 || !c->enable_contact)) {
+        set_error("v2p_env_create: joint_limits needs the link-per-lane schedule, the PGS solver and contacts on");
+        delete e;
+        return V2P_ERR_UNSUPPORTED;
+    }
     e->schedule = c->schedule;
     EnvParams& p = e->p;
     p.h = c->sim_dt / (float)c->substeps;
@@ -313,6 +323,7 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
     p.enable_early_termination = c->enable_early_termination;
     p.freeze_terminated = c->freeze_terminated_envs;
     p.solver_type = c->solver_type;
+    p.joint_limits = c->joint_limits ? 1 : 0;
     p.context_length = c->context_length; p.context_padding = c->context_padding;
     p.dt = (float)c->control_freq_inv * c->sim_dt;
     memcpy(p.term_heights, c->term_heights, sizeof(p.term_heights));
@@ -589,6 +600,7 @@ int v2p_env_set_schedule(v2p_env* e, int schedule) {
     if (!e || (schedule != 0 && schedule != 1)) { set_error("v2p_env_set_schedule: bad argument"); return V2P_ERR_INVALID; }
     if (schedule == 1 && e->num_shapes > 1) { set_error("v2p_env_set_schedule: the env-per-lane kernel handles single-shape batches only"); return V2P_ERR_UNSUPPORTED; }
     if (schedule == 1 && e->p.solver_type == 1) { set_error("v2p_env_set_schedule: the env-per-lane cross-check kernel solves PGS only"); return V2P_ERR_UNSUPPORTED; }
+    if (schedule == 1 && e->p.joint_limits) { set_error("v2p_env_set_schedule: the env-per-lane cross-check kernel has no joint limits"); return V2P_ERR_UNSUPPORTED; }
     if (schedule == 1) {
         DeviceGuard g(e->device);
         int rc = ensure_env_per_lane_buffers(e);

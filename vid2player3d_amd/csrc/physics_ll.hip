@@ -241,8 +241,13 @@ struct ContactStore<true> {
 // 4096 indivisible jobs of 0.14-0.65 ms on 2048-3072 wave slots and the launch is as long as its worst slot (82 % utilisation,
 // profiles/r02*_wave_times.txt); quarter-size jobs pack 4x finer.  Jobs are dispatched in index order (substep-major, heavy pairs
 // first), so a job only ever waits for one that was dispatched before it.
-template <bool CONTACT, bool MULTI, bool TGS, bool DIAG, bool BALL, bool JOBS>
-__global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG) ? 2 : V2P_LL_WPS) void physics_ll_kernel(PhysArgs a) {
+// LIMITS: joint-limit rows (v2p_sim_cfg.joint_limits; the model is stated in oracle/phys/v2p_phys_oracle.c).  A DOF whose range is
+// narrower than a full turn carries one row against its nearer limit; the rows of joint b form their own block update right before
+// the contact block of link b.  A limit impulse is a joint-space impulse: it enters the propagation as the link's `un`, and its
+// reaction (-impulse, a pure torque) joins what the link hands up to its parent.  The inverse mass of the rows is the joint-space
+// inverse inertia K = Di + ((T - 1)^T G (T - 1))_ww = Lambda_b,ww - H1 - H1^T + Lambda_parent,ww in the notation of the recursion below.
+template <bool CONTACT, bool MULTI, bool TGS, bool DIAG, bool BALL, bool JOBS, bool LIMITS>
+__global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_WPS) void physics_ll_kernel(PhysArgs a) {
     const int64_t N = a.n;
     const int lane = threadIdx.x & 63;
     const int half = lane >> 5;
@@ -434,6 +439,9 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG) ? 2 : V2P_LL_WPS) void 
         const V3 com{S->com[bo][0], S->com[bo][1], S->com[bo][2]};
         const Sym3 Ib{S->inertia[bo][0], S->inertia[bo][1], S->inertia[bo][2], S->inertia[bo][3], S->inertia[bo][4], S->inertia[bo][5]};
         V3 tau{0.f, 0.f, 0.f};
+        float lsgn[3] = {0.f, 0.f, 0.f}, lbias[3] = {0.f, 0.f, 0.f}, llam[3] = {0.f, 0.f, 0.f};  // LIMITS: this joint's rows (sign 0 = none)
+        bool limact = false;
+        Sym3 Kd{1.f, 0.f, 0.f, 1.f, 0.f, 1.f};  // LIMITS: joint-space inverse inertia of this joint, body axes
         Sym3 A;
         M3 B;
         Sym3 C{mass, 0.f, 0.f, mass, 0.f, mass};
@@ -441,7 +449,23 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG) ? 2 : V2P_LL_WPS) void 
         {
             const M3 R = q2mat(q);
             const float kp = S->kp[bo], kd = S->kd[bo];
-            if (b != 0) tau = mul(R, kp * (park_get3(PARK_TAR) - quat_to_expmap_stable(jq)) - (kd + h * kp) * wt);
+            const V3 qe = b != 0 ? quat_to_expmap_stable(jq) : V3{0.f, 0.f, 0.f};
+            if (b != 0) tau = mul(R, kp * (park_get3(PARK_TAR) - qe) - (kd + h * kp) * wt);
+            if (LIMITS) {
+                limact = false;
+                const float ih = PHYS_RCP(h);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const float lo = S->limit_lo[bo][i], hi = S->limit_hi[bo][i], qi = i == 0 ? qe.x : (i == 1 ? qe.y : qe.z);
+                    const bool on = P.joint_limits && valid && b != 0 && hi - lo < 6.28f;
+                    const float clo = qi - lo, chi = hi - qi;
+                    const float gap = clo <= chi ? clo : chi;
+                    lsgn[i] = on ? (clo <= chi ? 1.f : -1.f) : 0.f;
+                    lbias[i] = gap >= 0.f ? gap * ih : fmaxf(P.erp * gap * ih, -P.max_depen);
+                    llam[i] = 0.f;
+                    limact = limact || on;
+                }
+            }
             V3 dc = mul(R, com);
             V3 k0 = mul(Ib, V3{R.m[0], R.m[1], R.m[2]});
             V3 k1 = mul(Ib, V3{R.m[3], R.m[4], R.m[5]});
@@ -859,6 +883,8 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG) ? 2 : V2P_LL_WPS) void 
             const bool ballground = BALL && ball_lane && bl[BL_GA] != 0.f;
             const unsigned long long tb = __ballot(valid && (cnt > 0 || ballhit));
             const unsigned m0 = (unsigned)tb, m1 = (unsigned)(tb >> 32);
+            const unsigned long long lmb = LIMITS ? __ballot(valid && limact) : 0ull;
+            const unsigned lm0 = (unsigned)lmb, lm1 = (unsigned)(lmb >> 32);
             if (DIAG && a.wave_times) { const int tt = __popc(half ? m1 : m0); tsum += tt; tmaxs = tt > tmaxs ? tt : tmaxs; }
             if (last) {
                 const unsigned mine = half ? m1 : m0;
@@ -867,15 +893,15 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG) ? 2 : V2P_LL_WPS) void 
                 for (unsigned t = mine; t; t &= t - 1) { const int dd = M.depth[__ffs(t) - 1]; kdep = dd > kdep ? dd : kdep; }
             }
             if (DIAG && a.prof && ((a.prof_heavy ? blockIdx.x < 8u : (blockIdx.x & 63) == 0)) && lane == 0) { atomicAdd((unsigned long long*)&a.prof[9], (unsigned long long)(__popc(m0) + __popc(m1))); atomicAdd((unsigned long long*)&a.prof[10], 1ull); }
-            const bool sweep_on = ((m0 | m1) || (BALL && any64(ballground))) && P.n_iter > 0;
+            const bool sweep_on = ((m0 | m1 | lm0 | lm1) || (BALL && any64(ballground))) && P.n_iter > 0;
             if (PARK2 && !sweep_on) unpark_vel(w, xd);
             if (sweep_on) {
                 // deepest touched link of either env: links below it are never read during the sweep, so Lambda and the
                 // per-update propagation stop there; their velocities catch up once at the end (the propagation is linear)
                 // (each env stops at ITS deepest touched link, so its arithmetic does not depend on which env shares the wave)
                 int dn0 = 0, dn1 = 0;
-                for (unsigned t = m0; t; t &= t - 1) { const int dd = M.depth[__ffs(t) - 1]; dn0 = dd > dn0 ? dd : dn0; }
-                for (unsigned t = m1; t; t &= t - 1) { const int dd = M.depth[__ffs(t) - 1]; dn1 = dd > dn1 ? dd : dn1; }
+                for (unsigned t = m0 | lm0; t; t &= t - 1) { const int dd = M.depth[__ffs(t) - 1]; dn0 = dd > dn0 ? dd : dn0; }
+                for (unsigned t = m1 | lm1; t; t &= t - 1) { const int dd = M.depth[__ffs(t) - 1]; dn1 = dd > dn1 ? dd : dn1; }
                 const int dneed = dn0 > dn1 ? dn0 : dn1, dmin = dn0 < dn1 ? dn0 : dn1;
                 const bool insweep = dep <= (half ? dn1 : dn0);  // this link moves with every update; the others catch up afterwards
                 LLPH(4);
@@ -938,6 +964,14 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG) ? 2 : V2P_LL_WPS) void 
                                 Lam.B.m[3 * i + j] = aug * dot(row(DiM, i), col(Gb, j)) - dot(row(E, i), gcj);
                             }
                         Lam.C = Gc;
+                        if (LIMITS && limact) {
+                            const Sym3 K{Lam.A.xx - 2.f * H1.m[0] + Lp.A.xx, Lam.A.xy - H1.m[1] - H1.m[3] + Lp.A.xy, Lam.A.xz - H1.m[2] - H1.m[6] + Lp.A.xz,
+                                         Lam.A.yy - 2.f * H1.m[4] + Lp.A.yy, Lam.A.yz - H1.m[5] - H1.m[7] + Lp.A.yz, Lam.A.zz - 2.f * H1.m[8] + Lp.A.zz};
+                            const M3 R = q2mat(Q4{park[PARK_Q * 64], park[(PARK_Q + 1) * 64], park[(PARK_Q + 2) * 64], park[(PARK_Q + 3) * 64]});
+                            const V3 c0 = col(R, 0), c1 = col(R, 1), c2 = col(R, 2);
+                            const V3 k0 = mul(K, c0), k1 = mul(K, c1), k2 = mul(K, c2);
+                            Kd = Sym3{dot(c0, k0), dot(c0, k1), dot(c0, k2), dot(c1, k1), dot(c1, k2), dot(c2, k2)};
+                        }
                     }
                 }
 
@@ -987,6 +1021,8 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG) ? 2 : V2P_LL_WPS) void 
                         if ((int)((a.par_pack[nn / 12] >> (5 * (nn % 12))) & 31ull) == prev) chain1 |= 1u << nn;
                         prev = nn;
                     }
+                    chain0 &= ~lm0;  // the limit rows of a joint come between its parent's block and its own: no chaining into it
+                    chain1 &= ~lm1;
                 }
                 // ======================================================== block Gauss-Seidel: k-th touched body of each env at once
                 const float hs = h / (float)P.n_iter;  // TGS: length of a time slice
@@ -994,7 +1030,7 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG) ? 2 : V2P_LL_WPS) void 
                 const float tgs_pen = P.erp / hs;
                 auto rowbias = [&](float v) -> float { return TGS ? (v >= 0.f ? v * tgs_irem : fmaxf(tgs_pen * v, -P.max_depen)) : v; };
                 for (int it = 0; it < P.n_iter; ++it) {
-                    unsigned t0 = m0, t1 = m1;
+                    unsigned t0 = m0, t1 = m1, l0 = lm0, l1 = lm1;
                     bool moved = false;
                     if (TGS && it > 0) {
                         // gaps advance with the normal velocity the points have after the previous sweep (touched links are current)
@@ -1002,23 +1038,50 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG) ? 2 : V2P_LL_WPS) void 
                         for (int c = 0; c < 4; ++c) { const V3 rc = CS.cr(c); CS.set_bias(c, CS.bias(c) + hs * (rc.y * w.x - rc.x * w.y + xd.z)); }
                         tgs_irem = 1.f / (h - (float)it * hs);
                     }
-                    while (t0 | t1) {
+                    while (t0 | t1 | l0 | l1) {
                         // ---- one GROUP per env: a touched link and, while the next touched link (ascending order) is a child of the
                         // one just solved, that child too.  Inside a group a link sees its parent's impulses through the parent's own
                         // response (Lambda_parent x impulse, propagated over one joint), and the leaf->root->leaves propagation runs
                         // ONCE for the whole chain (a limb lying on the ground, ankle + toe of a standing foot) - linear, so the
                         // sequence of row updates is exactly the one of solving the links one by one.
                         int b0 = t0 ? __ffs(t0) - 1 : -1, b1 = t1 ? __ffs(t1) - 1 : -1;
-                        t0 &= t0 - 1;
-                        t1 &= t1 - 1;
+                        // LIMITS: the next event of an env is the limit block of joint j when no touched link below j is left
+                        const int j0 = l0 ? __ffs(l0) - 1 : 99, j1 = l1 ? __ffs(l1) - 1 : 99;
+                        const bool lim0 = LIMITS && j0 != 99 && (b0 < 0 || j0 <= b0), lim1 = LIMITS && j1 != 99 && (b1 < 0 || j1 <= b1);
+                        if (lim0) { b0 = j0; l0 &= l0 - 1; } else t0 &= t0 - 1;
+                        if (lim1) { b1 = j1; l1 &= l1 - 1; } else t1 &= t1 - 1;
+                        const bool mylim = half ? lim1 : lim0;
                         int last0 = b0, last1 = b1;
                         long long tsub = DIAG && a.prof ? clock64() : 0;
                         if (DIAG && a.prof && ((a.prof_heavy ? blockIdx.x < 8u : (blockIdx.x & 63) == 0)) && lane == 0) atomicAdd((unsigned long long*)&a.prof[8], 1ull);
                         V3 un{0.f, 0.f, 0.f}, uf{0.f, 0.f, 0.f};
                         V3 Dw{0.f, 0.f, 0.f}, Dv{0.f, 0.f, 0.f};  // velocity change of the link just solved due to the group's impulses so far
+                        V3 jt{0.f, 0.f, 0.f};  // LIMITS: the joint impulse of this block, world axes (its reaction goes to the parent)
+                        if (LIMITS && (lim0 || lim1)) {
+                            const V3 pw = pp(w, true);  // all links are current between blocks
+                            if (valid && mylim && lb == (half ? b1 : b0)) {
+                                const M3 R = q2mat(Q4{park[PARK_Q * 64], park[(PARK_Q + 1) * 64], park[(PARK_Q + 2) * 64], park[(PARK_Q + 3) * 64]});
+                                const V3 om0 = mulT(R, w - pw);  // joint rate, body axes
+                                float om[3] = {om0.x, om0.y, om0.z}, tq[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                                for (int i = 0; i < 3; ++i) {
+                                    const V3 kc = i == 0 ? V3{Kd.xx, Kd.xy, Kd.xz} : (i == 1 ? V3{Kd.xy, Kd.yy, Kd.yz} : V3{Kd.xz, Kd.yz, Kd.zz});
+                                    const float kii = i == 0 ? kc.x : (i == 1 ? kc.y : kc.z);
+                                    const float rel = lsgn[i] * om[i] + lbias[i];
+                                    const float nl = fmaxf(llam[i] - rel * __builtin_amdgcn_rcpf(kii), 0.f);
+                                    const float dl = lsgn[i] != 0.f ? nl - llam[i] : 0.f;
+                                    llam[i] += dl;
+                                    const float sdl = lsgn[i] * dl;
+                                    tq[i] = sdl;
+                                    om[0] += kc.x * sdl; om[1] += kc.y * sdl; om[2] += kc.z * sdl;
+                                }
+                                jt = mul(R, V3{tq[0], tq[1], tq[2]});
+                                un = jt;
+                            }
+                        }
                         for (int step = 0;; ++step) {
                             const int bsel = half ? b1 : b0;
-                            const bool me = valid && (lb == bsel);
+                            const bool me = valid && (lb == bsel) && !(LIMITS && mylim);
                             V3 tw{0.f, 0.f, 0.f}, tv{0.f, 0.f, 0.f};
                             if (step > 0) {
                                 const V3 pdw = pp(Dw, true), pdv = pp(Dv, true);
@@ -1107,7 +1170,7 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG) ? 2 : V2P_LL_WPS) void 
                             }
                             // does the chain go on?  (next touched link of the env, ascending, is a child of the one just solved)
                             const int n0 = t0 ? __ffs(t0) - 1 : -1, n1 = t1 ? __ffs(t1) - 1 : -1;
-                            const bool c0 = b0 >= 0 && n0 >= 0 && ((chain0 >> n0) & 1u), c1 = b1 >= 0 && n1 >= 0 && ((chain1 >> n1) & 1u);
+                            const bool c0 = !lim0 && b0 >= 0 && n0 >= 0 && ((chain0 >> n0) & 1u), c1 = !lim1 && b1 >= 0 && n1 >= 0 && ((chain1 >> n1) & 1u);
                             if (!(c0 || c1)) break;
                             b0 = c0 ? n0 : -1;
                             b1 = c1 ? n1 : -1;
@@ -1132,6 +1195,7 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG) ? 2 : V2P_LL_WPS) void 
                                 V3 na = aug * mul(Di, un);
                                 V3 fa = uf - V3{dot(col(E, 0), un), dot(col(E, 1), un), dot(col(E, 2), un)};
                                 cn = na + cross(r, fa);
+                                if (LIMITS) cn = cn - jt;
                                 cf = fa;
                             }
                             if ((nonchain >> d) & 1) {
@@ -1583,17 +1647,28 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s, float* actions) {
     const bool tgs = env->p.solver_type == 1;
     const bool diag = a.prof || a.wave_times;
     if (env->ball) a.ball = *env->ball;
-    if (env->ball && env->p.enable_contact && !tgs) {  // racket + ball: its own instantiation (PGS, with contacts)
-        if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, false, false, true, false>), grid, block, lds, s, a);
-        else hipLaunchKernelGGL((physics_ll_kernel<true, false, false, false, true, false>), grid, block, lds, s, a);
+    if (env->p.joint_limits && env->p.enable_contact && !tgs) {  // joint-limit rows: their own instantiations (PGS, with contacts, +- ball)
+        if (env->ball) {
+            if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, false, false, true, false, true>), grid, block, lds, s, a);
+            else hipLaunchKernelGGL((physics_ll_kernel<true, false, false, false, true, false, true>), grid, block, lds, s, a);
+        } else {
+            if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, false, false, false, false, true>), grid, block, lds, s, a);
+            else hipLaunchKernelGGL((physics_ll_kernel<true, false, false, false, false, false, true>), grid, block, lds, s, a);
+        }
+    } else if (env->p.joint_limits) {
+        set_error("physics: joint limits run with contacts on and the PGS solver");
+        return V2P_ERR_UNSUPPORTED;
+    } else if (env->ball && env->p.enable_contact && !tgs) {  // racket + ball: its own instantiation (PGS, with contacts)
+        if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, false, false, true, false, false>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((physics_ll_kernel<true, false, false, false, true, false, false>), grid, block, lds, s, a);
     } else if (env->ball) {
         set_error("physics: racket + ball runs with contacts on and the PGS solver");
         return V2P_ERR_UNSUPPORTED;
     } else if (diag && env->p.enable_contact && !tgs && !multi) {  // the instrumented build exists for the headline configuration only
-        hipLaunchKernelGGL((physics_ll_kernel<true, false, false, true, false, false>), grid, block, lds, s, a);
+        hipLaunchKernelGGL((physics_ll_kernel<true, false, false, true, false, false, false>), grid, block, lds, s, a);
     } else if (env->p.enable_contact && tgs) {
-        if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, true, false, false, false>), grid, block, lds, s, a);
-        else hipLaunchKernelGGL((physics_ll_kernel<true, false, true, false, false, false>), grid, block, lds, s, a);
+        if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, true, false, false, false, false>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((physics_ll_kernel<true, false, true, false, false, false, false>), grid, block, lds, s, a);
     } else if (env->p.enable_contact && env->substep_jobs && env->job_progress && blocks > 1) {
         // substep jobs: one launch of nsub x blocks workgroups, substep-major
         a.job_blocks = (int)blocks;
@@ -1607,14 +1682,14 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s, float* actions) {
         }
         a.job_mono = (int)(blocks * (unsigned)env->job_mono_permille / 1000u);
         const dim3 jgrid((unsigned)a.job_mono + (blocks - (unsigned)a.job_mono) * (unsigned)env->p.nsub);
-        if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, false, false, false, true>), jgrid, block, lds, s, a);
-        else hipLaunchKernelGGL((physics_ll_kernel<true, false, false, false, false, true>), jgrid, block, lds, s, a);
+        if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, false, false, false, true, false>), jgrid, block, lds, s, a);
+        else hipLaunchKernelGGL((physics_ll_kernel<true, false, false, false, false, true, false>), jgrid, block, lds, s, a);
     } else if (env->p.enable_contact) {
-        if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, false, false, false, false>), grid, block, lds, s, a);
-        else hipLaunchKernelGGL((physics_ll_kernel<true, false, false, false, false, false>), grid, block, lds, s, a);
+        if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, false, false, false, false, false>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((physics_ll_kernel<true, false, false, false, false, false, false>), grid, block, lds, s, a);
     } else {
-        if (multi) hipLaunchKernelGGL((physics_ll_kernel<false, true, false, false, false, false>), grid, block, lds, s, a);
-        else hipLaunchKernelGGL((physics_ll_kernel<false, false, false, false, false, false>), grid, block, lds, s, a);
+        if (multi) hipLaunchKernelGGL((physics_ll_kernel<false, true, false, false, false, false, false>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((physics_ll_kernel<false, false, false, false, false, false, false>), grid, block, lds, s, a);
     }
     env->pair_have = paired ? 1 : 0;
     return check_hip(hipGetLastError(), "physics_ll_kernel");

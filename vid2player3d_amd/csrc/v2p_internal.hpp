@@ -38,6 +38,7 @@ struct DevShape {
     int32_t hull_count[NB];        // real vertex count per body
     int32_t hull_cofs[NB + 1];     // offsets of the unpadded lists (LDS copy of the link-per-lane kernel)
     float hull_verts[MAX_HULL_VERTS][3];
+    float limit_lo[NB][3], limit_hi[NB][3];  // per-DOF range of the joint's exponential-map coordinate (radians), index = body id
 };
 
 // Body model as the kernels see it: the tree (uniform across lanes, scalar loads) + the shape of a single-shape batch.
@@ -92,6 +93,7 @@ struct EnvParams {
     int enable_early_termination;
     int freeze_terminated;  // envs whose reset flag is set are not simulated (their state stays as it is)
     int solver_type;        // 0 PGS, 1 TGS (frozen Jacobians)
+    int joint_limits;       // 1: limit rows for DOFs with a range narrower than a full turn
     int context_length, context_padding;
     float dt;              // control step
     float term_heights[NB];

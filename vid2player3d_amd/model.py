@@ -159,6 +159,9 @@ class BodyModel:
         self.kp = self.blob["kp"] * pd_scale * kp_scale
         self.kd = self.blob["kd"] * pd_scale * kd_scale
         self.armature = self.blob["armature"].astype(np.float64)
+        # per-DOF range of the exponential-map coordinate, radians (MJCF `range`); +-pi = unlimited
+        self.limit_lower = self.blob["limit_lower"].astype(np.float64) if "limit_lower" in self.blob else np.full(self.num_dof, -np.pi)
+        self.limit_upper = self.blob["limit_upper"].astype(np.float64) if "limit_upper" in self.blob else np.full(self.num_dof, np.pi)
         self.hull_offsets = self.blob["hull_offsets"].astype(np.int32)
         self.hull_verts = self.blob["hull_verts"].astype(np.float64)
         # dof bookkeeping the reference derives from asset dof names (humanoid_smpl_im.py:159-178)

@@ -51,10 +51,23 @@ def _cylinder_vertices(centre, axis, half_len, radius, n_ring):
     return np.concatenate([centre + half_len * axis + ring, centre - half_len * axis + ring])
 
 
-def with_racket(base, wrist_vertex_budget=30, **model_kw):
-    """(BodyModel with the racket folded into R_Wrist, geometry dict for the ball contacts)."""
+# joint ranges of the racket arm in the player MJCFs, degrees (smpl_mesh_humanoid_djokovic.xml:173, 178-180); every other DOF is +-180 / +-720
+PLAYER_ARM_LIMITS = {"R_Elbow": ((-180.0, 90.0), None, None), "R_Wrist": ((-10.0, 10.0), (-45.0, 45.0), (-90.0, 90.0))}
+
+
+def with_racket(base, wrist_vertex_budget=30, arm_limits=True, **model_kw):
+    """(BodyModel with the racket folded into R_Wrist, geometry dict for the ball contacts).  arm_limits: carry the player MJCF's joint
+    ranges of the racket arm (enforced when cfg['env']['joint_limits'] is on)."""
     b = base.body_index(RACKET_PARENT)
     blob = dict(base.blob)
+    if arm_limits:
+        lo, hi = base.limit_lower.copy(), base.limit_upper.copy()
+        for name, ranges in PLAYER_ARM_LIMITS.items():
+            j = 3 * (base.body_index(name) - 1)
+            for i, rg in enumerate(ranges):
+                if rg is not None:
+                    lo[j + i], hi[j + i] = np.deg2rad(rg[0]), np.deg2rad(rg[1])
+        blob["limit_lower"], blob["limit_upper"] = lo, hi
     cyls = racket_cylinders()
     # composite rigid body: wrist + handle + head
     parts = [(base.mass[b], base.com[b], base.inertia[b])] + [_cylinder_mass_properties(*c) for c in cyls]

@@ -341,7 +341,8 @@ class HumanoidSMPLIM:
         def create_model(m):
             d = _lib.ModelDesc(num_bodies=m.num_bodies, parents=iarr(m.parents), local_pos=farr(m.local_pos), mass=farr(m.mass),
                                com=farr(m.com), inertia=farr(m.inertia), kp=farr(m.kp), kd=farr(m.kd), armature=farr(m.armature),
-                               hull_offsets=iarr(m.hull_offsets), hull_verts=farr(m.hull_verts))
+                               hull_offsets=iarr(m.hull_offsets), hull_verts=farr(m.hull_verts),
+                               limit_lower=farr(m.limit_lower), limit_upper=farr(m.limit_upper))
             h = C.c_void_p()
             _lib.check(lib.v2p_model_create(C.byref(d), self.device_id, C.byref(h)), "v2p_model_create")
             return h
@@ -364,6 +365,11 @@ class HumanoidSMPLIM:
         c.substep_jobs = int(env.get("substep_jobs", True)) if c.solver_type == 0 and c.enable_contact and c.schedule == 0 else 0
         c.job_mono_permille = int(env.get("job_mono_permille", -1))  # -1: the engine's defaults
         c.pair_mix_permille = int(env.get("pair_mix_permille", -1))
+        # joint ranges of the MJCF enforced as limit rows (Isaac Gym always enforces them; only the racket arm of the player MJCFs has
+        # DOFs narrower than a full turn, the amass MJCF has none); runs whole control steps per workgroup
+        c.joint_limits = int(env.get("joint_limits", False))
+        if c.joint_limits:
+            c.substep_jobs = 0
         c.debug_contacts = int(env.get("debug_contacts", 0))  # 0 off, 1 last substep's contact vertices kept, 2 every substep's
         hold = env.get("residual_force_hold", "first_sim")
         c.residual_hold_sims = 1 if hold == "first_sim" else self.control_freq_inv
