@@ -194,6 +194,9 @@ constexpr bool PARK2 = V2P_LL_PARK2 != 0;
 #define V2P_LL_PARK3 1
 #endif
 constexpr bool PARK3 = V2P_LL_PARK3 != 0;
+#ifndef V2P_LL_PREFETCH_ROWS
+#define V2P_LL_PREFETCH_ROWS 0
+#endif
 constexpr int PARK_TAR = 0, PARK_W0 = 3, PARK_XD0 = 6, PARK_Q = 9, PARK_X = 13, PARK_CR = 16, PARK_CB = 28, PARK_CL = 32,
               PARK_SLOTS = PARK3 ? 44 : 16;  // LDS parking slots (dwords per lane)
 constexpr int ROOTLAM_FLOATS = 2 * 24;  // (PARK2) Lambda of the two root links while the contacts are generated
@@ -1092,17 +1095,33 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                             }
                             if (me) {
                                 V3 wl = w + tw, xl = xd + tv;
+#if V2P_LL_PREFETCH_ROWS
+                                // all four records of the link at once (one LDS round trip instead of one per point; unused slots hold zeros)
+                                V3 rr4[4], lam4[4];
+                                float bias4[4];
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) { rr4[c] = CS.cr(c); lam4[c] = CS.lam(c); bias4[c] = CS.bias(c); }
+#endif
 #pragma unroll
                                 for (int c = 0; c < 4; ++c) {
                                     const bool active = c < cnt;
                                     if (!any64(active)) break;  // uniform over the (at most two) touched links solved here
+#if V2P_LL_PREFETCH_ROWS
+                                    V3 rr = rr4[c];
+                                    const V3 lam0 = lam4[c];
+#else
                                     V3 rr = CS.cr(c);
                                     const V3 lam0 = CS.lam(c);
+#endif
                                     float ln = lam0.x, l1 = lam0.y, l2 = lam0.z;
                                     // a point without normal impulse (hence without friction impulses: they are clamped to mu x normal)
                                     // that is separating stays as it is: its three rows would change nothing
                                     // (masked per lane as well, so that an env's numbers do not depend on what its wave partner does)
+#if V2P_LL_PREFETCH_ROWS
+                                    const float bias_c = rowbias(bias4[c]);
+#else
                                     const float bias_c = rowbias(CS.bias(c));
+#endif
                                     const bool act = active && !(ln == 0.f && rr.y * wl.x - rr.x * wl.y + xl.z + bias_c >= 0.f);
                                     if (!any64(act)) continue;
 #pragma unroll
