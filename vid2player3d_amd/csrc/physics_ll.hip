@@ -117,6 +117,11 @@ struct ParentPull {
         if (V2P_LL_DPP_PARENT && !nonchain) return from_prev(v);
         return pull(v, plane);
     }
+    // DPP on chain-only levels whatever V2P_LL_DPP_PARENT says (the per-update propagation of the sweep, V2P_LL_DPP_DOWN)
+    __device__ __forceinline__ V3 fast(V3 v, bool nonchain) const {
+        if (!nonchain) return V3{from_prev(v.x), from_prev(v.y), from_prev(v.z)};
+        return V3{pull(v.x, plane), pull(v.y, plane), pull(v.z, plane)};
+    }
     __device__ __forceinline__ V3 operator()(V3 v, bool nonchain) const {
         if (V2P_LL_DPP_PARENT && !nonchain) return V3{from_prev(v.x), from_prev(v.y), from_prev(v.z)};
         return V3{pull(v.x, plane), pull(v.y, plane), pull(v.z, plane)};
@@ -195,7 +200,10 @@ constexpr bool PARK2 = V2P_LL_PARK2 != 0;
 #endif
 constexpr bool PARK3 = V2P_LL_PARK3 != 0;
 #ifndef V2P_LL_PREFETCH_ROWS
-#define V2P_LL_PREFETCH_ROWS 0
+#define V2P_LL_PREFETCH_ROWS 1
+#endif
+#ifndef V2P_LL_DPP_DOWN
+#define V2P_LL_DPP_DOWN 0
 #endif
 constexpr int PARK_TAR = 0, PARK_W0 = 3, PARK_XD0 = 6, PARK_Q = 9, PARK_X = 13, PARK_CR = 16, PARK_CB = 28, PARK_CL = 32,
               PARK_SLOTS = PARK3 ? 44 : 16;  // LDS parking slots (dwords per lane)
@@ -1240,7 +1248,11 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                         }
                         for (int d = 1; d <= dneed; ++d) {
                             const bool nc = (nonchain >> d) & 1;
+#if V2P_LL_DPP_DOWN
+                            V3 pdw = pp.fast(ddw, nc), pdv = pp.fast(ddv, nc);
+#else
                             V3 pdw = pp(ddw, nc), pdv = pp(ddv, nc);
+#endif
                             if (dep == d && insweep) {
                                 V3 av = pdv + cross(pdw, r);
                                 ddw = mul(Di, aug * pdw + un) - mul(E, av);
