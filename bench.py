@@ -73,13 +73,14 @@ def self_launch(gpus, argv, stub):
 
 
 # ---------------------------------------------------------------------------------------------- the workload
-def build_task(num_envs, device_id, seed, contact=True, per_clip_shapes=False, djokovic=False, freeze=False, solver="pgs", racket_ball=False, substep_jobs=False, joint_limits=None):
+def build_task(num_envs, device_id, seed, contact=True, per_clip_shapes=False, djokovic=False, freeze=False, solver="pgs", racket_ball=False, substep_jobs=False, joint_limits=None, env_extra=None):
     from vid2player3d_amd.tasks import HumanoidSMPLIM, HumanoidSMPLIMRacketBall, default_cfg
 
     cfg = default_cfg(num_envs, synthetic_motions={"seed": 7, "num_clips": 64, "min_frames": 90, "max_frames": 300},
                       enable_contact=contact, contact_solver=solver, substep_jobs=substep_jobs)
     if joint_limits is not None:
         cfg["env"]["joint_limits"] = bool(joint_limits)
+    cfg["env"].update(env_extra or {})
     if freeze:  # NOT the reference's behaviour (it keeps simulating terminated envs as ragdolls): reported separately, never as `value` of the default run
         cfg["env"]["freeze_terminated_envs"] = True
     if djokovic:  # BASELINE config 4 = cfg/djokovic_im.yaml: same task class, head termination height -0.5, faster (tennis-like) clips
@@ -275,6 +276,8 @@ def main():
     ap.add_argument("--solver", choices=["pgs", "tgs"], default="pgs")
     ap.add_argument("--freeze-terminated", action="store_true", help="opt-in engine feature: terminated envs are not simulated until the epoch reset (not reference behaviour)")
     ap.add_argument("--djokovic", action="store_true", help="BASELINE config 4 (djokovic_im.yaml: terminationHeadHeight -0.5, faster clips)")
+    ap.add_argument("--job-mono", type=int, default=None, help="v2p_sim_cfg.job_mono_permille (tuning sweeps)")
+    ap.add_argument("--pair-mix", type=int, default=None, help="v2p_sim_cfg.pair_mix_permille (tuning sweeps)")
     ap.add_argument("--substep-jobs", type=int, default=1, help="1: physics launch cut into (substep, env pair) jobs (v2p_sim_cfg.substep_jobs); same results, finer load balancing")
     ap.add_argument("--joint-limits", type=int, default=None, choices=(0, 1),
                     help="enforce the MJCF joint ranges as limit rows (only the racket arm of --racket-ball has any; default: on with --racket-ball, else off)")
@@ -323,7 +326,8 @@ def main():
             dist.barrier()
         task = build_task(n, local_rank, seed=7 + rank, contact=not args.no_contact, per_clip_shapes=args.per_clip_shapes, djokovic=args.djokovic or args.racket_ball,
                           freeze=args.freeze_terminated, solver=args.solver, racket_ball=args.racket_ball, substep_jobs=bool(args.substep_jobs) and not args.racket_ball,
-                          joint_limits=args.joint_limits)  # per-rank seed like run.py:37
+                          joint_limits=args.joint_limits,
+                          env_extra={k: v for k, v in (("job_mono_permille", args.job_mono), ("pair_mix_permille", args.pair_mix)) if v is not None})  # per-rank seed like run.py:37
     if args.ppo:
         return run_ppo(args, task, dist, world, rank)
     dev = task.device

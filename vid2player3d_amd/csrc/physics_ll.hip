@@ -320,6 +320,9 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
     // skips the substeps altogether (frozen envs sort to the end of the launch order, so they share waves)
     const bool frozen = P.freeze_terminated && a.reset[e] == 1;
     const int nsub = (P.freeze_terminated && !any64(!frozen)) ? 0 : P.nsub;
+#if defined(V2P_LL_PRIO_MONO)
+    if (JOBS && mono) __builtin_amdgcn_s_setprio(V2P_LL_PRIO_MONO);  // the heaviest pairs are the critical path of the launch
+#endif
 #if defined(V2P_LL_PRIO)
     {   // issue priority by predicted load: the heaviest pairs are the critical path of the launch, light waves fill the gaps they leave
         const int k0 = a.pair_key ? a.pair_key[e] : 0;
