@@ -390,8 +390,9 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
     }
     if (rc == V2P_OK) rc = check_hip(hipDeviceSynchronize(), "hipDeviceSynchronize(env_create)");
     if (rc == V2P_OK && getenv("V2P_WAVE_TIMES")) {
-        rc = check_hip(hipMalloc((void**)&e->wave_times, sizeof(long long) * 4 * (N / 2 + 1)), "hipMalloc(wave_times)");
-        if (rc == V2P_OK) rc = check_hip(hipMemset(e->wave_times, 0, sizeof(long long) * 4 * (N / 2 + 1)), "hipMemset(wave_times)");
+        // (one record per wave; per JOB in a V2P_LL_TIMELINE build: up to nsub per wave)
+        rc = check_hip(hipMalloc((void**)&e->wave_times, sizeof(long long) * 4 * (N / 2 + 1) * (size_t)p.nsub), "hipMalloc(wave_times)");
+        if (rc == V2P_OK) rc = check_hip(hipMemset(e->wave_times, 0, sizeof(long long) * 4 * (N / 2 + 1) * (size_t)p.nsub), "hipMemset(wave_times)");
     }
     if (rc == V2P_OK && getenv("V2P_PHASE_TIMING")) {
         rc = check_hip(hipMalloc((void**)&e->prof, sizeof(long long) * 24), "hipMalloc(prof)");
@@ -431,7 +432,7 @@ void v2p_env_destroy(v2p_env* e) {
     if (e->pair_hist) (void)hipFree(e->pair_hist);
     if (e->perm) (void)hipFree(e->perm);
     if (e->wave_times) {
-        const size_t nw = (size_t)(e->n + 1) / 2;
+        const size_t nw = ((size_t)e->n / 2 + 1) * (size_t)e->p.nsub;  // (records that were never written stay zero and are skipped)
         std::vector<long long> h(nw * 4);
         FILE* f = fopen(getenv("V2P_WAVE_TIMES") ? getenv("V2P_WAVE_TIMES") : "wave_times.bin", "wb");
         if (f && hipMemcpy(h.data(), e->wave_times, sizeof(long long) * h.size(), hipMemcpyDeviceToHost) == hipSuccess) fwrite(h.data(), sizeof(long long), h.size(), f);

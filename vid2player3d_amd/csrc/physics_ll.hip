@@ -414,6 +414,20 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
     }
     long long tprev = DIAG && a.prof ? clock64() : 0;
     const long long wt0 = DIAG && a.wave_times ? wall_clock64() : 0;
+#if defined(V2P_LL_TIMELINE)
+    // build-time diagnostics (tools/mkvariant.sh): wall-clock start / end of every JOB of the production kernels, by workgroup index
+    const long long tl0 = a.wave_times ? wall_clock64() : 0;
+    auto timeline = [&]() {
+        if (!DIAG && a.wave_times && lane == 0) {
+            long long* tl = a.wave_times + (int64_t)blockIdx.x * 4;
+            unsigned hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            tl[0] = tl0; tl[1] = wall_clock64(); tl[2] = (long long)bid + ((long long)sjob << 24) + ((long long)(mono ? 1 : 0) << 28) + ((long long)ksum << 32); tl[3] = hw;
+        }
+    };
+#else
+    auto timeline = [&]() {};
+#endif
     const int key_pred = DIAG && a.wave_times ? a.pair_key[e] : 0;  // what the launch order was built from (diagnostics)
     int tsum = 0, tmaxs = 0;
     V3 r{0.f, 0.f, 0.f};
@@ -1502,6 +1516,7 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (inline asm: the compiler must not drop or move this drain)
         if (lane == 0) __hip_atomic_store(progress, a.job_epoch * 8 + sjob + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        timeline();
         return;
     }
     if (valid && live_env) {
@@ -1563,6 +1578,7 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
         }
     }
     }
+    timeline();
 }
 
 // ---- pairing: the sweep of a wave costs max(touched links) of its two envs, so envs are handed to waves in descending order of
@@ -1679,7 +1695,11 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s, float* actions) {
     const dim3 grid(blocks), block(64 * LL_WPB);
     const size_t lds = sizeof(float) * LDS_FLOATS_PER_WAVE * LL_WPB;
     const bool tgs = env->p.solver_type == 1;
+#if defined(V2P_LL_TIMELINE)
+    const bool diag = a.prof != nullptr;
+#else
     const bool diag = a.prof || a.wave_times;
+#endif
     if (env->ball) a.ball = *env->ball;
     if (env->p.joint_limits && env->p.enable_contact && !tgs) {  // joint-limit rows: their own instantiations (PGS, with contacts, +- ball)
         if (env->ball) {
