@@ -336,7 +336,7 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
     const bool first_job = mono || sjob == 0, last_job = mono || sjob == P.nsub - 1;
     const bool handed = !mono && sjob > 0;  // the inputs of this job were written by another workgroup of this launch
     int* const progress = JOBS ? a.job_progress + (bid * LL_WPB + (threadIdx.x >> 6)) : nullptr;
-    if (handed) {
+    if constexpr (JOBS) if (handed) {
         // wait for the previous substep of this env pair (dispatched before this job: it is running or done)
         const int want = a.job_epoch * 8 + sjob;
         if (lane == 0) {
@@ -414,6 +414,10 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
     }
     long long tprev = DIAG && a.prof ? clock64() : 0;
     const long long wt0 = DIAG && a.wave_times ? wall_clock64() : 0;
+    const int key_pred = DIAG && a.wave_times ? a.pair_key[e] : 0;  // what the launch order was built from (diagnostics)
+    int tsum = 0, tmaxs = 0;
+    V3 r{0.f, 0.f, 0.f};
+    int ksum = 0, kdep = 0;  // contact load of this env over the launch (pairing key)
 #if defined(V2P_LL_TIMELINE)
     // build-time diagnostics (tools/mkvariant.sh): wall-clock start / end of every JOB of the production kernels, by workgroup index
     const long long tl0 = a.wave_times ? wall_clock64() : 0;
@@ -428,10 +432,6 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
 #else
     auto timeline = [&]() {};
 #endif
-    const int key_pred = DIAG && a.wave_times ? a.pair_key[e] : 0;  // what the launch order was built from (diagnostics)
-    int tsum = 0, tmaxs = 0;
-    V3 r{0.f, 0.f, 0.f};
-    int ksum = 0, kdep = 0;  // contact load of this env over the launch (pairing key)
 
     for (int sub = sub0; sub < sub1; ++sub) {
         const bool wrench_on = sub < P.hold_sub;
@@ -1500,7 +1500,7 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
     asm volatile("" : "+v"(e_out));
     {
     const int64_t e = e_out;
-    if (JOBS && !last_job) {
+    if constexpr (JOBS) if (!last_job) {
         // ---- hand the state over to the job of the next substep: system-scope stores, drained, then the progress word of the pair
         if (valid && live_env) {
             if (b == 0) {
