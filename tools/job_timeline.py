@@ -11,6 +11,11 @@ t0 = a[:, 0].min()
 start, end = (a[:, 0] - t0) / 100.0, (a[:, 1] - t0) / 100.0  # microseconds
 bid, sjob, mono, ksum = a[:, 2] & 0xffffff, (a[:, 2] >> 24) & 15, (a[:, 2] >> 28) & 1, a[:, 2] >> 32
 dur = end - start
+cyc = a[:, 3].astype(float)
+mhz = cyc / np.maximum(dur, 1e-3)
+print("shader clock seen by the jobs (cycles / wall time): mean %.0f MHz, p5 %.0f, p95 %.0f; jobs that start in the first 100 us %.0f MHz, after 450 us %.0f MHz"
+      % (mhz.mean(), *np.percentile(mhz, [5, 95]), mhz[start < 100].mean(), mhz[start > 450].mean() if (start > 450).any() else 0))
+print("cycles per job: mono mean %.0f k max %.0f k; cut mean %.0f k max %.0f k" % (cyc[mono == 1].mean() / 1e3, cyc[mono == 1].max() / 1e3, cyc[mono == 0].mean() / 1e3, cyc[mono == 0].max() / 1e3))
 print("jobs %d (mono %d, cut %d)  makespan %.1f us  sum(dur) %.0f us = %.1f us per slot at 3072 slots" % (len(a), mono.sum(), (1 - mono).sum(), end.max(), dur.sum(), dur.sum() / 3072))
 m = mono == 1
 print("mono jobs: dur mean %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f; start max %.1f; end p50 %.1f p99 %.1f max %.1f"

@@ -420,13 +420,12 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
     int ksum = 0, kdep = 0;  // contact load of this env over the launch (pairing key)
 #if defined(V2P_LL_TIMELINE)
     // build-time diagnostics (tools/mkvariant.sh): wall-clock start / end of every JOB of the production kernels, by workgroup index
-    const long long tl0 = a.wave_times ? wall_clock64() : 0;
+    const long long tl0 = a.wave_times ? wall_clock64() : 0, tc0 = a.wave_times ? clock64() : 0;
     auto timeline = [&]() {
         if (!DIAG && a.wave_times && lane == 0) {
             long long* tl = a.wave_times + (int64_t)blockIdx.x * 4;
-            unsigned hw;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-            tl[0] = tl0; tl[1] = wall_clock64(); tl[2] = (long long)bid + ((long long)sjob << 24) + ((long long)(mono ? 1 : 0) << 28) + ((long long)ksum << 32); tl[3] = hw;
+            tl[0] = tl0; tl[1] = wall_clock64(); tl[2] = (long long)bid + ((long long)sjob << 24) + ((long long)(mono ? 1 : 0) << 28) + ((long long)ksum << 32);
+            tl[3] = clock64() - tc0;  // shader cycles of the job: with the wall clock, the clock the job ran at
         }
     };
 #else
