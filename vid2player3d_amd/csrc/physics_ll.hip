@@ -270,7 +270,7 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
     // path of the launch: it starts at once and never waits); the other pairs are cut into one job per substep, substep-major
     const int nblk = JOBS ? a.job_blocks : (int)gridDim.x;                 // env pairs (wave slots) of the launch
     const bool mono = !JOBS || (int)blockIdx.x < a.job_mono;
-    const int jcut = JOBS ? nblk - a.job_mono : 1;                          // pairs that are cut into substep jobs
+    const int jcut = JOBS && nblk > a.job_mono ? nblk - a.job_mono : 1;     // pairs that are cut into substep jobs
     const int jrel = JOBS ? (int)blockIdx.x - a.job_mono : 0;
     const int sjob = mono ? 0 : jrel / jcut;                               // the substep this job runs
     const int bid = mono ? (int)blockIdx.x : a.job_mono + jrel % jcut;
@@ -1722,24 +1722,28 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s, float* actions) {
     } else if (env->p.enable_contact && tgs) {
         if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, true, false, false, false, false>), grid, block, lds, s, a);
         else hipLaunchKernelGGL((physics_ll_kernel<true, false, true, false, false, false, false>), grid, block, lds, s, a);
-    } else if (env->p.enable_contact && env->substep_jobs && env->job_progress && blocks > 1) {
-        // substep jobs: one launch of nsub x blocks workgroups, substep-major
+    } else if (env->p.enable_contact) {
+        // ONE instantiation whether the launch is cut into substep jobs or not (job_mono = every pair: whole control steps per
+        // workgroup, nothing handed over): "substep jobs are invisible" holds by construction - two instantiations of the template
+        // are two compilations, and under -fassociative-math nothing makes them round alike
+        const bool cut = env->substep_jobs && env->job_progress && blocks > 1;
         a.job_blocks = (int)blocks;
         a.job_progress = env->job_progress;
-        a.job_epoch = ++env->job_epoch;
-        if (env->job_epoch > (1 << 26)) env->job_epoch = 0;  // (wraps before the progress words overflow; a wrap needs them cleared)
-        if (env->job_epoch == 0) {
-            int rc0 = check_hip(hipMemsetAsync(env->job_progress, 0, sizeof(int) * (blocks * LL_WPB + 1), s), "hipMemsetAsync(job_progress)");
-            if (rc0 != V2P_OK) return rc0;
-            a.job_epoch = env->job_epoch = 1;
+        a.job_mono = (int)blocks;
+        if (cut) {
+            // substep jobs: one launch of job_mono + nsub x (blocks - job_mono) workgroups, substep-major
+            a.job_epoch = ++env->job_epoch;
+            if (env->job_epoch > (1 << 26)) env->job_epoch = 0;  // (wraps before the progress words overflow; a wrap needs them cleared)
+            if (env->job_epoch == 0) {
+                int rc0 = check_hip(hipMemsetAsync(env->job_progress, 0, sizeof(int) * (blocks * LL_WPB + 1), s), "hipMemsetAsync(job_progress)");
+                if (rc0 != V2P_OK) return rc0;
+                a.job_epoch = env->job_epoch = 1;
+            }
+            a.job_mono = (int)(blocks * (unsigned)env->job_mono_permille / 1000u);
         }
-        a.job_mono = (int)(blocks * (unsigned)env->job_mono_permille / 1000u);
         const dim3 jgrid((unsigned)a.job_mono + (blocks - (unsigned)a.job_mono) * (unsigned)env->p.nsub);
         if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, false, false, false, true, false>), jgrid, block, lds, s, a);
         else hipLaunchKernelGGL((physics_ll_kernel<true, false, false, false, false, true, false>), jgrid, block, lds, s, a);
-    } else if (env->p.enable_contact) {
-        if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, false, false, false, false, false>), grid, block, lds, s, a);
-        else hipLaunchKernelGGL((physics_ll_kernel<true, false, false, false, false, false, false>), grid, block, lds, s, a);
     } else {
         if (multi) hipLaunchKernelGGL((physics_ll_kernel<false, true, false, false, false, false, false>), grid, block, lds, s, a);
         else hipLaunchKernelGGL((physics_ll_kernel<false, false, false, false, false, false, false>), grid, block, lds, s, a);
