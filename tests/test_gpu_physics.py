@@ -476,9 +476,9 @@ def test_non_uniform_body_shapes_match_oracle():
 
 
 def test_fused_step_equals_staged_step(mlib):
-    """v2p_env_step (pre-physics inside the physics kernel's prologue, compiled with precise semantics there) against pre_physics +
-    physics + post_physics as separate kernels: bit-identical state, observations, rewards and masks over 3 steps; dead envs get
-    their action rows zeroed in place by both."""
+    """v2p_env_step (pre-physics inside the physics kernel's prologue, post-physics in its epilogue, both compiled with precise
+    semantics there) against pre_physics + physics + post_physics as separate kernels: bit-identical state, observations, rewards,
+    masks, times and targets over 3 steps; dead envs get their action rows zeroed in place by both."""
     n = 96
     outs = []
     for fused in (False, True):
@@ -499,7 +499,11 @@ def test_fused_step_equals_staged_step(mlib):
             acts.append(N(a))
         torch.cuda.synchronize()
         outs.append({"acts": np.stack(acts), "pd": N(task._pd_target), "rb": N(task._rigid_body_state), "dof": N(task._dof_state), "obs": N(task.obs_buf),
-                     "rew": N(task.rew_buf), "reset": N(task.reset_buf), "ids": N(task.debug_contacts())})
+                     "rew": N(task.rew_buf), "reset": N(task.reset_buf), "ids": N(task.debug_contacts()),
+                     # post-physics runs in the epilogue of the physics kernel in the fused step, as its own kernel in the staged one
+                     "sub_rewards": N(task._sub_rewards), "terminate": N(task._terminate_buf), "progress": N(task.progress_buf),
+                     "cur_time": N(task._cur_ref_motion_times), "target0": N(task._target_bufs[0]), "target1": N(task._target_bufs[1]),
+                     "target_dof_pos": N(task._target_dof_pos)})
         task.close()
     a, b = outs
     assert (a["acts"][:, ::5] == 0).all() and (a["acts"][:, 1] != 0).any()

@@ -466,10 +466,10 @@ int v2p_env_pre_physics(v2p_env* e, float* actions, void* stream) {
 }
 
 // the physics launch of either schedule, bracketed by events while a measurement is open
-static int physics_launch(v2p_env* e, hipStream_t s, float* actions) {
+static int physics_launch(v2p_env* e, hipStream_t s, float* actions, int* fused_post = nullptr) {
     const bool rec = e->prof_ev && e->prof_n < e->prof_cap;
     if (rec) (void)hipEventRecord(e->prof_ev[2 * e->prof_n], s);
-    int rc = e->schedule != 0 ? launch_env_physics(e, s) : launch_env_physics_ll(e, s, actions);
+    int rc = e->schedule != 0 ? launch_env_physics(e, s) : launch_env_physics_ll(e, s, actions, fused_post);
     if (rec) { (void)hipEventRecord(e->prof_ev[2 * e->prof_n + 1], s); ++e->prof_n; }
     return rc;
 }
@@ -580,8 +580,11 @@ int v2p_env_step(v2p_env* e, float* actions, void* stream) {
     if (e && actions && e->schedule == 0) {
         // link-per-lane schedule: pre-physics runs in the physics kernel's prologue (lane = link owns its joint's action components)
         DeviceGuard g(e->device);
-        int rc = physics_launch(e, (hipStream_t)stream, actions);
-        if (rc == V2P_OK) rc = launch_env_post(e, (hipStream_t)stream);
+        // ... and post-physics in the epilogue of every env's last job, where the kernel instantiation has it (else its own kernel)
+        int fused = 0;
+        int rc = physics_launch(e, (hipStream_t)stream, actions, &fused);
+        if (rc == V2P_OK && fused) e->cur_target = 1 - e->cur_target;
+        else if (rc == V2P_OK) rc = launch_env_post(e, (hipStream_t)stream);
         return rc;
     }
     int rc = v2p_env_pre_physics(e, actions, stream);

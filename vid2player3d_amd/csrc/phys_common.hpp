@@ -30,6 +30,15 @@ struct BallDev {
     float* contact;        // [N,2,3] force on the ball from the racket / from the ground, last substep
 };
 
+// post-physics fused into the physics launch (v2p_env_step, link-per-lane schedule): what env_post_kernel takes
+struct PostArgs {
+    v2p_env_buffers b;
+    v2p_motion_tables t;
+    const int64_t* motion_id;
+    int32_t cur;  // index of the current target buffer
+    int32_t on;   // 1: the job of an env's last substep also runs its post-physics (obs, reward, reset flags, next target)
+};
+
 struct PhysArgs {
     const DevModel* __restrict__ model;
     float* __restrict__ state;
@@ -68,6 +77,7 @@ struct PhysArgs {
     // substep jobs (physics_ll.hip JOBS): workgroups per substep, progress word per wave slot (+1 error word), epoch of this launch
     int32_t job_blocks, job_epoch, job_mono;
     int32_t* job_progress;
+    PostArgs post;
 };
 
 

@@ -48,6 +48,15 @@ namespace v2p {
 namespace strict {
 #pragma clang fp reassociate(off) reciprocal(off) contract(off)
 #include "v2p_math.inc"
+#include "motion_sample.inc"
+#include "post_ops.inc"
+// sum of 24 consecutive floats, ascending (the order env_post_kernel adds the bodies' reward terms in)
+__device__ __forceinline__ float sum_bodies(const float* p) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) s += p[i];
+    return s;
+}
 __device__ __forceinline__ float pd_clamp(float act, float q, float lim) { return fmaxf(fminf(act, q + lim), q - lim); }
 // root_rot: rigid-body rotation of the root (xyzw); a3: the three action components of the force (or torque) part
 __device__ __forceinline__ V3 residual_wrench(const float* root_rot, float a0, float a1, float a2, float scale) {
@@ -206,7 +215,8 @@ constexpr bool PARK3 = V2P_LL_PARK3 != 0;
 #define V2P_LL_DPP_DOWN 0
 #endif
 constexpr int PARK_TAR = 0, PARK_W0 = 3, PARK_XD0 = 6, PARK_Q = 9, PARK_X = 13, PARK_CR = 16, PARK_CB = 28, PARK_CL = 32,
-              PARK_SLOTS = PARK3 ? 44 : 16;  // LDS parking slots (dwords per lane)
+              PARK_SCR = PARK3 ? 44 : 16,  // (one row of 64 dwords per wave: lane of the k-th near link)
+              PARK_SLOTS = PARK_SCR + 1;  // LDS parking slots (dwords per lane)
 constexpr int ROOTLAM_FLOATS = 2 * 24;  // (PARK2) Lambda of the two root links while the contacts are generated
 // ball block (64 floats per env, after the parking area of the wave): state 13 | aero force 3 | ground contact: active gap bias lambda3 |
 // racket point j at BL_RK + 16 j: active gap bias rl3 n3 lambda3
@@ -746,31 +756,33 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
             const unsigned long long nball = __ballot(near);
             LLSUB(16);
             if (nball) {
-                // The hulls of the few links near the ground are scanned by GROUPS of 8 lanes (4 groups per env, 4 near links per
-                // round): lane gl of a group takes vertices gl, gl+8, ... and the group combines with three DPP steps.  Every
-                // selection keeps the serial rule "first index attaining the extreme": per lane indices ascend, across lanes ties
-                // go to the lower index.
+                // The hulls of the few links near the ground are scanned by GROUPS of 8 lanes, 8 groups per wave: in every round group g
+                // takes the next near link of the WAVE (the near links of both envs in lane order), whichever env it belongs to - a
+                // ragdoll with 17 near links that shares its wave with a standing humanoid needs 3 rounds instead of 5.  Lane gl of a
+                // group takes vertices gl, gl+8, ... and the group combines with three DPP steps.  Every selection keeps the serial rule
+                // "first index attaining the extreme": per lane indices ascend, across lanes ties go to the lower index; which group
+                // scans a link changes nothing in its numbers.
                 const unsigned nm = half ? (unsigned)(nball >> 32) : (unsigned)nball;
                 const int nr0 = __popc((unsigned)nball), nr1 = __popc((unsigned)(nball >> 32));
-                const int rounds = ((nr0 > nr1 ? nr0 : nr1) + 3) >> 2;
-                const int myidx = __popc(nm & ((1u << lb) - 1u));  // rank of this link among the near links of its env
-                const int grp = lb >> 3, gl = lb & 7;
-                unsigned remn = nm;
+                const int ntot = nr0 + nr1;
+                const int rounds = (ntot + 7) >> 3;
+                const int myk = (half ? nr0 : 0) + __popc(nm & ((1u << lb) - 1u));  // rank of this link among the near links of the wave
+                const int grp = lane >> 3, gl = lane & 7;
+                int* const scr = (int*)(park_all + (threadIdx.x >> 6) * LDS_FLOATS_PER_WAVE + PARK_SCR * 64);  // k-th near link -> its lane
+                if (near) scr[myk] = lane;
                 if (DIAG && a.prof && ((a.prof_heavy ? blockIdx.x < 8u : (blockIdx.x & 63) == 0)) && lane == 0) atomicAdd((unsigned long long*)&a.prof[13], (unsigned long long)rounds);
                 for (int rd = 0; rd < rounds; ++rd) {
-                    unsigned cb = remn;
-                    if (grp >= 1) cb &= cb - 1;
-                    if (grp >= 2) cb &= cb - 1;
-                    if (grp >= 3) cb &= cb - 1;
-                    const bool gon = cb != 0u;
-                    const int L = gon ? __ffs(cb) - 1 : 0;
-                    remn &= remn - 1; remn &= remn - 1; remn &= remn - 1; remn &= remn - 1;
-                    const int src = base + L;
+                    const int kk = 8 * rd + grp;
+                    const bool gon = kk < ntot;
+                    const int src = gon ? scr[kk] : lane;
                     // the group works in the frame of ITS link: pose pulled from the owner lane (7 values instead of 12)
                     const M3 RL = q2mat(pull(q, src));
                     const V3 xL = pull(x, src);
                     const float r6 = RL.m[6], r7 = RL.m[7], r8 = RL.m[8], xz = xL.z;
                     const int v0L = __builtin_amdgcn_ds_bpermute(src << 2, v0), nvL = __builtin_amdgcn_ds_bpermute(src << 2, nv);
+                    // (per-env shapes: the link may belong to the other env of the wave)
+                    ConstShape* const SL = MULTI ? (ConstShape*)(a.shapes + __builtin_amdgcn_ds_bpermute(src << 2, sid)) : S;
+                    auto hullv = [&](int idx) -> float4 { return make_float4(SL->hull_verts[idx][0], SL->hull_verts[idx][1], SL->hull_verts[idx][2], 0.f); };
                     // ---- one pass over the hull: 8 vertices per lane (all loads in flight at once), ground-plane coordinates kept
                     // for the manifold reduction; candidates (z < contact_offset) as a bit mask, deepest one tracked
                     const float r0 = RL.m[0], r1 = RL.m[1], r2 = RL.m[2], xx = xL.x;
@@ -862,8 +874,8 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                         }
                     }
                     const int gpack = (s0 & 0x7f) | ((s1 & 0x7f) << 7) | ((s2 & 0x7f) << 14) | ((s3 & 0x7f) << 21) | (ns << 28);
-                    const int got = __builtin_amdgcn_ds_bpermute((base + ((myidx & 3) << 3)) << 2, gpack);
-                    pack = (near && (myidx >> 2) == rd) ? got : pack;
+                    const int got = __builtin_amdgcn_ds_bpermute(((myk & 7) << 3) << 2, gpack);
+                    pack = (near && (myk >> 3) == rd) ? got : pack;
                 }
             }
             LLSUB(17);
@@ -1518,6 +1530,7 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
         timeline();
         return;
     }
+    V3 qe{0.f, 0.f, 0.f};  // exposed dof position of this lane's joint
     if (valid && live_env) {
         if (b == 0) {
             st[SIDX(ST_ROOT_QUAT + 0)] = q.x; st[SIDX(ST_ROOT_QUAT + 1)] = q.y; st[SIDX(ST_ROOT_QUAT + 2)] = q.z; st[SIDX(ST_ROOT_QUAT + 3)] = q.w;
@@ -1529,7 +1542,7 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
             st[SIDX(jb + 0)] = jq.x; st[SIDX(jb + 1)] = jq.y; st[SIDX(jb + 2)] = jq.z; st[SIDX(jb + 3)] = jq.w;
             st[SIDX(vb + 0)] = wt.x; st[SIDX(vb + 1)] = wt.y; st[SIDX(vb + 2)] = wt.z;
             // exposed dof state: (exp-map position, joint rate) interleaved like gym's dof state tensor
-            V3 qe = quat_to_expmap_stable(jq);
+            qe = quat_to_expmap_stable(jq);
             float* od = a.x_dof + (e * NDOF + 3 * (b - 1)) * 2;
             od[0] = qe.x; od[1] = wt.x; od[2] = qe.y; od[3] = wt.y; od[4] = qe.z; od[5] = wt.z;
         }
@@ -1574,6 +1587,33 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                 const int j = lb + 32 * r;
                 if (j < NB * 13 / 4) dst[j] = src[j];
             }
+        }
+    }
+    if constexpr (JOBS && !BALL && !LIMITS && !TGS && !DIAG) {
+        // ---- post-physics fused in (v2p_env_step): the same functions, compiled with the same semantics, as env_post_kernel; lane = body
+        // holds exactly the values the exposed tensors were just given.  The post-physics kernel cost a launch of its own right behind
+        // the tail of this one (the heaviest env pairs finish last, on an almost empty GPU); here every pair does it as it finishes.
+        if (a.post.on) {
+            const PostArgs& Z = a.post;
+            bool fl = false;
+            int64_t mid = 0;
+            float t_new = 0.f;
+            strict::RewardPartial rp{0.f, 0.f, 0.f, 0.f};
+            if (valid && live_env) {
+                mid = Z.motion_id[e];
+                t_new = Z.b.cur_time[e] + P.dt;  // _cur_ref_motion_times += dt
+                rp = strict::post_body(Z.b, Z.t, P, mid, t_new, Z.cur, e, b, strict::V3{x.x, x.y, x.z}, strict::Q4{q.x, q.y, q.z, q.w}, strict::V3{xd.x, xd.y, xd.z},
+                                       strict::V3{w.x, w.y, w.z}, strict::V3{qe.x, qe.y, qe.z}, strict::V3{wt.x, wt.y, wt.z}, fl);
+            }
+            // reward sums over the bodies, bodies ascending like env_post_kernel: the terms go through this lane's LDS column (the parking
+            // area is idle by now; a wave's LDS accesses execute in order), lanes 0..3 of each env add one term each
+            park[0] = rp.dof; park[64] = rp.vel; park[128] = rp.pos; park[192] = rp.rot;
+            const unsigned long long fb = __ballot(fl);
+            const bool fell = (half ? (unsigned)(fb >> 32) : (unsigned)fb) != 0u;
+            float sk = 0.f;
+            if (lb < 4) sk = strict::sum_bodies(park_all + (threadIdx.x >> 6) * LDS_FLOATS_PER_WAVE + lb * 64 + base);
+            const float s4[4] = {pull(sk, base), pull(sk, base + 1), pull(sk, base + 2), pull(sk, base + 3)};
+            if (lb == 0 && live_env) strict::post_env(Z.b, Z.t, P, mid, t_new, e, s4, fell);
         }
     }
     }
@@ -1648,7 +1688,8 @@ int launch_env_pairing(v2p_env* env, hipStream_t s) {
     return check_hip(hipGetLastError(), "pair_scatter_kernel");
 }
 
-int launch_env_physics_ll(v2p_env* env, hipStream_t s, float* actions) {
+int launch_env_physics_ll(v2p_env* env, hipStream_t s, float* actions, int* fused_post) {
+    if (fused_post) *fused_post = 0;
     const bool paired = env_pairing_on(env);
     if (paired && env->pair_have) {  // pre-physics has not consumed the last launch's keys
         int rc = launch_env_pairing(env, s);
@@ -1742,6 +1783,14 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s, float* actions) {
             a.job_mono = (int)(blocks * (unsigned)env->job_mono_permille / 1000u);
         }
         const dim3 jgrid((unsigned)a.job_mono + (blocks - (unsigned)a.job_mono) * (unsigned)env->p.nsub);
+        if (fused_post && actions && env->mlib) {  // v2p_env_step: post-physics runs in the epilogue of every env's last job
+            a.post.b = env->buf;
+            a.post.t = env->mlib->t;
+            a.post.motion_id = env->motion_id;
+            a.post.cur = env->cur_target;
+            a.post.on = 1;
+            *fused_post = 1;
+        }
         if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, false, false, false, true, false>), jgrid, block, lds, s, a);
         else hipLaunchKernelGGL((physics_ll_kernel<true, false, false, false, false, true, false>), jgrid, block, lds, s, a);
     } else {

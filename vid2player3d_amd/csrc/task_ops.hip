@@ -433,6 +433,7 @@ __global__ __launch_bounds__(EB_BLOCK) void env_post_kernel(EnvView v) {
     float t_new = 0.f;
     int64_t mid = 0;
     if (live && j == 0 && v.pair.perm) pair_scatter(v.pair, e);  // wave order of the next physics launch (see physics_ll.hip)
+    bool fl = false;
     if (live) {
         mid = v.motion_id[e];
         t_new = v.b.cur_time[e] + v.p.dt;  // _cur_ref_motion_times += dt
@@ -446,16 +447,8 @@ __global__ __launch_bounds__(EB_BLOCK) void env_post_kernel(EnvView v) {
             dpos = V3{d[0], d[2], d[4]};
             dvel = V3{d[1], d[3], d[5]};
         }
-        write_obs(v, e, j, pos, rot, vel, ang, dpos, dvel);
-        // reward against the PREVIOUS target = the target that was current during this step (:677-680)
-        const float* tg = v.b.target[v.cur] + e * MSD;
-        V3 z{0.f, 0.f, 0.f};
-        r = reward_partial(j, pos, rot, ld3(tg + MS_RB_POS + 3 * j), ld4(tg + MS_RB_ROT + 4 * j), dpos, dvel,
-                           j ? ld3(tg + MS_DOF_POS + 3 * (j - 1)) : z, j ? ld3(tg + MS_DOF_VEL + 3 * (j - 1)) : z, v.p.body_pos_weights[j]);
-        if (pos.z < v.p.term_heights[j]) atomicOr(&fell[le], 1);
-        // new target at cur_time + dt (one step ahead), written to the other buffer
-        FrameRef fr = frame_lookup(v.t, mid, t_new + v.p.dt, 1, v.p.ground_tolerance);
-        sample_body(v.t, fr, j, e, packed_out(v.b.target[1 - v.cur]));
+        r = post_body(v.b, v.t, v.p, mid, t_new, v.cur, e, j, pos, rot, vel, ang, dpos, dvel, fl);
+        if (fl) atomicOr(&fell[le], 1);
     }
     red[le][j][0] = r.dof; red[le][j][1] = r.vel; red[le][j][2] = r.pos; red[le][j][3] = r.rot;
     __syncthreads();
@@ -463,22 +456,7 @@ __global__ __launch_bounds__(EB_BLOCK) void env_post_kernel(EnvView v) {
         float s[4] = {0.f, 0.f, 0.f, 0.f};
         for (int b = 0; b < NB; ++b)
             for (int k = 0; k < 4; ++k) s[k] += red[le][b][k];
-        float rw, sb[4];
-        reward_finish(v.p.reward_specs, s[0], s[1], s[2], s[3], rw, sb);
-        int64_t old_reset = v.b.reset[e];
-        int64_t old_term = v.b.terminate[e];
-        if (old_reset == 1) { rw = 0.f; sb[0] = sb[1] = sb[2] = sb[3] = 0.f; }  // :688-691
-        v.b.rew[e] = rw;
-        for (int k = 0; k < 4; ++k) v.b.sub_rewards[e * 4 + k] = sb[k];
-        int64_t prog = v.b.progress[e] + 1;
-        v.b.progress[e] = prog;
-        v.b.cur_time[e] = t_new;
-        int64_t term = (v.p.enable_early_termination && fell[le] && prog > 1) ? 1 : 0;
-        bool cond = ((float)prog >= v.p.max_episode_length - 1.f) || (t_new >= v.t.motion_lengths[mid]);
-        int64_t rst = cond ? 1 : term;
-        if (old_reset == 1) { rst = 1; term = old_term; }  // sticky until the next epoch reset (:735-738)
-        v.b.reset[e] = rst;
-        v.b.terminate[e] = term;
+        post_env(v.b, v.t, v.p, mid, t_new, e, s, fell[le] != 0);
     }
 }
 

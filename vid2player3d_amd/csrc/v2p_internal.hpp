@@ -185,7 +185,8 @@ int launch_gae(int64_t horizon, int64_t n, const float* fdones, const float* val
 int launch_env_reset(v2p_env* e, const int64_t* env_ids, int64_t n, const float* motion_times, hipStream_t s);
 int launch_env_pre(v2p_env* e, float* actions, hipStream_t s);
 int launch_env_physics(v2p_env* e, hipStream_t s);
-int launch_env_physics_ll(v2p_env* e, hipStream_t s, float* actions = nullptr);  // actions: fuse pre-physics into the kernel
+// actions: fuse pre-physics into the kernel; fused_post (with actions): non-null = post-physics may be fused in as well, *fused_post says whether it was
+int launch_env_physics_ll(v2p_env* e, hipStream_t s, float* actions = nullptr, int* fused_post = nullptr);
 bool env_pairing_on(const v2p_env* e);
 struct PairView;
 PairView env_pair_view(const v2p_env* e);
