@@ -1,4 +1,6 @@
 """Helpers shared by the `-m gpu` parity tests."""
+import os
+
 import numpy as np
 import torch
 
@@ -53,4 +55,7 @@ def close(a, b, tol, what=""):
     err = np.abs(a - b).max()
     lim = tol * max(1.0, np.abs(b).max())
     assert np.isfinite(a).all(), what + ": non-finite values"
+    if os.environ.get("V2P_CLOSE_REPORT"):  # A/B of kernel variants: print how much of each tolerance is used instead of asserting
+        print("[close] %-40s err %.3e  limit %.3e  used %.3f" % (what, err, lim, err / lim))
+        return
     assert err <= lim, "%s: max abs err %.3e > %.1e" % (what, err, lim)

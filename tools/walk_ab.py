@@ -1,0 +1,27 @@
+#!/usr/bin/env python
+"""A/B of two builds of the physics kernel on identical inputs: per-env error against the float64 oracle (forced to the kernel's
+contact vertices) after one control step, for standing / fallen / fast fixtures.  usage: python tools/walk_ab.py out.npz"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+import test_gpu_physics as T  # noqa: E402
+from gpu_util import DEV, synth_tables  # noqa: E402
+from vid2player3d_amd.motion_lib import MotionLib  # noqa: E402
+
+mlib = MotionLib(synth_tables(seed=5, num_clips=8, min_frames=60, max_frames=120), DEV)
+out = {}
+for name, kw in (("standing", dict(seed=11, lift=0.0, vel_sigma=0.5)), ("fallen", dict(seed=3, lift=-0.75, vel_sigma=0.2)),
+                 ("fast", dict(seed=13, lift=-0.5, vel_sigma=3.0)), ("low", dict(seed=17, lift=-0.9, vel_sigma=1.0))):
+    (got, ref), = T._run_pair(mlib, 512, contact=True, what=name, **kw)
+    e_dv = np.abs(got["dvel"] - ref["dvel"]).max(axis=1)
+    e_rv = np.abs(got["rb"][..., 7:] - ref["rb"][..., 7:]).reshape(512, -1).max(axis=1)
+    touched = (got["ids"] >= 0).any(axis=2).sum(axis=1)
+    out[name + "_dvel"] = got["dvel"]; out[name + "_edv"] = e_dv; out[name + "_erv"] = e_rv; out[name + "_touched"] = touched
+    print("%-9s touched mean %.1f max %d | dof-vel err vs oracle: median %.2e p90 %.2e p99 %.2e max %.2e | rb-vel err: median %.2e p99 %.2e max %.2e"
+          % (name, touched.mean(), touched.max(), np.median(e_dv), np.percentile(e_dv, 90), np.percentile(e_dv, 99), e_dv.max(), np.median(e_rv),
+             np.percentile(e_rv, 99), e_rv.max()))
+np.savez(sys.argv[1], **out)

@@ -211,6 +211,9 @@ constexpr bool PARK3 = V2P_LL_PARK3 != 0;
 #ifndef V2P_LL_PREFETCH_ROWS
 #define V2P_LL_PREFETCH_ROWS 1
 #endif
+#ifndef V2P_LL_WALK
+#define V2P_LL_WALK 1  // 0: the sweep with a leaf -> root -> leaves propagation after every touched group (A/B; the ball / joint-limit kernels use it)
+#endif
 #ifndef V2P_LL_DPP_DOWN
 #define V2P_LL_DPP_DOWN 0
 #endif
@@ -269,6 +272,7 @@ struct ContactStore<true> {
 // inverse inertia K = Di + ((T - 1)^T G (T - 1))_ww = Lambda_b,ww - H1 - H1^T + Lambda_parent,ww in the notation of the recursion below.
 template <bool CONTACT, bool MULTI, bool TGS, bool DIAG, bool BALL, bool JOBS, bool LIMITS>
 __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_WPS) void physics_ll_kernel(PhysArgs a) {
+    constexpr bool WALK = V2P_LL_WALK && !BALL && !LIMITS;  // the sweep as one walk over the tree (see the sweep)
     const int64_t N = a.n;
     const int lane = threadIdx.x & 63;
     const int half = lane >> 5;
@@ -1068,6 +1072,234 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                 float tgs_irem = 1.f / h;                // TGS: 1 / (time left in the substep) for separated points
                 const float tgs_pen = P.erp / hs;
                 auto rowbias = [&](float v) -> float { return TGS ? (v >= 0.f ? v * tgs_irem : fmaxf(tgs_pen * v, -P.max_depen)) : v; };
+                if constexpr (WALK) {
+                // ---- the sweep as ONE WALK over the tree.  Solving the touched links one by one in ascending order, iteration after
+                // iteration, visits them in depth-first order, cyclically; between two of them only the links on the tree path
+                // cur -> LCA -> next need anything:
+                //   up    cur .. LCA: every link hands what its subtree has collected since it last did so (un_new, uf_new) to its parent,
+                //         and the LCA answers what arrives with its own Lambda (Lambda_cc is the response of the whole system at c);
+                //   down  LCA .. next: velocity change of a link = its parent's, carried over the joint, + the joint's answer to everything
+                //         its subtree has collected so far (un_tot) - the relation the root -> leaves pass uses, valid here because a
+                //         depth-first walk enters a subtree only after everything applied inside it has been handed up through its root.
+                // (Dw, Dv) of a link = its velocity change since the start of the sweep, valid whenever the walk stands on it; w, xd keep
+                // the velocities of the start of the sweep.  After the last iteration the walk returns to the root and ONE root -> leaves
+                // pass moves every link.  By linearity the row updates see exactly the velocities of the one-by-one sweep with a
+                // leaf -> root -> leaves propagation after every link; that costs (touched groups x 2 x depth) level steps per iteration,
+                // the walk 2 x (edges of the subtree the touched links span): the same for two feet on the ground, about half for a
+                // fallen humanoid with 7 scattered touched links - the critical path of a launch.
+                // TGS advances the gaps with the velocities after every iteration: there the walk is closed after every iteration.
+                V3 un_tot{0.f, 0.f, 0.f}, un_new{0.f, 0.f, 0.f}, uf_new{0.f, 0.f, 0.f}, Dw{0.f, 0.f, 0.f}, Dv{0.f, 0.f, 0.f};
+                int cur0 = 0, cur1 = 0;            // link the walk of each env stands on
+                bool live0 = false, live1 = false;  // the env has applied an impulse (until then all its changes are zero and its walk rests)
+                // the move INTO each touched link, from the touched link before it (cyclically): depth of their lowest common ancestor |
+                // depth of the link before << 4 | own depth << 8.  (A link has depth + 1 ancestors-or-self: depths from ballots.)
+                int minfo = 0;
+                {
+                    int p0 = m0 ? 31 - __clz(m0) : 0, p1 = m1 ? 31 - __clz(m1) : 0;
+                    for (unsigned s0 = m0, s1 = m1; s0 | s1; s0 &= s0 - 1, s1 &= s1 - 1) {
+                        const int b0 = s0 ? __ffs(s0) - 1 : p0, b1 = s1 ? __ffs(s1) - 1 : p1;
+                        const int selp = half ? p1 : p0, selb = half ? b1 : b0;
+                        const bool ap = valid && ((desc >> selp) & 1), ab = valid && ((desc >> selb) & 1);
+                        const unsigned long long bp = __ballot(ap), bb = __ballot(ab), bc = __ballot(ap && ab);
+                        const int du = __popc(half ? (unsigned)(bp >> 32) : (unsigned)bp) - 1, dn = __popc(half ? (unsigned)(bb >> 32) : (unsigned)bb) - 1,
+                                  dl = __popc(half ? (unsigned)(bc >> 32) : (unsigned)bc) - 1;
+                        if (valid && lb == selb && ((half ? s1 : s0) != 0u)) minfo = dl | (du << 4) | (dn << 8);
+                        p0 = b0;
+                        p1 = b1;
+                    }
+                }
+                // one move of both walks: env h goes from cur_h to its next link when mv_h (info_h = the move, see minfo), else it rests
+                auto walk_to = [&](int nx0, int nx1, int info0, int info1, bool mv0, bool mv1) {
+                    long long tsub = DIAG && a.prof ? clock64() : 0;
+                    // a resting env: empty ranges that do not widen the loops (LCA depth 15, depths 0)
+                    // (readfirstlane: the compiler must see wave-uniform loop bounds, or it runs the level loops with per-lane exits)
+                    const int pk0 = __builtin_amdgcn_readfirstlane(mv0 ? info0 : 0x00f), pk1 = __builtin_amdgcn_readfirstlane(mv1 ? info1 : 0x00f);
+                    const int du0 = (pk0 >> 4) & 15, dl0 = pk0 & 15, dn0 = (pk0 >> 8) & 15;
+                    const int du1 = (pk1 >> 4) & 15, dl1 = pk1 & 15, dn1 = (pk1 >> 8) & 15;
+                    const int selc = half ? cur1 : cur0, seln = half ? nx1 : nx0, mydl = half ? dl1 : dl0;
+                    const bool onc = valid && ((desc >> selc) & 1), onn = valid && ((desc >> seln) & 1);  // ancestors (or self) of cur / of next
+                    // depth of this lane's link if it is on the way up (cur .. LCA + 1) / on the way down (LCA + 1 .. next), else -1
+                    const int updep = (onc && dep > mydl) ? dep : -1, dndep = (onn && dep > mydl) ? dep : -1;
+                    const int turndep = (onc && dep == mydl) ? dep : -2;  // the LCA itself: where this env's move turns
+                    const int dlmin = dl0 < dl1 ? dl0 : dl1;
+                    // ---- up
+                    for (int d = du0 > du1 ? du0 : du1; d > dlmin; --d) {
+                        // (levels in a gap between the two envs' ranges run idle: a range test here makes the compiler run the whole loop
+                        // with per-lane exits and d in a VGPR)
+                        V3 cn{0.f, 0.f, 0.f}, cf{0.f, 0.f, 0.f};
+                        if (updep == d) {
+                            const V3 na = aug * mul(Di, un_new);
+                            const V3 fa = uf_new - V3{dot(col(E, 0), un_new), dot(col(E, 1), un_new), dot(col(E, 2), un_new)};
+                            cn = na + cross(r, fa);
+                            cf = fa;
+                            un_new = V3{0.f, 0.f, 0.f};
+                            uf_new = V3{0.f, 0.f, 0.f};
+                        }
+                        const bool side = ((multi >> d) & 1) && any64(updep == d && !firstchild);  // a path enters its parent through child 1 or 2
+                        if (d - 1 == dl0 || d - 1 == dl1 || side) {
+                            // a level where a walk turns (or a side entry): what arrives is kept apart, the LCA answers it with its Lambda
+                            V3 rn, rf;
+                            if ((nonchain >> d) & 1) {
+                                rn = mask(has0, from_next(cn));
+                                rf = mask(has0, from_next(cf));
+                            } else {
+                                rn = from_next(cn);
+                                rf = from_next(cf);
+                            }
+                            if (side) {
+                                rn = rn + mask(has1, pull(cn, cl1)) + mask(has2, pull(cn, cl2));
+                                rf = rf + mask(has1, pull(cf, cl1)) + mask(has2, pull(cf, cl2));
+                            }
+                            un_new = un_new + rn;
+                            uf_new = uf_new + rf;
+                            un_tot = un_tot + rn;
+                            if (turndep == d - 1) {
+                                Dw = Dw + mul(Lam.A, rn) + mul(Lam.B, rf);
+                                Dv = Dv + V3{dot(col(Lam.B, 0), rn), dot(col(Lam.B, 1), rn), dot(col(Lam.B, 2), rn)} + mul(Lam.C, rf);
+                            }
+                        } else if ((nonchain >> d) & 1) {
+                            const V3 rn = mask(has0, from_next(cn));
+                            un_new = un_new + rn;
+                            uf_new = uf_new + mask(has0, from_next(cf));
+                            un_tot = un_tot + rn;
+                        } else {
+                            // every link of this level directly follows its parent: the shifted values are added unmasked (DPP operand of the add)
+                            un_new = un_new + from_next(cn);
+                            uf_new = uf_new + from_next(cf);
+                            un_tot = un_tot + from_next(cn);
+                        }
+                    }
+                    LLSUB(12);
+                    // ---- down
+                    const int dtop = dn0 > dn1 ? dn0 : dn1;
+                    for (int d = dlmin + 1; d <= dtop; ++d) {
+                        if (!(((d > dl0) & (d <= dn0)) | ((d > dl1) & (d <= dn1)))) continue;
+                        const bool nc = (nonchain >> d) & 1;
+                        const V3 pdw = pp(Dw, nc), pdv = pp(Dv, nc);
+                        if (dndep == d) {
+                            const V3 tv = pdv + cross(pdw, r);
+                            Dw = mul(Di, aug * pdw + un_tot) - mul(E, tv);
+                            Dv = tv;
+                        }
+                    }
+                    LLSUB(14);
+                };
+                // the walk returns to the root (its Lambda answers the total) and one root -> leaves pass moves the links down to depth dlast
+                auto walk_close = [&](int dlast) {
+                    const int i0 = (int)__builtin_amdgcn_readlane(dep, cur0) << 4, i1 = (int)__builtin_amdgcn_readlane(dep, 32 + cur1) << 4;
+                    const int slive = __builtin_amdgcn_readfirstlane((live0 ? 1 : 0) | (live1 ? 2 : 0));
+                    walk_to(0, 0, i0, i1, (slive & 1) != 0, (slive & 2) != 0);
+                    long long tsub = DIAG && a.prof ? clock64() : 0;
+                    V3 ddw{0.f, 0.f, 0.f}, ddv{0.f, 0.f, 0.f};
+                    if (lb == 0) {
+                        ddw = Dw;
+                        ddv = Dv;
+                        w = w + ddw;
+                        xd = xd + ddv;
+                    }
+                    for (int d = 1; d <= dlast; ++d) {
+                        const bool nc = (nonchain >> d) & 1;
+                        const V3 pdw = pp(ddw, nc), pdv = pp(ddv, nc);
+                        if (dep == d) {
+                            const V3 av = pdv + cross(pdw, r);
+                            ddw = mul(Di, aug * pdw + un_tot) - mul(E, av);
+                            ddv = av;
+                            w = w + ddw;
+                            xd = xd + ddv;
+                        }
+                    }
+                    LLSUB(14);
+                };
+                for (int it = 0; it < P.n_iter; ++it) {
+                    unsigned t0 = m0, t1 = m1;
+                    bool moved = false;
+                    if (TGS && it > 0) {
+                        // gaps advance with the normal velocity the points have after the previous sweep (touched links are current)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) { const V3 rc = CS.cr(c); CS.set_bias(c, CS.bias(c) + hs * (rc.y * w.x - rc.x * w.y + xd.z)); }
+                        tgs_irem = 1.f / (h - (float)it * hs);
+                    }
+                    while (t0 | t1) {
+                        const int b0 = t0 ? __ffs(t0) - 1 : -1, b1 = t1 ? __ffs(t1) - 1 : -1;
+                        t0 &= t0 - 1;
+                        t1 &= t1 - 1;
+                        if (DIAG && a.prof && ((a.prof_heavy ? blockIdx.x < 8u : (blockIdx.x & 63) == 0)) && lane == 0) atomicAdd((unsigned long long*)&a.prof[8], 1ull);
+                        // (readfirstlane: wave-uniform by construction, and the compiler must know it - the level loops are scalar loops)
+                        const int smv = __builtin_amdgcn_readfirstlane(((live0 && b0 >= 0 && b0 != cur0) ? 1 : 0) | ((live1 && b1 >= 0 && b1 != cur1) ? 2 : 0));
+                        if (smv) {
+                            const int i0 = __builtin_amdgcn_readlane(minfo, b0 < 0 ? 0 : b0), i1 = __builtin_amdgcn_readlane(minfo, 32 + (b1 < 0 ? 0 : b1));
+                            walk_to(b0 < 0 ? 0 : b0, b1 < 0 ? 0 : b1, i0, i1, (smv & 1) != 0, (smv & 2) != 0);
+                        }
+                        if (b0 >= 0) cur0 = b0;
+                        if (b1 >= 0) cur1 = b1;
+                        // ---- the rows of the link the walk stands on
+                        long long tsub = DIAG && a.prof ? clock64() : 0;
+                        const int bsel = half ? b1 : b0;
+                        const bool me = valid && lb == bsel;
+                        V3 gn{0.f, 0.f, 0.f}, gf{0.f, 0.f, 0.f};  // what these rows add to the link's impulse
+                        if (me) {
+                            V3 wl = w + Dw, xl = xd + Dv;
+                            // all four records of the link at once (one LDS round trip instead of one per point; unused slots hold zeros)
+                            V3 rr4[4], lam4[4];
+                            float bias4[4];
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) { rr4[c] = CS.cr(c); lam4[c] = CS.lam(c); bias4[c] = CS.bias(c); }
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const bool active = c < cnt;
+                                if (!any64(active)) break;  // uniform over the (at most two) touched links solved here
+                                const V3 rr = rr4[c];
+                                const V3 lam0 = lam4[c];
+                                float ln = lam0.x, l1 = lam0.y, l2 = lam0.z;
+                                // a point without normal impulse (hence without friction impulses: they are clamped to mu x normal)
+                                // that is separating stays as it is: its three rows would change nothing
+                                // (masked per lane as well, so that an env's numbers do not depend on what its wave partner does)
+                                const float bias_c = rowbias(bias4[c]);
+                                const bool act = active && !(ln == 0.f && rr.y * wl.x - rr.x * wl.y + xl.z + bias_c >= 0.f);
+                                if (!any64(act)) continue;
+#pragma unroll
+                                for (int ax = 0; ax < 3; ++ax) {
+                                    const V3 dir = ax == 0 ? V3{0.f, 0.f, 1.f} : (ax == 1 ? V3{1.f, 0.f, 0.f} : V3{0.f, 1.f, 0.f});
+                                    const V3 jn = cross(rr, dir);
+                                    const V3 yw = mul(Lam.A, jn) + mul(Lam.B, dir);
+                                    const V3 yv = V3{dot(col(Lam.B, 0), jn), dot(col(Lam.B, 1), jn), dot(col(Lam.B, 2), jn)} + mul(Lam.C, dir);
+                                    const float wii = dot(jn, yw) + dot(dir, yv);
+                                    const float rel = dot(jn, wl) + dot(dir, xl) + (ax == 0 ? bias_c : 0.f);
+                                    const float old = ax == 0 ? ln : (ax == 1 ? l1 : l2);
+                                    float nl = old - rel * __builtin_amdgcn_rcpf(wii);
+                                    if (ax == 0) nl = fmaxf(nl, 0.f);
+                                    else { const float lim = P.mu * ln; nl = fminf(fmaxf(nl, -lim), lim); }
+                                    const float dl = act ? nl - old : 0.f;
+                                    if (ax == 0) ln += dl; else if (ax == 1) l1 += dl; else l2 += dl;
+                                    wl = wl + dl * yw;
+                                    xl = xl + dl * yv;
+                                    gn = gn + dl * jn;
+                                    gf = gf + dl * dir;
+                                }
+                                CS.set_lam(c, V3{ln, l1, l2});
+                            }
+                            Dw = wl - w;
+                            Dv = xl - xd;
+                            un_tot = un_tot + gn;
+                            un_new = un_new + gn;
+                            uf_new = uf_new + gf;
+                        }
+                        const unsigned long long chg = __ballot(gn.x != 0.f || gn.y != 0.f || gn.z != 0.f || gf.x != 0.f || gf.y != 0.f || gf.z != 0.f);
+                        live0 = live0 || (unsigned)chg != 0u;
+                        live1 = live1 || (unsigned)(chg >> 32) != 0u;
+                        moved = moved || chg != 0ull;
+                        if (DIAG && a.prof && !chg && ((a.prof_heavy ? blockIdx.x < 8u : (blockIdx.x & 63) == 0)) && lane == 0) atomicAdd((unsigned long long*)&a.prof[19], 1ull);
+                        LLSUB(11);
+                    }
+                    if (TGS && (live0 || live1)) {
+                        walk_close(maxd);
+                        un_tot = un_new = uf_new = Dw = Dv = V3{0.f, 0.f, 0.f};
+                        live0 = live1 = false;
+                    }
+                    if (!TGS && !moved) break;  // a whole iteration without any change: the remaining ones would repeat it (PGS: fixed biases)
+                }
+                if (!TGS && (live0 || live1)) walk_close(maxd);
+                } else
                 for (int it = 0; it < P.n_iter; ++it) {
                     unsigned t0 = m0, t1 = m1, l0 = lm0, l1 = lm1;
                     bool moved = false;
@@ -1323,8 +1555,9 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                     if (!TGS && !moved) break;  // a whole iteration without any change: the remaining ones would repeat it (PGS: fixed biases)
                 }
                 // links below the deepest touched one: one catch-up pass with the accumulated motion of their parents
+                // (the walk moves every link when it closes)
                 V3 accw = w - park_get3(PARK_W0), accv = xd - park_get3(PARK_XD0);
-                for (int d = dmin + 1; d <= maxd; ++d) {
+                for (int d = dmin + 1; d <= (WALK ? 0 : maxd); ++d) {
                     const bool nc = (nonchain >> d) & 1;
                     V3 pdw = pp(accw, nc), pdv = pp(accv, nc);
                     if (dep == d && !insweep) {
