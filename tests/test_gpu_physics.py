@@ -243,10 +243,13 @@ def _epoch_against_oracles(lib, tabs, n, steps, seed, sigma, **env):
         ref.set_sim_state(res["dpos"].astype(np.float32), res["dvel"].astype(np.float32), res["rb"].astype(np.float32))
         ref.post_physics_step()
         rb = N(task._rigid_body_state).reshape(n, 24, 13)
-        # (one-step tolerances widened x2..x5 here: the flailing ragdolls of this fixture reach joint rates of tens of rad/s)
+        # (one-step tolerances widened x3..x5 here: the flailing ragdolls of this fixture reach joint rates of tens of rad/s, and a row
+        # of the sweep that sits on its clamp in float32 and just off it in float64 is a difference of this size in one env; over 2048
+        # envs of tools/walk_ab.py two equivalent float32 orderings of the sweep differ from the oracle by up to 5e-3 rad/s in single envs
+        # with medians of 1e-5, profiles/r02c_walk_ab.log)
         close(rb[..., :3], res["rb"][..., :3], 1e-4, "rb pos, step %d" % k)
-        close(rb[..., 7:], res["rb"][..., 7:], 2 * TOL_VEL, "rb vel, step %d" % k)
-        close(N(task._dof_vel), res["dvel"], 2 * TOL_VEL, "dof vel, step %d" % k)
+        close(rb[..., 7:], res["rb"][..., 7:], 3 * TOL_VEL, "rb vel, step %d" % k)
+        close(N(task._dof_vel), res["dvel"], 3 * TOL_VEL, "dof vel, step %d" % k)
         assert np.array_equal(N(task.progress_buf), ref.progress_buf), "progress, step %d" % k
         assert np.array_equal(N(task.reset_buf), ref.reset_buf), "reset flags, step %d: %d differ" % (k, (N(task.reset_buf) != ref.reset_buf).sum())
         assert np.array_equal(N(task._terminate_buf), ref.terminate_buf), "terminate flags, step %d" % k

@@ -160,6 +160,8 @@ int v2p_model_create(const v2p_model_desc* d, int device, v2p_model** out) {
             if (h.children[p][0] != p + 1) { set_error("v2p_model_create: links must be in depth-first order (first child of %d is %d)", p, h.children[p][0]); delete m; return V2P_ERR_UNSUPPORTED; }
         }
     }
+    h.side_depths[0] = 0;
+    for (int b = 1; b < NB; ++b) h.side_depths[b] = h.side_depths[h.parents[b]] | ((h.parents[b] != b - 1) ? 1 << h.depth[b] : 0);
     for (int b = 0; b < NB; ++b) {
         h.desc_mask[b] = 0;
         for (int j = 0; j < NB; ++j)

@@ -1092,7 +1092,7 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                 int cur0 = 0, cur1 = 0;            // link the walk of each env stands on
                 bool live0 = false, live1 = false;  // the env has applied an impulse (until then all its changes are zero and its walk rests)
                 // the move INTO each touched link, from the touched link before it (cyclically): depth of their lowest common ancestor |
-                // depth of the link before << 4 | own depth << 8.  (A link has depth + 1 ancestors-or-self: depths from ballots.)
+                // depth of the link before << 4 | own depth << 8 | side-entry levels << 12.  (A link has depth + 1 ancestors-or-self: depths from ballots.)
                 int minfo = 0;
                 {
                     int p0 = m0 ? 31 - __clz(m0) : 0, p1 = m1 ? 31 - __clz(m1) : 0;
@@ -1103,7 +1103,9 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                         const unsigned long long bp = __ballot(ap), bb = __ballot(ab), bc = __ballot(ap && ab);
                         const int du = __popc(half ? (unsigned)(bp >> 32) : (unsigned)bp) - 1, dn = __popc(half ? (unsigned)(bb >> 32) : (unsigned)bb) - 1,
                                   dl = __popc(half ? (unsigned)(bc >> 32) : (unsigned)bc) - 1;
-                        if (valid && lb == selb && ((half ? s1 : s0) != 0u)) minfo = dl | (du << 4) | (dn << 8);
+                        // (levels of the way up where the path link is not its parent's first child: it hands over through a pull, see walk_to)
+                        const int sd = (half ? M.side_depths[p1] : M.side_depths[p0]) & ~((2 << dl) - 1);
+                        if (valid && lb == selb && ((half ? s1 : s0) != 0u)) minfo = dl | (du << 4) | (dn << 8) | (sd << 12);
                         p0 = b0;
                         p1 = b1;
                     }
@@ -1122,10 +1124,13 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                     const int updep = (onc && dep > mydl) ? dep : -1, dndep = (onn && dep > mydl) ? dep : -1;
                     const int turndep = (onc && dep == mydl) ? dep : -2;  // the LCA itself: where this env's move turns
                     const int dlmin = dl0 < dl1 ? dl0 : dl1;
-                    // ---- up
+                    // levels (bit d = the links at depth d hand over) that need the long form: a walk turns at their parent, or a path link
+                    // is not the first child of its parent (it does not sit in the lane next to it)
+                    const unsigned sideb = (unsigned)(pk0 >> 12) | (unsigned)(pk1 >> 12);
+                    const unsigned longb = sideb | (dl0 < 15 ? 2u << dl0 : 0u) | (dl1 < 15 ? 2u << dl1 : 0u);
+                    // ---- up  (levels in a gap between the two envs' ranges run idle: a range test here makes the compiler run the whole
+                    // loop with per-lane exits and d in a VGPR)
                     for (int d = du0 > du1 ? du0 : du1; d > dlmin; --d) {
-                        // (levels in a gap between the two envs' ranges run idle: a range test here makes the compiler run the whole loop
-                        // with per-lane exits and d in a VGPR)
                         V3 cn{0.f, 0.f, 0.f}, cf{0.f, 0.f, 0.f};
                         if (updep == d) {
                             const V3 na = aug * mul(Di, un_new);
@@ -1135,18 +1140,16 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                             un_new = V3{0.f, 0.f, 0.f};
                             uf_new = V3{0.f, 0.f, 0.f};
                         }
-                        const bool side = ((multi >> d) & 1) && any64(updep == d && !firstchild);  // a path enters its parent through child 1 or 2
-                        if (d - 1 == dl0 || d - 1 == dl1 || side) {
-                            // a level where a walk turns (or a side entry): what arrives is kept apart, the LCA answers it with its Lambda
-                            V3 rn, rf;
-                            if ((nonchain >> d) & 1) {
-                                rn = mask(has0, from_next(cn));
-                                rf = mask(has0, from_next(cf));
-                            } else {
-                                rn = from_next(cn);
-                                rf = from_next(cf);
-                            }
-                            if (side) {
+                        if (!((longb >> d) & 1u)) {
+                            // every link that hands over is the first child of its parent = the lane before it; the others hand over zeros:
+                            // the shifted values are added as they are (DPP operand of the add)
+                            un_new = un_new + from_next(cn);
+                            uf_new = uf_new + from_next(cf);
+                            un_tot = un_tot + from_next(cn);
+                        } else {
+                            // what arrives is kept apart: the link where a walk turns answers it with its Lambda
+                            V3 rn = from_next(mask(firstchild, cn)), rf = from_next(mask(firstchild, cf));
+                            if ((sideb >> d) & 1u) {
                                 rn = rn + mask(has1, pull(cn, cl1)) + mask(has2, pull(cn, cl2));
                                 rf = rf + mask(has1, pull(cf, cl1)) + mask(has2, pull(cf, cl2));
                             }
@@ -1157,23 +1160,12 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                                 Dw = Dw + mul(Lam.A, rn) + mul(Lam.B, rf);
                                 Dv = Dv + V3{dot(col(Lam.B, 0), rn), dot(col(Lam.B, 1), rn), dot(col(Lam.B, 2), rn)} + mul(Lam.C, rf);
                             }
-                        } else if ((nonchain >> d) & 1) {
-                            const V3 rn = mask(has0, from_next(cn));
-                            un_new = un_new + rn;
-                            uf_new = uf_new + mask(has0, from_next(cf));
-                            un_tot = un_tot + rn;
-                        } else {
-                            // every link of this level directly follows its parent: the shifted values are added unmasked (DPP operand of the add)
-                            un_new = un_new + from_next(cn);
-                            uf_new = uf_new + from_next(cf);
-                            un_tot = un_tot + from_next(cn);
                         }
                     }
                     LLSUB(12);
                     // ---- down
                     const int dtop = dn0 > dn1 ? dn0 : dn1;
                     for (int d = dlmin + 1; d <= dtop; ++d) {
-                        if (!(((d > dl0) & (d <= dn0)) | ((d > dl1) & (d <= dn1)))) continue;
                         const bool nc = (nonchain >> d) & 1;
                         const V3 pdw = pp(Dw, nc), pdv = pp(Dv, nc);
                         if (dndep == d) {
@@ -1186,7 +1178,8 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                 };
                 // the walk returns to the root (its Lambda answers the total) and one root -> leaves pass moves the links down to depth dlast
                 auto walk_close = [&](int dlast) {
-                    const int i0 = (int)__builtin_amdgcn_readlane(dep, cur0) << 4, i1 = (int)__builtin_amdgcn_readlane(dep, 32 + cur1) << 4;
+                    const int i0 = ((int)__builtin_amdgcn_readlane(dep, cur0) << 4) | (M.side_depths[cur0] << 12);
+                    const int i1 = ((int)__builtin_amdgcn_readlane(dep, 32 + cur1) << 4) | (M.side_depths[cur1] << 12);
                     const int slive = __builtin_amdgcn_readfirstlane((live0 ? 1 : 0) | (live1 ? 2 : 0));
                     walk_to(0, 0, i0, i1, (slive & 1) != 0, (slive & 2) != 0);
                     long long tsub = DIAG && a.prof ? clock64() : 0;

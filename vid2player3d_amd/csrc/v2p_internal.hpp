@@ -54,6 +54,7 @@ struct DevModel {
     int32_t max_hull_count;
     int32_t nonchain_levels;     // bit d set when some link at depth d does not directly follow its parent (parent != link - 1)
     int32_t lam_slot[NB];  // index into the saved-Lambda register sets for branching links (root = 0), -1 otherwise
+    int32_t side_depths[NB];  // bit d set when the ancestor (or self) of the link at depth d is not the FIRST child of its parent
     DevShape shape;
 };
 
