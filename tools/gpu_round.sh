@@ -26,4 +26,6 @@ V2P_WAVE_TIMES=$O/wave_times.bin timeout 300 python bench.py --steps 29 --warmup
 python tools/wave_times.py $O/wave_times.bin > $O/wave_times.txt 2>&1; rm -f $O/wave_times.bin
 V2P_PHASE_TIMING=1 timeout 300 python bench.py --steps 64 --warmup 0 --no-cpu-baseline 2>&1 | grep phase > $O/phase.log
 V2P_PHASE_HEAVY=1 V2P_PHASE_TIMING=1 timeout 300 python bench.py --steps 64 --warmup 0 --no-cpu-baseline 2>&1 | grep phase > $O/phase_heavy.log
+[ -f variants/libv2p_nowalk.so ] && bash tools/walk_ab.sh > $O/walk_ab.log 2>&1
+python tools/epoch_profile.py --epochs 4 > $O/epoch_profile.txt 2>&1
 tail -3 $O/pytest_gpu.log; tail -2 $O/smoke.log; tail -1 $O/bench.log | cut -c1-1500; cut -c1-260 $O/bench_variants.log; tail -1 $O/bench_ppo.log | cut -c1-400; head -8 $O/rocprof_stats.txt

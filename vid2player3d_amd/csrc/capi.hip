@@ -373,6 +373,8 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
         const size_t words = (N + 1) / 2 + 2;
         rc = check_hip(hipMalloc((void**)&e->job_progress, sizeof(int32_t) * words), "hipMalloc(job_progress)");
         if (rc == V2P_OK) rc = check_hip(hipMemset(e->job_progress, 0, sizeof(int32_t) * words), "hipMemset(job_progress)");
+        // the state as the jobs hand it over: 50 16-byte chunks per env (see physics_ll.hip)
+        if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->job_hand, sizeof(float) * HAND_FLOATS * N), "hipMalloc(job_hand)");
     }
     if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->pair_key, sizeof(int32_t) * N), "hipMalloc(pair_key)");
     if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->pair_pos, sizeof(int32_t) * N), "hipMalloc(pair_pos)");
@@ -425,6 +427,7 @@ void v2p_env_destroy(v2p_env* e) {
     if (e->contact_ids) (void)hipFree(e->contact_ids);
     if (e->contact_ids_sub) (void)hipFree(e->contact_ids_sub);
     if (e->job_progress) (void)hipFree(e->job_progress);
+    if (e->job_hand) (void)hipFree(e->job_hand);
     profile_free(e);
     if (e->shapes_dev) (void)hipFree(e->shapes_dev);
     if (e->shape_aug_dev) (void)hipFree(e->shape_aug_dev);

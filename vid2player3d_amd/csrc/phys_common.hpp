@@ -77,6 +77,7 @@ struct PhysArgs {
     // substep jobs (physics_ll.hip JOBS): workgroups per substep, progress word per wave slot (+1 error word), epoch of this launch
     int32_t job_blocks, job_epoch, job_mono;
     int32_t* job_progress;
+    float* job_hand;  // [N][HAND_FLOATS] state hand-off between the substep jobs of an env pair
     PostArgs post;
 };
 

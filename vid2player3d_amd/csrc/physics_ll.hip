@@ -77,6 +77,20 @@ __device__ __forceinline__ bool any64(bool p) { return __builtin_amdgcn_ballot_w
 // system-scope relaxed atomics = `sc0 sc1` loads / stores on both sides (MI355X_MICROARCH.md, inter-workgroup visibility, valid forms)
 __device__ __forceinline__ float cload(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void cstore(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// the same in 16-byte pieces (MI355X_MICROARCH.md: a dword `sc1` store is its own fabric write, ~6x the time per byte of a dwordx4 one;
+// __hip_atomic_* stops at 8 bytes).  The compiler does not count these accesses: the loads are drained inside the asm block, the stores
+// by the s_waitcnt vmcnt(0) in front of the progress word (memory operations retire in order, so the compiler's own counts only over-wait).
+typedef float f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void cstore4(float* p, float x, float y, float z, float w) {
+    const f4 v{x, y, z, w};
+    // (s_nop 1: gfx940+ needs two wait states between a VMEM store of more than 8 bytes and a VALU write of its data registers; the
+    // compiler's hazard recogniser does not look into inline asm and reuses the registers at once - with one wait state short, the
+    // hand-offs of a loaded GPU carried the NEXT values of those registers)
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void cload4x2(const float* p0, const float* p1, f4& a, f4& b) {
+    asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dwordx4 %1, %3, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(a), "=&v"(b) : "v"(p0), "v"(p1) : "memory");
+}
 
 __device__ __forceinline__ float pull(float v, int src_lane) {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
@@ -292,6 +306,9 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
     const bool live_env = slot < N;
     int64_t e = live_env ? slot : N - 1;
     if (a.perm) e = a.perm[e];
+    // the env index behind an opaque move: addresses formed from it inside the substep loop are computed where they are used instead of
+    // being hoisted in front of the loop and kept (spilled: 64-bit pointers, 8 bytes of scratch per lane each) across all of it
+    auto env_here = [&]() -> int64_t { int64_t v = e; asm volatile("" : "+v"(v)); return v; };
     ConstModel& M = *(ConstModel*)a.model;
     // numeric data of this env's body shape: the model's own shape, or (MULTI) one of the batch's shapes, per env
     const int sid = MULTI ? a.env_shape[e] : 0;
@@ -373,15 +390,39 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
     // ---- state: the root lane carries the root pose/velocity, every other lane its joint
     Q4 q{0.f, 0.f, 0.f, 1.f}, jq{0.f, 0.f, 0.f, 1.f};
     V3 x{0.f, 0.f, 0.f}, w{0.f, 0.f, 0.f}, xd{0.f, 0.f, 0.f}, wt{0.f, 0.f, 0.f}, tar{0.f, 0.f, 0.f};
+    // (JOBS: the job of an env's first substep reads the engine's state, the others what the job before them handed over: 16-byte chunks,
+    // chunk 2b, 2b+1 = joint b (quaternion | rate), chunks 0, 1, 48, 49 = the root (quat | pos, vx | vy, vz, wx, wy | wz))
+    float* const hand = JOBS ? a.job_hand + e * HAND_FLOATS : nullptr;
+    bool got = false;
+    if constexpr (JOBS) if (handed) {
+        f4 c0, c1;
+        cload4x2(hand + 8 * b, hand + 8 * b + 4, c0, c1);
+        if (b == 0) {
+            f4 c2, c3;
+            cload4x2(hand + 4 * 48, hand + 4 * 49, c2, c3);
+            q = Q4{c0.x, c0.y, c0.z, c0.w};
+            x = V3{c1.x, c1.y, c1.z};
+            xd = V3{c1.w, c2.x, c2.y};
+            w = V3{c2.z, c2.w, c3.x};
+        } else {
+            jq = Q4{c0.x, c0.y, c0.z, c0.w};
+            wt = V3{c1.x, c1.y, c1.z};
+        }
+        got = true;
+    }
     if (b == 0) {
-        q = Q4{ldin(&st[SIDX(ST_ROOT_QUAT + 0)]), ldin(&st[SIDX(ST_ROOT_QUAT + 1)]), ldin(&st[SIDX(ST_ROOT_QUAT + 2)]), ldin(&st[SIDX(ST_ROOT_QUAT + 3)])};
-        x = V3{ldin(&st[SIDX(ST_ROOT_POS + 0)]), ldin(&st[SIDX(ST_ROOT_POS + 1)]), ldin(&st[SIDX(ST_ROOT_POS + 2)])};
-        xd = V3{ldin(&st[SIDX(ST_VEL + 0)]), ldin(&st[SIDX(ST_VEL + 1)]), ldin(&st[SIDX(ST_VEL + 2)])};
-        w = V3{ldin(&st[SIDX(ST_VEL + 3)]), ldin(&st[SIDX(ST_VEL + 4)]), ldin(&st[SIDX(ST_VEL + 5)])};
+        if (!got) {
+            q = Q4{st[SIDX(ST_ROOT_QUAT + 0)], st[SIDX(ST_ROOT_QUAT + 1)], st[SIDX(ST_ROOT_QUAT + 2)], st[SIDX(ST_ROOT_QUAT + 3)]};
+            x = V3{st[SIDX(ST_ROOT_POS + 0)], st[SIDX(ST_ROOT_POS + 1)], st[SIDX(ST_ROOT_POS + 2)]};
+            xd = V3{st[SIDX(ST_VEL + 0)], st[SIDX(ST_VEL + 1)], st[SIDX(ST_VEL + 2)]};
+            w = V3{st[SIDX(ST_VEL + 3)], st[SIDX(ST_VEL + 4)], st[SIDX(ST_VEL + 5)]};
+        }
     } else {
         const int jb = ST_JQUAT + 4 * (b - 1), vb = ST_VEL + 6 + 3 * (b - 1), cb = CT_PD + 3 * (b - 1);
-        jq = Q4{ldin(&st[SIDX(jb + 0)]), ldin(&st[SIDX(jb + 1)]), ldin(&st[SIDX(jb + 2)]), ldin(&st[SIDX(jb + 3)])};
-        wt = V3{ldin(&st[SIDX(vb + 0)]), ldin(&st[SIDX(vb + 1)]), ldin(&st[SIDX(vb + 2)])};
+        if (!got) {
+            jq = Q4{st[SIDX(jb + 0)], st[SIDX(jb + 1)], st[SIDX(jb + 2)], st[SIDX(jb + 3)]};
+            wt = V3{st[SIDX(vb + 0)], st[SIDX(vb + 1)], st[SIDX(vb + 2)]};
+        }
         if (!a.actions || handed) tar = V3{ldin(&a.ctrl[CIDX(cb + 0)]), ldin(&a.ctrl[CIDX(cb + 1)]), ldin(&a.ctrl[CIDX(cb + 2)])};
     }
     auto stctl = [&](float* p, float v) { if (!mono) cstore(p, v); else *p = v; };  // ctrl is read by the later jobs of the pair
@@ -523,8 +564,9 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
             pf = mass * (wwd - V3{0.f, 0.f, P.gravity_z});
             pn = cross(w, mul(Ic, w)) + cross(dc, pf);
             if (b == 0 && wrench_on) {
-                const V3 extF{ldin(&a.ctrl[CIDX(CT_FORCE + 0)]), ldin(&a.ctrl[CIDX(CT_FORCE + 1)]), ldin(&a.ctrl[CIDX(CT_FORCE + 2)])};
-                const V3 extT{ldin(&a.ctrl[CIDX(CT_TORQUE + 0)]), ldin(&a.ctrl[CIDX(CT_TORQUE + 1)]), ldin(&a.ctrl[CIDX(CT_TORQUE + 2)])};
+                const float* cw = a.ctrl + env_here() * CTRL_SLOTS;
+                const V3 extF{ldin(&cw[CT_FORCE + 0]), ldin(&cw[CT_FORCE + 1]), ldin(&cw[CT_FORCE + 2])};
+                const V3 extT{ldin(&cw[CT_TORQUE + 0]), ldin(&cw[CT_TORQUE + 1]), ldin(&cw[CT_TORQUE + 2])};
                 pn = pn - extT - cross(dc, extF);  // force acts at the root COM
                 pf = pf - extF;
             }
@@ -904,11 +946,11 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
             }
             if (a.contact_ids && last && valid && live_env && !frozen) {  // diagnostics (v2p_sim_cfg.debug_contacts)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) a.contact_ids[(e * NB + b) * 4 + c] = c < cnt ? b * 64 + sel4[c] : -1;
+                for (int c = 0; c < 4; ++c) a.contact_ids[(env_here() * NB + b) * 4 + c] = c < cnt ? b * 64 + sel4[c] : -1;
             }
             if (a.contact_ids_sub && valid && live_env && !frozen) {  // diagnostics: the ids of every substep (parity tests)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) a.contact_ids_sub[((e * nsub + sub) * NB + b) * 4 + c] = c < cnt ? b * 64 + sel4[c] : -1;
+                for (int c = 0; c < 4; ++c) a.contact_ids_sub[((env_here() * nsub + sub) * NB + b) * 4 + c] = c < cnt ? b * 64 + sel4[c] : -1;
             }
 
             LLSUB(18);
@@ -1579,7 +1621,9 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                 if (last && valid && live_env && !frozen) {  // joint drive torque actually applied over the substep (implicit form)
                     const float kp = S->kp[b], kd = S->kd[b];
                     V3 tf = kp * (park_get3(PARK_TAR) - quat_to_expmap_stable(jold) - h * wn) - kd * wn;
-                    float* of = a.x_dof_force + e * NDOF + 3 * (b - 1);
+                    int bh = b;
+                    asm volatile("" : "+v"(bh));
+                    float* of = a.x_dof_force + env_here() * NDOF + 3 * (bh - 1);
                     of[0] = tf.x; of[1] = tf.y; of[2] = tf.z;
                 }
                 wn = sc * wn;
@@ -1656,12 +1700,16 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                     if (c < cnt) { const V3 lc = CS.lam(c); cforce.z += lc.x * ih; cforce.x += lc.y * ih; cforce.y += lc.z * ih; }
                 if (BALL && lb == BP.racket_link) cforce = cforce - park_get3(PARK_W0);
             }
-            float* oc = a.x_contact + (e * NB + b) * 3;
+            float* oc = a.x_contact + (env_here() * NB + b) * 3;
             oc[0] = cforce.x; oc[1] = cforce.y; oc[2] = cforce.z;
         }
     }
 
     LLPH(7);
+    // (opaque copy of the link index for everything after the substeps: indices and addresses formed from it are computed here instead of
+    // being kept - spilled to scratch, which is HBM write traffic for every wave - since the prologue)
+    int bo2 = b;
+    asm volatile("" : "+v"(bo2));
     if (frozen && nsub > 0) {  // frozen env sharing a wave with a live one: it was carried along, its result is dropped
         if (b == 0) {
             q = Q4{st[SIDX(ST_ROOT_QUAT + 0)], st[SIDX(ST_ROOT_QUAT + 1)], st[SIDX(ST_ROOT_QUAT + 2)], st[SIDX(ST_ROOT_QUAT + 3)]};
@@ -1669,14 +1717,14 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
             xd = V3{st[SIDX(ST_VEL + 0)], st[SIDX(ST_VEL + 1)], st[SIDX(ST_VEL + 2)]};
             w = V3{st[SIDX(ST_VEL + 3)], st[SIDX(ST_VEL + 4)], st[SIDX(ST_VEL + 5)]};
         } else {
-            const int jb = ST_JQUAT + 4 * (b - 1), vb = ST_VEL + 6 + 3 * (b - 1);
+            const int jb = ST_JQUAT + 4 * (bo2 - 1), vb = ST_VEL + 6 + 3 * (bo2 - 1);
             jq = Q4{st[SIDX(jb + 0)], st[SIDX(jb + 1)], st[SIDX(jb + 2)], st[SIDX(jb + 3)]};
             wt = V3{st[SIDX(vb + 0)], st[SIDX(vb + 1)], st[SIDX(vb + 2)]};
         }
     }
     // ==================================================================== final kinematics -> state, rigid-body state, dof_pos
     // (JOBS: only the job of the last substep produces the exposed tensors and the pairing keys; the others hand the state over)
-    const V3 lpos{S->local_pos[b][0], S->local_pos[b][1], S->local_pos[b][2]};
+    const V3 lpos{S->local_pos[bo2][0], S->local_pos[bo2][1], S->local_pos[bo2][2]};
     for (int d = 1; d <= (last_job ? maxd : 0); ++d) {
         const bool nc = (nonchain >> d) & 1;
         Q4 pq = pp(q, nc);
@@ -1703,8 +1751,8 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
         int ksoon = 0;
         {
             const float rz0 = 2.f * (q.x * q.z - q.w * q.y), rz1 = 2.f * (q.y * q.z + q.w * q.x), rz2 = 1.f - 2.f * (q.x * q.x + q.y * q.y);
-            const float zl = x.z + rz0 * S->aabb_c[b][0] + rz1 * S->aabb_c[b][1] + rz2 * S->aabb_c[b][2] -
-                             (fabsf(rz0) * S->aabb_e[b][0] + fabsf(rz1) * S->aabb_e[b][1] + fabsf(rz2) * S->aabb_e[b][2]);
+            const float zl = x.z + rz0 * S->aabb_c[bo2][0] + rz1 * S->aabb_c[bo2][1] + rz2 * S->aabb_c[bo2][2] -
+                             (fabsf(rz0) * S->aabb_e[bo2][0] + fabsf(rz1) * S->aabb_e[bo2][1] + fabsf(rz2) * S->aabb_e[bo2][2]);
             const unsigned long long nb2 = __ballot(valid && zl + fminf(xd.z, 0.f) * P.dt < P.contact_offset);
             ksoon = __popc(half ? (unsigned)(nb2 >> 32) : (unsigned)nb2);
         }
@@ -1740,19 +1788,23 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
     if constexpr (JOBS) if (!last_job) {
         // ---- hand the state over to the job of the next substep: system-scope stores, drained, then the progress word of the pair
         if (valid && live_env) {
+            float* const ho = a.job_hand + e * HAND_FLOATS;
             if (b == 0) {
-                cstore(&st[SIDX(ST_ROOT_QUAT + 0)], q.x); cstore(&st[SIDX(ST_ROOT_QUAT + 1)], q.y); cstore(&st[SIDX(ST_ROOT_QUAT + 2)], q.z); cstore(&st[SIDX(ST_ROOT_QUAT + 3)], q.w);
-                cstore(&st[SIDX(ST_ROOT_POS + 0)], x.x); cstore(&st[SIDX(ST_ROOT_POS + 1)], x.y); cstore(&st[SIDX(ST_ROOT_POS + 2)], x.z);
-                cstore(&st[SIDX(ST_VEL + 0)], xd.x); cstore(&st[SIDX(ST_VEL + 1)], xd.y); cstore(&st[SIDX(ST_VEL + 2)], xd.z);
-                cstore(&st[SIDX(ST_VEL + 3)], w.x); cstore(&st[SIDX(ST_VEL + 4)], w.y); cstore(&st[SIDX(ST_VEL + 5)], w.z);
+                cstore4(ho, q.x, q.y, q.z, q.w);
+                cstore4(ho + 4, x.x, x.y, x.z, xd.x);
+                cstore4(ho + 4 * 48, xd.y, xd.z, w.x, w.y);
+                cstore4(ho + 4 * 49, w.z, 0.f, 0.f, 0.f);
             } else {
-                const int jb = ST_JQUAT + 4 * (b - 1), vb = ST_VEL + 6 + 3 * (b - 1);
-                cstore(&st[SIDX(jb + 0)], jq.x); cstore(&st[SIDX(jb + 1)], jq.y); cstore(&st[SIDX(jb + 2)], jq.z); cstore(&st[SIDX(jb + 3)], jq.w);
-                cstore(&st[SIDX(vb + 0)], wt.x); cstore(&st[SIDX(vb + 1)], wt.y); cstore(&st[SIDX(vb + 2)], wt.z);
+                cstore4(ho + 8 * bo2, jq.x, jq.y, jq.z, jq.w);
+                cstore4(ho + 8 * bo2 + 4, wt.x, wt.y, wt.z, 0.f);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (inline asm: the compiler must not drop or move this drain)
-        if (lane == 0) __hip_atomic_store(progress, a.job_epoch * 8 + sjob + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (lane == 0) {
+            int bid_here = bid;  // (the address of the progress word is formed here: kept from the prologue it is a spilled 64-bit pointer)
+            asm volatile("" : "+s"(bid_here));
+            __hip_atomic_store(a.job_progress + (bid_here * LL_WPB + (threadIdx.x >> 6)), a.job_epoch * 8 + sjob + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         timeline();
         return;
     }
@@ -1764,12 +1816,12 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
             st[SIDX(ST_VEL + 0)] = xd.x; st[SIDX(ST_VEL + 1)] = xd.y; st[SIDX(ST_VEL + 2)] = xd.z;
             st[SIDX(ST_VEL + 3)] = w.x; st[SIDX(ST_VEL + 4)] = w.y; st[SIDX(ST_VEL + 5)] = w.z;
         } else {
-            const int jb = ST_JQUAT + 4 * (b - 1), vb = ST_VEL + 6 + 3 * (b - 1);
+            const int jb = ST_JQUAT + 4 * (bo2 - 1), vb = ST_VEL + 6 + 3 * (bo2 - 1);
             st[SIDX(jb + 0)] = jq.x; st[SIDX(jb + 1)] = jq.y; st[SIDX(jb + 2)] = jq.z; st[SIDX(jb + 3)] = jq.w;
             st[SIDX(vb + 0)] = wt.x; st[SIDX(vb + 1)] = wt.y; st[SIDX(vb + 2)] = wt.z;
             // exposed dof state: (exp-map position, joint rate) interleaved like gym's dof state tensor
             qe = quat_to_expmap_stable(jq);
-            float* od = a.x_dof + (e * NDOF + 3 * (b - 1)) * 2;
+            float* od = a.x_dof + (e * NDOF + 3 * (bo2 - 1)) * 2;
             od[0] = qe.x; od[1] = wt.x; od[2] = qe.y; od[3] = wt.y; od[4] = qe.z; od[5] = wt.z;
         }
         if (b == 0) {
@@ -1996,6 +2048,7 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s, float* actions, int* fuse
         const bool cut = env->substep_jobs && env->job_progress && blocks > 1;
         a.job_blocks = (int)blocks;
         a.job_progress = env->job_progress;
+        a.job_hand = env->job_hand;
         a.job_mono = (int)blocks;
         if (cut) {
             // substep jobs: one launch of job_mono + nsub x (blocks - job_mono) workgroups, substep-major

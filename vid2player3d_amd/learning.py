@@ -4,6 +4,7 @@ argument meaning, forwarding to the HIP library (no CPU path):
   * `ImitationObs` — `ImitatorBuilder.Network.preprocess_input` + `compute_humanoid_obs` + `running_obs`
     (models/im_network_builder.py:150-189, env/tasks/humanoid_smpl_im.py:773-850, models/running_norm.py:32-43): the 734-d
     in-network observation computed straight from the packed 461-d obs rows and the context frames, RunningNorm (eval) fused.
+  * `RunningNorm` — models/running_norm.py:5-43 including the training-mode update of the statistics.
   * `discount_values` — `CommonAgent.discount_values` (learning/common_agent.py:423-435), the GAE reverse scan.
 """
 import torch
@@ -16,6 +17,53 @@ OBS_IMITATION_DIM = 734
 def _chk(t, shape_tail, name):
     if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda or tuple(t.shape[-len(shape_tail):]) != tuple(shape_tail):
         raise RuntimeError("%s must be a contiguous float32 CUDA tensor [..., %s]" % (name, ", ".join(map(str, shape_tail))))
+
+
+class RunningNorm:
+    """models/running_norm.py:5-43: y = clamp((x - mean) / (std + 1e-8)) with running estimates.  Same buffers (n mean var std), same
+    update rule and the same order (training mode updates the statistics with the batch BEFORE normalising it; nothing is normalised
+    while n == 0).  Plain torch on whatever device the buffers live on: the statistics of a batch depend on the whole batch, so the
+    training-mode pass cannot be fused into the per-row observation kernel; eval mode is what `ImitationObs` fuses."""
+
+    def __init__(self, dim, demean=True, destd=True, clip=5.0, device=None):
+        self.dim, self.demean, self.destd, self.clip = int(dim), demean, destd, clip
+        self.n = torch.zeros((), dtype=torch.long, device=device)
+        self.mean = torch.zeros(dim, device=device)
+        self.var = torch.zeros(dim, device=device)
+        self.std = torch.zeros(dim, device=device)
+        self.training = True
+
+    def train(self, mode=True):
+        self.training = bool(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    @torch.no_grad()
+    def update(self, x):
+        var_x, mean_x = torch.var_mean(x, dim=0, unbiased=False)
+        m = x.shape[0]
+        w = self.n.to(x.dtype) / (m + self.n).to(x.dtype)
+        self.var[:] = w * self.var + (1 - w) * var_x + w * (1 - w) * (mean_x - self.mean).pow(2)
+        self.mean[:] = w * self.mean + (1 - w) * mean_x
+        self.std[:] = torch.sqrt(self.var)
+        self.n += m
+
+    def normalize(self, x):
+        if int(self.n) > 0:
+            if self.demean:
+                x = x - self.mean
+            if self.destd:
+                x = x / (self.std + 1e-8)
+            if self.clip:
+                x = torch.clamp(x, -self.clip, self.clip)
+        return x
+
+    def __call__(self, x):
+        if self.training:
+            self.update(x)
+        return self.normalize(x)
 
 
 class ImitationObs:
@@ -72,15 +120,26 @@ class ImitationObs:
         _chk(context_feat, (378,), "context_feat")
         return self._run(obs, context_feat, 1, self.context_padding + int(t))
 
-    def training(self, obs, context_feat):
-        """training flavour (flatten=True): obs [N,T,461] (or [N*T,461]), context_feat [N,L,378] -> [N*T,734]."""
+    def training(self, obs, context_feat, running_norm=None):
+        """training flavour (flatten=True): obs [N,T,461] (or [N*T,461]), context_feat [N,L,378] -> [N*T,734].
+        running_norm: a `RunningNorm` (or the reference's module) in TRAINING mode - its statistics are updated with this batch's raw
+        features first, then the batch is normalised with them (running_norm.py:32-43); the kernel then produces the raw features and
+        the normalisation is the module's own.  None: the statistics given at construction, fused into the kernel (eval mode)."""
         _chk(obs, (_lib.NUM_OBS,), "obs")
         _chk(context_feat, (378,), "context_feat")
         n = context_feat.shape[0]
         flat = obs.reshape(-1, _lib.NUM_OBS)
         if flat.shape[0] % n:
             raise RuntimeError("obs rows %d are not a multiple of the %d envs of context_feat" % (flat.shape[0], n))
-        return self._run(flat, context_feat, flat.shape[0] // n, self.context_padding)
+        if running_norm is None:
+            return self._run(flat, context_feat, flat.shape[0] // n, self.context_padding)
+        keep = self._mean, self._std
+        self._mean = self._std = None
+        try:
+            raw = self._run(flat, context_feat, flat.shape[0] // n, self.context_padding)
+        finally:
+            self._mean, self._std = keep
+        return running_norm(raw)
 
 
 def discount_values(mb_fdones, mb_values, mb_rewards, mb_next_values, gamma, tau):

@@ -118,8 +118,6 @@ class HumanoidSMPLIM:
             raise NotImplementedError("pdControl=False (direct torque actuation) is not built; amass_im/djokovic_im use PD targets")
         self._state_init = HumanoidSMPLIM.StateInit[env.get("stateInit", "Hybrid")]
         self._hybrid_init_prob = env.get("hybridInitProb", 1.0)
-        if self._state_init == HumanoidSMPLIM.StateInit.Default or (self._state_init == HumanoidSMPLIM.StateInit.Hybrid and self._hybrid_init_prob < 1.0):
-            raise NotImplementedError("default-pose state init is not built; amass_im/djokovic_im use reference-state init (hybridInitProb 1.0)")
         self.ground_tolerance = env.get("ground_tolerance", 0.0)
         self.max_episode_length = env.get("episodeLength", 300)
         self._local_root_obs = env.get("localRootObs", True)
@@ -294,12 +292,26 @@ class HumanoidSMPLIM:
         # the tensors gym.acquire_*_tensor would have returned (humanoid_smpl.py:66-113)
         self._root_states = torch.zeros((n, 13), **f)
         self._humanoid_root_states = self._root_states
+        # the actors' start pose (humanoid_smpl.py:348-353: char_h 0.89, identity rotation), velocities zeroed (:89-90): what
+        # _reset_default restores
+        self._root_states[:, 2] = 0.89
+        self._root_states[:, 6] = 1.0
         self._initial_humanoid_root_states = self._root_states.clone()
         self._dof_state = torch.zeros((n * self._num_dof, 2), **f)
         ds = self._dof_state.view(n, self._num_dof, 2)
         self._dof_pos, self._dof_vel = ds[..., 0], ds[..., 1]
         self._rigid_body_state = torch.zeros((n * self.num_bodies, 13), **f)
         rb = self._rigid_body_state.view(n, self.num_bodies, 13)
+        # bodies of the freshly created actors: the start pose with every joint at zero (a default-pose reset leaves the rigid-body
+        # tensor as it is until the next simulate(), like gym.refresh_rigid_body_state_tensor does: at creation it holds this pose)
+        bm0 = self.body_model
+        if bm0 is not None:
+            pos = np.zeros((self.num_bodies, 3), dtype=np.float32)
+            pos[0] = (0.0, 0.0, 0.89)
+            for b in range(1, self.num_bodies):
+                pos[b] = pos[int(bm0.parents[b])] + np.asarray(bm0.local_pos[b], dtype=np.float32)
+            rb[:, :, 0:3] = torch.as_tensor(pos, **f)
+            rb[:, :, 6] = 1.0
         self._rigid_body_pos, self._rigid_body_rot = rb[..., 0:3], rb[..., 3:7]
         self._rigid_body_vel, self._rigid_body_ang_vel = rb[..., 7:10], rb[..., 10:13]
         self._contact_forces = torch.zeros((n, self.num_bodies, 3), **f)
@@ -489,12 +501,46 @@ class HumanoidSMPLIM:
             if n == 0:
                 return
             motion_ids = self._reset_ref_motion_ids[ids_t]
+        # _reset_actors (humanoid_smpl_im.py:470-480): default pose, reference state, or a Bernoulli mix of the two (:638-651)
+        if self._state_init == HumanoidSMPLIM.StateInit.Default:
+            self._reset_default(ids_t)
+            return
+        if self._state_init == HumanoidSMPLIM.StateInit.Hybrid and self._hybrid_init_prob < 1.0:
+            all_ids = torch.arange(self.num_envs, device=self.device, dtype=torch.long) if ids_t is None else ids_t
+            ref_mask = torch.bernoulli(torch.full((n,), float(self._hybrid_init_prob), device=self.device)) == 1.0
+            ref_ids, def_ids = all_ids[ref_mask].contiguous(), all_ids[~ref_mask].contiguous()
+            if def_ids.numel() > 0:
+                self._reset_default(def_ids)
+            if ref_ids.numel() == 0:
+                return
+            ids_t, n, motion_ids = ref_ids, ref_ids.shape[0], self._reset_ref_motion_ids[ref_ids]
         if self._state_init == HumanoidSMPLIM.StateInit.Start:
             times = torch.zeros(n, device=self.device)
         else:
             trunc = self.context_length * self.dt if self.truncate_time else None
             times = self._motion_lib.sample_time(motion_ids, truncate_time=trunc).to(self.device)
         self.reset_with_times(ids_t, times)
+
+    def _reset_default(self, env_ids):
+        """_reset_default (humanoid_smpl_im.py:482-487) + _reset_env_tensors (humanoid_smpl.py:161-173) + the observation of the reset
+        envs (:153-158): root at the actor's start pose, joints and velocities at zero, pushed into the engine; progress / reset /
+        terminate flags cleared.  Like the reference, nothing else moves: the clip time, the target and the context of these envs stay,
+        and the rigid-body tensor keeps showing the bodies of before the reset until the next physics step (Isaac Gym only refreshes it
+        from the last simulate()), so the observation of a default-reset env mixes new joint coordinates with old body poses."""
+        ids = slice(None) if env_ids is None else env_ids
+        self._humanoid_root_states[ids] = self._initial_humanoid_root_states[ids]
+        self._dof_pos[ids] = 0.0
+        self._dof_vel[ids] = 0.0
+        self._reset_env_tensors(env_ids)
+        self.progress_buf[ids] = 0
+        self.reset_buf[ids] = 0
+        self._terminate_buf[ids] = 0
+        self._reset_default_env_ids = env_ids
+        # _compute_humanoid_obs on the reset envs (:653-668; layout :198): plain copies of the exposed tensors
+        k = self.num_envs if env_ids is None else env_ids.shape[0]
+        self.obs_buf[ids] = torch.cat([self._rigid_body_pos[ids].reshape(k, -1), self._rigid_body_rot[ids].reshape(k, -1), self._dof_pos[ids],
+                                       self._dof_vel[ids], self._rigid_body_vel[ids].reshape(k, -1), self._rigid_body_ang_vel[ids].reshape(k, -1),
+                                       self._reset_ref_motion_bodies[ids][:, :11]], dim=1)
 
     def reset_with_times(self, env_ids, motion_times):
         """Reference-state init at explicit clip times (parity tests; _reset_ref_state_init :489-528)."""
