@@ -319,6 +319,38 @@ def test_imitation_obs_running_norm_semantics(golden_task_ops):
         ImitationObs(8, torch.zeros(10), torch.ones(10))
 
 
+def test_imitation_obs_training_mode_updates_the_statistics(golden_task_ops):
+    """RunningNorm in training mode (models/running_norm.py:32-35): the statistics take the batch's raw in-network features in first,
+    then normalise that very batch; a second batch merges by count.  The kernel supplies the raw features."""
+    from vid2player3d_amd.learning import ImitationObs, RunningNorm
+
+    g = golden_task_ops
+    steps = 4
+    envs = g["obs734"].shape[0] // steps
+    rows = envs * steps
+    obs, frame = _packed_inputs(g, rows)
+    ctx = np.zeros((envs, 48, 378), np.float32)
+    ctx[:, 8:8 + steps] = frame[:rows].reshape(envs, steps, 378)
+    enc = ImitationObs(8)
+    o, c = T(obs[:rows].reshape(envs, steps, 461)), T(ctx)
+    raw = enc.training(o, c)
+    rn = RunningNorm(734, device=DEV)
+    y = enc.training(o, c, running_norm=rn)
+    assert int(rn.n) == rows
+    var, mean = torch.var_mean(raw, dim=0, unbiased=False)
+    close(N(rn.mean), N(mean), 1e-6, "mean after the first batch")
+    close(N(rn.var), N(var), 1e-6, "var after the first batch")
+    close(N(y), N(torch.clamp((raw - mean) / (torch.sqrt(var) + 1e-8), -5.0, 5.0)), 1e-5, "training-mode output")
+    enc.training(o, c, running_norm=rn)
+    assert int(rn.n) == 2 * rows
+    close(N(rn.mean), N(mean), 1e-5, "the same batch again leaves the mean")
+    rn.eval()
+    y_eval = enc.training(o, c, running_norm=rn)
+    assert int(rn.n) == 2 * rows, "eval mode leaves the statistics alone"
+    fused = ImitationObs.from_running_norm(rn, 8).training(o, c)
+    close(N(fused), N(y_eval), 2e-5, "eval mode = the fused kernel with the same statistics")
+
+
 def test_replay_tool_on_the_golden_trace(tmp_path, golden_tables, capsys, monkeypatch):
     """tools/replay_trace.py (the procedure that pins physics parity on a box with Isaac Gym) runs end to end on the golden trace:
     teacher-forced task ops within float32 rounding of the recording."""

@@ -76,6 +76,11 @@ def default_cfg(num_envs=8192, **env_overrides):
     return {"env": env, "sim": sim, "args": None}
 
 
+# uhc/smpllib/smpl_parser.py:10-35: the SMPL joints in SMPL order, by the names the MJCF bodies carry
+SMPL_BONE_ORDER_NAMES = ["Pelvis", "L_Hip", "R_Hip", "Torso", "L_Knee", "R_Knee", "Spine", "L_Ankle", "R_Ankle", "Chest", "L_Toe", "R_Toe", "Neck",
+                         "L_Thorax", "R_Thorax", "Head", "L_Shoulder", "R_Shoulder", "L_Elbow", "R_Elbow", "L_Wrist", "R_Wrist", "L_Hand", "R_Hand"]
+
+
 class HumanoidSMPLIM:
     class StateInit(Enum):
         Default = 0
@@ -209,7 +214,9 @@ class HumanoidSMPLIM:
         self.stiffness = torch.tensor(last.kp, dtype=torch.float32, device=self.device)
         self.damping = torch.tensor(last.kd, dtype=torch.float32, device=self.device)
 
-        # agent back-channels (:325-327); joints in MJCF body order (the SMPL-order table needs the licensed SMPL model)
+        # agent back-channels (:325-327): rest joints, parents and first children in SMPL joint order (uhc/smpllib/smpl_parser.py:10-35,
+        # 340-350), what the network builder's inverse kinematics indexes with (im_network_builder.py:81-102).  The rest joints are the
+        # body origins of the zero pose: the MJCF bodies sit at the SMPL joints they were generated from.
         def rest_joints(m):
             rest = np.zeros((self.num_bodies, 3))
             for b in range(self.num_bodies):
@@ -217,14 +224,30 @@ class HumanoidSMPLIM:
                 rest[b] = m.local_pos[b] + (rest[p] if p >= 0 else 0.0)
             return rest
 
+        names = list(self.body_model.body_names)
+        smpl_named = self.num_bodies == 24 and all(nm in names for nm in SMPL_BONE_ORDER_NAMES)
+        if smpl_named:
+            to_smpl = np.array([names.index(nm) for nm in SMPL_BONE_ORDER_NAMES])  # SMPL joint i = MJCF body to_smpl[i]
+        else:  # (a body model with other bodies: MJCF order)
+            to_smpl = np.arange(self.num_bodies)
+        from_mjcf = np.full(self.num_bodies, -1)
+        from_mjcf[to_smpl] = np.arange(len(to_smpl))
         if self._env_shape_ids is None:
-            self.smpl_rest_joints = torch.tensor(rest_joints(self.body_model), dtype=torch.float32, device=self.device).unsqueeze(0).repeat(self.num_envs, 1, 1)
+            self.smpl_rest_joints = torch.tensor(rest_joints(self.body_model)[to_smpl], dtype=torch.float32, device=self.device).unsqueeze(0).repeat(self.num_envs, 1, 1)
         else:
-            per_shape = np.stack([rest_joints(m) for m in self.body_shapes])
+            per_shape = np.stack([rest_joints(m)[to_smpl] for m in self.body_shapes])
             self.smpl_rest_joints = torch.tensor(per_shape[self._env_shape_ids], dtype=torch.float32, device=self.device)
-        self.smpl_parents = torch.tensor(self.body_model.parents, dtype=torch.long, device=self.device)
-        ch = self.body_model.children_lists()
-        self.smpl_children = torch.tensor([(c[0] if c else -1) for c in ch], dtype=torch.long, device=self.device)
+        par = np.asarray(self.body_model.parents)
+        smpl_par = np.array([(-1 if par[b] < 0 else from_mjcf[par[b]]) for b in to_smpl])
+        self.smpl_parents = torch.tensor(smpl_par, dtype=torch.long, device=self.device)
+        children = np.full(len(to_smpl), -1)  # SMPL_Parser._parents_to_children: the first child in joint order ...
+        for i in range(len(to_smpl)):
+            if smpl_par[i] != -1 and children[smpl_par[i]] < 0:
+                children[smpl_par[i]] = i
+        if smpl_named:
+            children[0] = 3                                    # ... except the pelvis -> Torso
+            children[9] = SMPL_BONE_ORDER_NAMES.index("Neck")  # and Chest (SPINE3) -> Neck
+        self.smpl_children = torch.tensor(children, dtype=torch.long, device=self.device)
 
         self._create_engine()
         self._sub_rewards_names = "dof_reward,vel_reward,body_pos_reward,body_rot_reward"
