@@ -4,22 +4,27 @@
 // the schedule:
 //
 //   * the three tree recursions run level-synchronously (max depth 8 instead of 23 sequential links);
-//     parent -> child and child -> parent transfers are cross-lane pulls (ds_bpermute) inside the wave
-//   * contact generation: a box test culls, each link near the ground is scanned by a group of 8 lanes (DPP reductions)
+//     parent -> child and child -> parent transfers are cross-lane pulls (ds_bpermute / DPP lane shifts) inside the wave
+//   * contact generation: a box test culls, each link near the ground is scanned by a group of 8 lanes (DPP reductions), the
+//     8 groups of a wave take the near links of both environments
 //   * the block Gauss-Seidel sweep visits, per environment, only the bodies that environment touches
-//     (k-th touched body of both environments at once), and the impulse propagation is again level
-//     synchronous: leaf -> root along the path, root -> leaves down to the env's deepest touched link; updates that
-//     change no impulse skip the propagation
-//   * envs are handed to waves in descending order of their contact load (the sweep costs max(load) of the pair), a
-//     counting sort spread over this kernel's epilogue and the pre-physics kernel; an env's arithmetic never depends on
+//     (k-th touched body of both environments at once) and keeps their velocities current by WALKING the tree from one
+//     touched link to the next (up to the lowest common ancestor, which answers with its Lambda, and down again); one
+//     root -> leaves pass at the end of the sweep moves every link (see the sweep)
+//   * envs are handed to waves in descending order of their contact load (the heaviest quarter each next to one of the lightest),
+//     a counting sort spread over this kernel's epilogue and a small scatter kernel; an env's arithmetic never depends on
 //     the env it shares a wave with
-//   * no global workspace: the kernel reads the state once, keeps it in registers for the 4 substeps and
-//     writes the state and the caller's row-major tensors once (lane = body gives contiguous rows); hull vertices and
-//     per-link constants come from the (per-env) shape table through L1/L2; LDS is only a parking area for a few long-lived values
-//   * 256 VGPRs, 2 waves per SIMD (needs -fno-slp-vectorize: SLP packing costs ~160 registers here)
+//   * one launch = (substep, env pair) JOBS: the heaviest pairs run their four substeps in one workgroup, the others hand the
+//     state over from job to job through memory (16-byte write-through stores / loads + a progress word per pair)
+//   * pre-physics (PD-target clamp, residual wrench) runs in the prologue of an env's first job, post-physics (observation, reward,
+//     reset flags, next target) in the epilogue of its last: v2p_env_step is this one kernel
+//   * no global workspace: a job reads the state once, keeps it in registers and writes the state (and, the last job, the
+//     caller's row-major tensors: lane = body gives contiguous rows) once; hull vertices and per-link constants come from the
+//     (per-env) shape table through L1/L2; LDS holds the contact records of a link (28 floats per lane) and values a phase does not touch
+//   * 168 VGPRs, 3 waves per SIMD (needs -fno-slp-vectorize: SLP packing costs ~160 registers here)
 //
 // The sequential semantics of the Gauss-Seidel sweep (bodies ascending, points in slot order, rows
-// n, t1, t2) are unchanged, so results agree with the one-env-per-lane kernel to rounding.
+// n, t1, t2) are unchanged, so results agree with the one-env-per-lane kernel and the float64 oracle to rounding.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdlib.h>
