@@ -137,6 +137,25 @@ class StubTask:
         return 0.001 * self._launches, self._launches
 
 
+def print_last(line, dist):
+    """The JSON line as the LAST thing on stdout: RCCL writes its version banner through C stdio, which a redirected stdout holds back
+    until the process exits - after anything Python printed.  Every rank drains its C buffers, the ranks meet, rank 0 prints."""
+    import ctypes
+
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if dist is not None:
+        dist.barrier()
+    if line is not None:
+        print(line)
+        sys.stdout.flush()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 _ACT_MASK = {}
 
 
@@ -257,11 +276,10 @@ def run_ppo(args, task, dist, world, rank):
                           "T_play_s_per_epoch": play / args.ppo_epochs, "T_update_s_per_epoch": (total - play) / args.ppo_epochs,
                           "step_rewards_last_epoch": rows[-1]["step_rewards"], "alive_ratio_last_epoch": rows[-1]["alive_ratio"]},
                "build": build.build_info()}
-        print(json.dumps(out))
-        sys.stdout.flush()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        line = json.dumps(out)
+    else:
+        line = None
+    print_last(line, dist)
 
 
 def main():
@@ -405,11 +423,10 @@ def main():
             out["build"] = build.build_info()
         if world == 1 and not args.no_cpu_baseline and not stub:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
-        sys.stdout.flush()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        line = json.dumps(out)
+    else:
+        line = None
+    print_last(line, dist)
 
 
 if __name__ == "__main__":
