@@ -291,7 +291,7 @@ struct ContactStore<true> {
 // inverse inertia K = Di + ((T - 1)^T G (T - 1))_ww = Lambda_b,ww - H1 - H1^T + Lambda_parent,ww in the notation of the recursion below.
 template <bool CONTACT, bool MULTI, bool TGS, bool DIAG, bool BALL, bool JOBS, bool LIMITS>
 __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_WPS) void physics_ll_kernel(PhysArgs a) {
-    constexpr bool WALK = V2P_LL_WALK && !BALL && !LIMITS;  // the sweep as one walk over the tree (see the sweep)
+    constexpr bool WALK = V2P_LL_WALK != 0;  // the sweep as one walk over the tree (see the sweep)
     const int64_t N = a.n;
     const int lane = threadIdx.x & 63;
     const int half = lane >> 5;
@@ -1139,11 +1139,14 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                 int cur0 = 0, cur1 = 0;            // link the walk of each env stands on
                 bool live0 = false, live1 = false;  // the env has applied an impulse (until then all its changes are zero and its walk rests)
                 // the move INTO each touched link, from the touched link before it (cyclically): depth of their lowest common ancestor |
-                // depth of the link before << 4 | own depth << 8 | side-entry levels << 12.  (A link has depth + 1 ancestors-or-self: depths from ballots.)
+                // depth of the link before << 4 | own depth << 8 | side-entry levels << 12 (12 bits).  (A link has depth + 1 ancestors-or-self: depths from ballots.)
+                // LIMITS: the walk also stops at the joints that carry limit rows (their block comes right before the contact block of the link)
+                const unsigned v0 = LIMITS ? m0 | lm0 : m0, v1 = LIMITS ? m1 | lm1 : m1;
+                V3 jt_new{0.f, 0.f, 0.f};  // LIMITS: limit impulse of this joint not yet handed up (its reaction, -jt, goes to the parent)
                 int minfo = 0;
                 {
-                    int p0 = m0 ? 31 - __clz(m0) : 0, p1 = m1 ? 31 - __clz(m1) : 0;
-                    for (unsigned s0 = m0, s1 = m1; s0 | s1; s0 &= s0 - 1, s1 &= s1 - 1) {
+                    int p0 = v0 ? 31 - __clz(v0) : 0, p1 = v1 ? 31 - __clz(v1) : 0;
+                    for (unsigned s0 = v0, s1 = v1; s0 | s1; s0 &= s0 - 1, s1 &= s1 - 1) {
                         const int b0 = s0 ? __ffs(s0) - 1 : p0, b1 = s1 ? __ffs(s1) - 1 : p1;
                         const int selp = half ? p1 : p0, selb = half ? b1 : b0;
                         const bool ap = valid && ((desc >> selp) & 1), ab = valid && ((desc >> selb) & 1);
@@ -1152,7 +1155,8 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                                   dl = __popc(half ? (unsigned)(bc >> 32) : (unsigned)bc) - 1;
                         // (levels of the way up where the path link is not its parent's first child: it hands over through a pull, see walk_to)
                         const int sd = (half ? M.side_depths[p1] : M.side_depths[p0]) & ~((2 << dl) - 1);
-                        if (valid && lb == selb && ((half ? s1 : s0) != 0u)) minfo = dl | (du << 4) | (dn << 8) | (sd << 12);
+                        // (bit 28: the link itself is not its parent's first child - the one-joint bounce of a limit block needs it)
+                        if (valid && lb == selb && ((half ? s1 : s0) != 0u)) minfo = dl | (du << 4) | (dn << 8) | (sd << 12) | ((LIMITS && !firstchild) ? 1 << 28 : 0);
                         p0 = b0;
                         p1 = b1;
                     }
@@ -1173,7 +1177,7 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                     const int dlmin = dl0 < dl1 ? dl0 : dl1;
                     // levels (bit d = the links at depth d hand over) that need the long form: a walk turns at their parent, or a path link
                     // is not the first child of its parent (it does not sit in the lane next to it)
-                    const unsigned sideb = (unsigned)(pk0 >> 12) | (unsigned)(pk1 >> 12);
+                    const unsigned sideb = ((unsigned)(pk0 >> 12) | (unsigned)(pk1 >> 12)) & 0xfffu;
                     const unsigned longb = sideb | (dl0 < 15 ? 2u << dl0 : 0u) | (dl1 < 15 ? 2u << dl1 : 0u);
                     // ---- up  (levels in a gap between the two envs' ranges run idle: a range test here makes the compiler run the whole
                     // loop with per-lane exits and d in a VGPR)
@@ -1186,6 +1190,10 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                             cf = fa;
                             un_new = V3{0.f, 0.f, 0.f};
                             uf_new = V3{0.f, 0.f, 0.f};
+                            if (LIMITS) {  // the reaction of the joint's limit impulses: a pure torque on the parent
+                                cn = cn - jt_new;
+                                jt_new = V3{0.f, 0.f, 0.f};
+                            }
                         }
                         if (!((longb >> d) & 1u)) {
                             // every link that hands over is the first child of its parent = the lane before it; the others hand over zeros:
@@ -1251,7 +1259,7 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                     LLSUB(14);
                 };
                 for (int it = 0; it < P.n_iter; ++it) {
-                    unsigned t0 = m0, t1 = m1;
+                    unsigned t0 = v0, t1 = v1;
                     bool moved = false;
                     if (TGS && it > 0) {
                         // gaps advance with the normal velocity the points have after the previous sweep (touched links are current)
@@ -1266,16 +1274,69 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                         if (DIAG && a.prof && ((a.prof_heavy ? blockIdx.x < 8u : (blockIdx.x & 63) == 0)) && lane == 0) atomicAdd((unsigned long long*)&a.prof[8], 1ull);
                         // (readfirstlane: wave-uniform by construction, and the compiler must know it - the level loops are scalar loops)
                         const int smv = __builtin_amdgcn_readfirstlane(((live0 && b0 >= 0 && b0 != cur0) ? 1 : 0) | ((live1 && b1 >= 0 && b1 != cur1) ? 2 : 0));
+                        int came_down = 0;  // LIMITS: bit h = env h has just come DOWN to its link (the lowest common ancestor of the move lies above it)
                         if (smv) {
                             const int i0 = __builtin_amdgcn_readlane(minfo, b0 < 0 ? 0 : b0), i1 = __builtin_amdgcn_readlane(minfo, 32 + (b1 < 0 ? 0 : b1));
                             walk_to(b0 < 0 ? 0 : b0, b1 < 0 ? 0 : b1, i0, i1, (smv & 1) != 0, (smv & 2) != 0);
+                            if (LIMITS) came_down = smv & (((i0 & 15) < ((i0 >> 8) & 15) ? 1 : 0) | ((i1 & 15) < ((i1 >> 8) & 15) ? 2 : 0));
                         }
                         if (b0 >= 0) cur0 = b0;
                         if (b1 >= 0) cur1 = b1;
+                        const int bsel = half ? b1 : b0;
+                        if constexpr (LIMITS) {
+                            // ---- the limit rows of the joint the walk stands on (before the contact rows of its link).  A limit impulse is a
+                            // joint-space impulse: it joins the link's collected impulse, and its reaction, a pure torque, what the link hands up.
+                            const bool hl0 = b0 >= 0 && ((lm0 >> b0) & 1u), hl1 = b1 >= 0 && ((lm1 >> b1) & 1u);
+                            if (hl0 || hl1) {
+                                // one joint up (the parent turns), one joint down again: the move that makes the joint and its parent current
+                                const int m0i = __builtin_amdgcn_readlane(minfo, b0 < 0 ? 0 : b0), m1i = __builtin_amdgcn_readlane(minfo, 32 + (b1 < 0 ? 0 : b1));
+                                const int d0 = (m0i >> 8) & 15, d1 = (m1i >> 8) & 15;
+                                const int j0i = (d0 - 1) | (d0 << 4) | (d0 << 8) | ((((m0i >> 28) & 1) << d0) << 12);
+                                const int j1i = (d1 - 1) | (d1 << 4) | (d1 << 8) | ((((m1i >> 28) & 1) << d1) << 12);
+                                // the rows read the PARENT's velocity as well.  It is current when the walk came down through it; when the walk
+                                // turned at this very link (or never left it) the parent still lacks what this link's subtree has collected since
+                                // - this move hands exactly that up.
+                                const int spre = __builtin_amdgcn_readfirstlane((((live0 && hl0) ? 1 : 0) | ((live1 && hl1) ? 2 : 0)) & ~came_down);
+                                if (spre) walk_to(b0 < 0 ? 0 : b0, b1 < 0 ? 0 : b1, j0i, j1i, (spre & 1) != 0, (spre & 2) != 0);
+                                const V3 wc = w + Dw;
+                                const V3 pw = pp(wc, true);
+                                bool lchg = false;
+                                if (valid && lb == bsel && (half ? hl1 : hl0)) {
+                                    const M3 R = q2mat(Q4{park[PARK_Q * 64], park[(PARK_Q + 1) * 64], park[(PARK_Q + 2) * 64], park[(PARK_Q + 3) * 64]});
+                                    const V3 om0 = mulT(R, wc - pw);  // joint rate, body axes
+                                    float om[3] = {om0.x, om0.y, om0.z}, tq[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                                    for (int i = 0; i < 3; ++i) {
+                                        const V3 kc = i == 0 ? V3{Kd.xx, Kd.xy, Kd.xz} : (i == 1 ? V3{Kd.xy, Kd.yy, Kd.yz} : V3{Kd.xz, Kd.yz, Kd.zz});
+                                        const float kii = i == 0 ? kc.x : (i == 1 ? kc.y : kc.z);
+                                        const float rel = lsgn[i] * om[i] + lbias[i];
+                                        const float nl = fmaxf(llam[i] - rel * __builtin_amdgcn_rcpf(kii), 0.f);
+                                        const float dl = lsgn[i] != 0.f ? nl - llam[i] : 0.f;
+                                        llam[i] += dl;
+                                        const float sdl = lsgn[i] * dl;
+                                        tq[i] = sdl;
+                                        om[0] += kc.x * sdl; om[1] += kc.y * sdl; om[2] += kc.z * sdl;
+                                    }
+                                    const V3 jt = mul(R, V3{tq[0], tq[1], tq[2]});
+                                    un_new = un_new + jt;
+                                    un_tot = un_tot + jt;
+                                    jt_new = jt_new + jt;
+                                    lchg = tq[0] != 0.f || tq[1] != 0.f || tq[2] != 0.f;
+                                }
+                                const unsigned long long lc = __ballot(lchg);
+                                const int sl = __builtin_amdgcn_readfirstlane(((unsigned)lc != 0u ? 1 : 0) | ((unsigned)(lc >> 32) != 0u ? 2 : 0));
+                                if (sl) {
+                                    // the joint answers, and so does everything above it: one joint up (the parent turns), one joint down again
+                                    live0 = live0 || (sl & 1);
+                                    live1 = live1 || (sl & 2);
+                                    moved = true;
+                                    walk_to(b0 < 0 ? 0 : b0, b1 < 0 ? 0 : b1, j0i, j1i, (sl & 1) != 0, (sl & 2) != 0);
+                                }
+                            }
+                        }
                         // ---- the rows of the link the walk stands on
                         long long tsub = DIAG && a.prof ? clock64() : 0;
-                        const int bsel = half ? b1 : b0;
-                        const bool me = valid && lb == bsel;
+                        const bool me = valid && lb == bsel && (!LIMITS || (((half ? m1 : m0) >> (bsel < 0 ? 0 : bsel)) & 1u));
                         V3 gn{0.f, 0.f, 0.f}, gf{0.f, 0.f, 0.f};  // what these rows add to the link's impulse
                         if (me) {
                             V3 wl = w + Dw, xl = xd + Dv;
@@ -1318,6 +1379,45 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                                 }
                                 CS.set_lam(c, V3{ln, l1, l2});
                             }
+                            if (BALL && ballhit) {
+                                // ---- ball x racket points: two-body rows (ball point velocity minus racket point velocity); the ball side is
+                                // a free sphere (1/m, 1/I), the link side goes through Lambda_b like every row of this block
+                                V3 bv{bl[BL_VEL], bl[BL_VEL + 1], bl[BL_VEL + 2]}, bw{bl[BL_ANG], bl[BL_ANG + 1], bl[BL_ANG + 2]};
+#pragma unroll 1
+                                for (int j = 0; j < 2; ++j) {
+                                    volatile float* rk = bl + BL_RK + 16 * j;
+                                    if (rk[RK_A] == 0.f) continue;
+                                    const V3 n{rk[RK_N], rk[RK_N + 1], rk[RK_N + 2]}, rl{rk[RK_RL], rk[RK_RL + 1], rk[RK_RL + 2]};
+                                    V3 t1v, t2v;
+                                    ball_dirs(n, t1v, t2v);
+                                    const V3 rb = -BP.radius * n;
+                                    float lamn = rk[RK_LAM];
+#pragma unroll 1
+                                    for (int ax = 0; ax < 3; ++ax) {
+                                        const V3 dir = ax == 0 ? n : (ax == 1 ? t1v : t2v);
+                                        const V3 jn = cross(rl, dir), jb = cross(rb, dir);
+                                        const V3 yw = mul(Lam.A, jn) + mul(Lam.B, dir);
+                                        const V3 yv = V3{dot(col(Lam.B, 0), jn), dot(col(Lam.B, 1), jn), dot(col(Lam.B, 2), jn)} + mul(Lam.C, dir);
+                                        const float wii = dot(jn, yw) + dot(dir, yv) + BP.inv_mass + BP.inv_inertia * dot(jb, jb);
+                                        const float rel = dot(dir, bv) + dot(jb, bw) - dot(jn, wl) - dot(dir, xl) + (ax == 0 ? rk[RK_BIAS] : 0.f);
+                                        const float old = rk[RK_LAM + ax];
+                                        float nl = old - rel * __builtin_amdgcn_rcpf(wii);
+                                        if (ax == 0) nl = fmaxf(nl, 0.f);
+                                        else { const float lim = BP.fric_racket * lamn; nl = fminf(fmaxf(nl, -lim), lim); }
+                                        const float dl = nl - old;
+                                        rk[RK_LAM + ax] = nl;
+                                        if (ax == 0) lamn = nl;
+                                        bv = bv + (dl * BP.inv_mass) * dir;      // +impulse on the ball
+                                        bw = bw + (dl * BP.inv_inertia) * jb;
+                                        wl = wl - dl * yw;                        // -impulse on the racket's link
+                                        xl = xl - dl * yv;
+                                        gn = gn - dl * jn;
+                                        gf = gf - dl * dir;
+                                    }
+                                }
+                                bl[BL_VEL] = bv.x; bl[BL_VEL + 1] = bv.y; bl[BL_VEL + 2] = bv.z;
+                                bl[BL_ANG] = bw.x; bl[BL_ANG + 1] = bw.y; bl[BL_ANG + 2] = bw.z;
+                            }
                             Dw = wl - w;
                             Dv = xl - xd;
                             un_tot = un_tot + gn;
@@ -1330,6 +1430,35 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                         moved = moved || chg != 0ull;
                         if (DIAG && a.prof && !chg && ((a.prof_heavy ? blockIdx.x < 8u : (blockIdx.x & 63) == 0)) && lane == 0) atomicAdd((unsigned long long*)&a.prof[19], 1ull);
                         LLSUB(11);
+                    }
+                    if (BALL) {
+                        // ---- ball x ground: the last rows of the iteration (point at -R z of the centre; rows n = z, t1 = x, t2 = y)
+                        bool bmoved = false;
+                        if (ballground) {
+                            V3 bv{bl[BL_VEL], bl[BL_VEL + 1], bl[BL_VEL + 2]}, bw{bl[BL_ANG], bl[BL_ANG + 1], bl[BL_ANG + 2]};
+                            const V3 rb{0.f, 0.f, -BP.radius};
+                            float lamn = bl[BL_GLAM];
+#pragma unroll
+                            for (int ax = 0; ax < 3; ++ax) {
+                                const V3 dir = ax == 0 ? V3{0.f, 0.f, 1.f} : (ax == 1 ? V3{1.f, 0.f, 0.f} : V3{0.f, 1.f, 0.f});
+                                const V3 jb = cross(rb, dir);
+                                const float wii = BP.inv_mass + BP.inv_inertia * dot(jb, jb);
+                                const float rel = dot(dir, bv) + dot(jb, bw) + (ax == 0 ? bl[BL_GBIAS] : 0.f);
+                                const float old = bl[BL_GLAM + ax];
+                                float nl = old - rel * __builtin_amdgcn_rcpf(wii);
+                                if (ax == 0) nl = fmaxf(nl, 0.f);
+                                else { const float lim = BP.fric_ground * lamn; nl = fminf(fmaxf(nl, -lim), lim); }
+                                const float dl = nl - old;
+                                bl[BL_GLAM + ax] = nl;
+                                if (ax == 0) lamn = nl;
+                                bv = bv + (dl * BP.inv_mass) * dir;
+                                bw = bw + (dl * BP.inv_inertia) * jb;
+                                bmoved = bmoved || dl != 0.f;
+                            }
+                            bl[BL_VEL] = bv.x; bl[BL_VEL + 1] = bv.y; bl[BL_VEL + 2] = bv.z;
+                            bl[BL_ANG] = bw.x; bl[BL_ANG + 1] = bw.y; bl[BL_ANG + 2] = bw.z;
+                        }
+                        if (any64(bmoved)) moved = true;
                     }
                     if (TGS && (live0 || live1)) {
                         walk_close(maxd);
