@@ -379,11 +379,15 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
     if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->pair_key, sizeof(int32_t) * N), "hipMalloc(pair_key)");
     if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->pair_pos, sizeof(int32_t) * N), "hipMalloc(pair_pos)");
     if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->perm, sizeof(int32_t) * N), "hipMalloc(perm)");
-    if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->pair_hist, sizeof(int32_t) * (2 * PAIR_BINS + 1)), "hipMalloc(pair_hist)");
+    if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->pair_hist, sizeof(int32_t) * (4 * PAIR_BINS + 1)), "hipMalloc(pair_hist)");
+    for (int k = 0; k < 2 && rc == V2P_OK; ++k) rc = check_hip(hipMalloc((void**)&e->pair_list[k], sizeof(int32_t) * PAIR_BINS * (size_t)N), "hipMalloc(pair_list)");
+    if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->pair_slot_env, sizeof(int32_t) * N), "hipMalloc(pair_slot_env)");
     if (rc == V2P_OK) {
-        e->pair_start = e->pair_hist + PAIR_BINS;
-        e->pair_done = e->pair_hist + 2 * PAIR_BINS;
-        rc = check_hip(hipMemset(e->pair_hist, 0, sizeof(int32_t) * (2 * PAIR_BINS + 1)), "hipMemset(pair_hist)");
+        e->pair_starts[0] = e->pair_hist + PAIR_BINS;
+        e->pair_starts[1] = e->pair_hist + 2 * PAIR_BINS;
+        e->pair_start = e->pair_starts[0];
+        e->pair_done = e->pair_hist + 4 * PAIR_BINS;
+        rc = check_hip(hipMemset(e->pair_hist, 0, sizeof(int32_t) * (4 * PAIR_BINS + 1)), "hipMemset(pair_hist)");
     }
     if (rc == V2P_OK) rc = check_hip(hipMemset(e->pair_key, 0, sizeof(int32_t) * N), "hipMemset(pair_key)");
     if (rc == V2P_OK) {
@@ -436,6 +440,8 @@ void v2p_env_destroy(v2p_env* e) {
     if (e->pair_pos) (void)hipFree(e->pair_pos);
     if (e->pair_hist) (void)hipFree(e->pair_hist);
     if (e->perm) (void)hipFree(e->perm);
+    for (int k = 0; k < 2; ++k) if (e->pair_list[k]) (void)hipFree(e->pair_list[k]);
+    if (e->pair_slot_env) (void)hipFree(e->pair_slot_env);
     if (e->wave_times) {
         const size_t nw = ((size_t)e->n / 2 + 1) * (size_t)e->p.nsub;  // (records that were never written stay zero and are skipped)
         std::vector<long long> h(nw * 4);

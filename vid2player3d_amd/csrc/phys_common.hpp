@@ -63,7 +63,13 @@ struct PhysArgs {
     const DevShape* shapes;    // [num_shapes] per-env body shapes (multi-shape batches only)
     const int32_t* env_shape;  // [N] shape of each env
     const float* shape_aug;    // [num_shapes][24] joint-diagonal augmentation of each shape
-    const int32_t* perm;  // [N] wave slot -> env (envs with similar contact load share a wave), NULL = identity
+    // wave slot -> env (envs are handed to waves by contact load): slot -> rank (the heavy x light mix) -> load bin (pl_start) -> env (pl_list);
+    // pl_start NULL = identity.  The launch fills pl_list_next / pair_start for the next one.
+    const int32_t* pl_start;   // [256] first rank of each load bin (0 = heaviest)
+    const int32_t* pl_list;    // [256][N] envs of each bin in arrival order
+    int32_t* pl_list_next;     // [256][N]
+    int32_t pl_mix;            // the `mix` heaviest envs are paired with the `mix` lightest ones
+    int32_t* pl_slot_env;      // [N] env of each wave slot, handed from the job of a pair's first substep to the later ones
     int32_t* pair_hist;   // [256] envs per load bin (0 = heaviest), filled by atomics, consumed + cleared by the last workgroup
     int32_t* pair_start;  // [256] first slot of each bin (exclusive scan of the histogram), written by the last workgroup
     int32_t* pair_done;   // [1] workgroups that have finished

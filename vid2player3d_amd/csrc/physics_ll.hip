@@ -309,8 +309,48 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
     const int bid = mono ? (int)blockIdx.x : a.job_mono + jrel % jcut;
     const int64_t slot = ((int64_t)bid * LL_WPB + (threadIdx.x >> 6)) * 2 + half;
     const bool live_env = slot < N;
+    const bool first_job = mono || sjob == 0, last_job = mono || sjob == a.p.nsub - 1;
+    const bool handed = !mono && sjob > 0;  // the inputs of this job were written by another workgroup of this launch
+    int* const progress = JOBS ? a.job_progress + (bid * LL_WPB + (threadIdx.x >> 6)) : nullptr;
+    if constexpr (JOBS) if (handed) {
+        // wait for the previous substep of this env pair (dispatched before this job: it is running or done)
+        const int want = a.job_epoch * 8 + sjob;
+        if (lane == 0) {
+            int* const errword = a.job_progress + a.job_blocks * LL_WPB;
+            long spins = 0;
+            while (__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+                __builtin_amdgcn_s_sleep(16);
+                ++spins;
+                // ~0.25 s without progress, or another job has already given up: report (v2p_env_check) instead of hanging the GPU
+                if (spins > 500000l || ((spins & 1023) == 0 && __hip_atomic_load(errword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)) {
+                    __hip_atomic_store(errword, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
     int64_t e = live_env ? slot : N - 1;
-    if (a.perm) e = a.perm[e];
+    if (a.pl_start && handed) {
+        // (looked up by the job of the pair's first substep, which has handed it over with everything else)
+        e = __hip_atomic_load(&a.pl_slot_env[live_env ? slot : N - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else if (a.pl_start) {
+        // ---- which env this wave slot simulates: slot -> rank by contact load (the heaviest `mix` envs sit in the even slots 0, 2, ...,
+        // each next to one of the lightest in the odd slot; the rest follows by rank) -> load bin (the last of the 256 bins that starts at
+        // or before the rank: one 16-byte load per lane + four ballots) -> the env that arrived in that bin as number (rank - start).
+        // The tables are what the previous launch left (physics epilogue); looked up here, no kernel has to scatter them in between.
+        const int nn = (int)N, mixn = a.pl_mix;
+        const int64_t sl0 = ((int64_t)bid * LL_WPB + (threadIdx.x >> 6)) * 2;
+        const int s0 = (int)(sl0 < N ? sl0 : N - 1), s1 = (int)(sl0 + 1 < N ? sl0 + 1 : N - 1);
+        const int r0 = s0 < 2 * mixn ? ((s0 & 1) ? nn - 1 - (s0 >> 1) : (s0 >> 1)) : s0 - mixn;
+        const int r1 = s1 < 2 * mixn ? ((s1 & 1) ? nn - 1 - (s1 >> 1) : (s1 >> 1)) : s1 - mixn;
+        const int4 st = ((const int4*)a.pl_start)[lane];
+        const int c0 = __popcll(__ballot(st.x <= r0)) + __popcll(__ballot(st.y <= r0)) + __popcll(__ballot(st.z <= r0)) + __popcll(__ballot(st.w <= r0));
+        const int c1 = __popcll(__ballot(st.x <= r1)) + __popcll(__ballot(st.y <= r1)) + __popcll(__ballot(st.z <= r1)) + __popcll(__ballot(st.w <= r1));
+        const int bin = half ? c1 - 1 : c0 - 1, rk = half ? r1 : r0;
+        e = a.pl_list[(int64_t)bin * N + (rk - a.pl_start[bin])];
+        if (JOBS && !mono && lb == 0 && live_env) __hip_atomic_store(&a.pl_slot_env[slot], (int32_t)e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     // the env index behind an opaque move: addresses formed from it inside the substep loop are computed where they are used instead of
     // being hoisted in front of the loop and kept (spilled: 64-bit pointers, 8 bytes of scratch per lane each) across all of it
     auto env_here = [&]() -> int64_t { int64_t v = e; asm volatile("" : "+v"(v)); return v; };
@@ -369,27 +409,6 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
     }
 #endif
     const int sub0 = mono ? 0 : sjob, sub1 = mono ? nsub : (nsub ? sjob + 1 : 0);  // substeps of this job
-    const bool first_job = mono || sjob == 0, last_job = mono || sjob == P.nsub - 1;
-    const bool handed = !mono && sjob > 0;  // the inputs of this job were written by another workgroup of this launch
-    int* const progress = JOBS ? a.job_progress + (bid * LL_WPB + (threadIdx.x >> 6)) : nullptr;
-    if constexpr (JOBS) if (handed) {
-        // wait for the previous substep of this env pair (dispatched before this job: it is running or done)
-        const int want = a.job_epoch * 8 + sjob;
-        if (lane == 0) {
-            int* const errword = a.job_progress + a.job_blocks * LL_WPB;
-            long spins = 0;
-            while (__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
-                __builtin_amdgcn_s_sleep(16);
-                ++spins;
-                // ~0.25 s without progress, or another job has already given up: report (v2p_env_check) instead of hanging the GPU
-                if (spins > 500000l || ((spins & 1023) == 0 && __hip_atomic_load(errword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)) {
-                    __hip_atomic_store(errword, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    break;
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
     auto ldin = [&](const float* p) -> float { return handed ? cload(p) : *p; };
 
     // ---- state: the root lane carries the root pose/velocity, every other lane its joint
@@ -1896,6 +1915,7 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
             const int pos = atomicAdd(&a.pair_hist[PAIR_BINS - 1 - key], 1);
             a.pair_key[e] = key;
             a.pair_pos[e] = pos;
+            a.pl_list_next[(int64_t)(PAIR_BINS - 1 - key) * N + pos] = (int32_t)e;  // what the next launch looks its envs up in
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's bin counts are in before its ticket is drawn
         int ticket = -1;
@@ -2076,11 +2096,7 @@ int launch_env_pre(v2p_env* env, float* actions, hipStream_t s) {
     a.x_rb = env->buf.rb_state;
     a.n = env->n;
     a.p = env->p;
-    PairView pv{nullptr, nullptr, nullptr, nullptr, 0, 0};
-    if (env_pairing_on(env) && env->pair_have) {  // the wave order of the next physics launch, from the keys the last one left
-        pv = env_pair_view(env);
-        env->pair_have = 0;
-    }
+    PairView pv{nullptr, nullptr, nullptr, nullptr, 0, 0};  // (the physics kernel looks its envs up itself: nothing to scatter here)
     const int64_t threads = env->n * NACT;
     hipLaunchKernelGGL(env_pre_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a, pv);
     return check_hip(hipGetLastError(), "env_pre_kernel");
@@ -2095,24 +2111,25 @@ PairView env_pair_view(const v2p_env* env) {
 }
 
 int launch_env_pairing(v2p_env* env, hipStream_t s) {
+    // (v2p_env_debug_pairing only: the wave order the next launch will look up, as an explicit slot -> env table)
     hipLaunchKernelGGL(pair_scatter_kernel, dim3((unsigned)((env->n + 255) / 256)), dim3(256), 0, s, env_pair_view(env), env->n);
-    env->pair_have = 0;
     return check_hip(hipGetLastError(), "pair_scatter_kernel");
 }
 
 int launch_env_physics_ll(v2p_env* env, hipStream_t s, float* actions, int* fused_post) {
     if (fused_post) *fused_post = 0;
     const bool paired = env_pairing_on(env);
-    if (paired && env->pair_have) {  // pre-physics has not consumed the last launch's keys
-        int rc = launch_env_pairing(env, s);
-        if (rc != V2P_OK) return rc;
-    }
     PhysArgs a = {};
-    a.perm = paired ? env->perm : nullptr;
+    const int buf = env->pair_buf;
+    a.pl_start = (paired && env->pair_have) ? env->pair_starts[buf] : nullptr;
+    a.pl_list = env->pair_list[buf];
+    a.pl_list_next = env->pair_list[1 - buf];
+    a.pl_mix = env_pair_view(env).mix;
+    a.pl_slot_env = env->pair_slot_env;
     a.pair_key = env->pair_key;
     a.pair_pos = env->pair_pos;
     a.pair_hist = paired ? env->pair_hist : nullptr;
-    a.pair_start = env->pair_start;
+    a.pair_start = env->pair_starts[1 - buf];
     a.pair_done = env->pair_done;
     a.model = env->model->dev;
     a.state = env->state;
@@ -2210,7 +2227,11 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s, float* actions, int* fuse
         if (multi) hipLaunchKernelGGL((physics_ll_kernel<false, true, false, false, false, false, false>), grid, block, lds, s, a);
         else hipLaunchKernelGGL((physics_ll_kernel<false, false, false, false, false, false, false>), grid, block, lds, s, a);
     }
-    env->pair_have = paired ? 1 : 0;
+    if (paired) {  // the tables this launch has filled are what the next one reads
+        env->pair_buf = 1 - buf;
+        env->pair_start = env->pair_starts[env->pair_buf];
+        env->pair_have = 1;
+    }
     return check_hip(hipGetLastError(), "physics_ll_kernel");
 }
 

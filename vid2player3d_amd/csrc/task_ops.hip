@@ -463,10 +463,6 @@ __global__ __launch_bounds__(EB_BLOCK) void env_post_kernel(EnvView v) {
 int launch_env_post(v2p_env* env, hipStream_t s) {
     EnvView v = make_view(env);
     unsigned blocks = (unsigned)((env->n + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK);
-    if (env_pairing_on(env) && env->pair_have) {
-        v.pair = env_pair_view(env);
-        env->pair_have = 0;
-    }
     hipLaunchKernelGGL(env_post_kernel, dim3(blocks), dim3(EB_BLOCK), 0, s, v);
     int rc = check_hip(hipGetLastError(), "env_post_kernel");
     if (rc == V2P_OK) env->cur_target = 1 - env->cur_target;

@@ -135,7 +135,11 @@ struct v2p_env {
     int32_t* pair_hist;       // [256] + pair_start [256] + pair_done [1] (one allocation)
     int32_t* pair_start;
     int32_t* pair_done;
-    int32_t* perm;            // [N] wave slot -> env for the next physics launch
+    int32_t* perm;            // [N] wave slot -> env of the next physics launch, materialised for v2p_env_debug_pairing only
+    int32_t* pair_list[2];    // [256][N] envs of each load bin in arrival order: what the NEXT launch looks its envs up in (double
+    int32_t* pair_starts[2];  // [256]    first rank of each bin                  buffered: a launch reads one set and fills the other)
+    int pair_buf;             // the set the next launch reads
+    int32_t* pair_slot_env;   // [N] env of each wave slot of the running launch: looked up by the job of the first substep, read by the later ones
     int pair_period;          // 0 = pairing off (v2p_sim_cfg.pair_envs_by_load = 0), else on
     int substeps_per_sim;     // substeps of one simulate() call
     int substep_jobs;         // v2p_sim_cfg.substep_jobs: the physics launch is cut into (substep, env pair) jobs
