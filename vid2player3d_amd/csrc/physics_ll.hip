@@ -12,7 +12,8 @@
 //     touched link to the next (up to the lowest common ancestor, which answers with its Lambda, and down again); one
 //     root -> leaves pass at the end of the sweep moves every link (see the sweep)
 //   * envs are handed to waves in descending order of their contact load (the heaviest quarter each next to one of the lightest),
-//     a counting sort spread over this kernel's epilogue and a small scatter kernel; an env's arithmetic never depends on
+//     a counting sort spread over this kernel's epilogue (bin histogram + arrival lists) and the next launch's prologue (every wave
+//     looks its two envs up: slot -> rank -> bin -> arrival list); an env's arithmetic never depends on
 //     the env it shares a wave with
 //   * one launch = (substep, env pair) JOBS: the heaviest pairs run their four substeps in one workgroup, the others hand the
 //     state over from job to job through memory (16-byte write-through stores / loads + a progress word per pair)
@@ -1897,7 +1898,7 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
     }
     if (a.pair_hist && last_job) {
         // ---- pairing key of this env (touched links, then the deepest of them: what the sweep's cost follows) into its load bin;
-        // the workgroup that finishes last turns the histogram into bin offsets for the scatter that builds the next launch's order
+        // the workgroup that finishes last turns the histogram into the first rank of every bin, what the next launch's lookup starts from
         // links about to touch (bounding box within the contact offset of the ground after one more control step at the current
         // vertical speed) count like touched ones: a humanoid that falls goes from 2-4 to 12+ touched links within one control
         // step, and a heavy pair that is dispatched late because it was predicted light is the tail of the whole launch (+17 %)
@@ -2052,19 +2053,19 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
     timeline();
 }
 
-// ---- pairing: the sweep of a wave costs max(touched links) of its two envs, so envs are handed to waves in descending order of
-// their contact load (heavy waves first also keeps the tail of the launch short).  A counting sort spread over the kernels that
-// run anyway: every env draws an arrival index in its load bin at the end of the physics kernel (atomics), the workgroup that
-// finishes last scans the 256 bin counts, and the scatter slot = start[bin] + index happens in the next pre-physics kernel (or
-// in the small kernel below when pre-physics is not called between two launches).  The order inside a bin depends on arrival,
-// which is harmless: an env's arithmetic does not depend on the env it shares a wave with (tests: bit-identical results).
+// ---- pairing: a wave costs the union of its two envs' contact structure, so envs are handed to waves in descending order of
+// their contact load (heavy waves first also keeps the tail of the launch short; the heaviest quarter each next to one of the lightest).
+// A counting sort without a sorting kernel: every env draws an arrival index in its load bin at the end of the physics kernel (atomics)
+// and appends itself to the bin's arrival list, the workgroup that finishes last scans the 256 bin counts, and the next launch looks
+// its envs up (prologue of physics_ll_kernel).  The order inside a bin depends on arrival, which is harmless: an env's arithmetic does
+// not depend on the env it shares a wave with (tests: bit-identical results).  The explicit slot -> env table below is built on
+// demand only (v2p_env_debug_pairing).
 __global__ void pair_scatter_kernel(PairView pv, int64_t n) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < n) pair_scatter(pv, e);
 }
 
-// ---- stand-alone pre-physics (the staged API, v2p_env_pre_physics): one thread per action component; also hosts the scatter of
-// the pairing order for the next physics launch
+// ---- stand-alone pre-physics (the staged API, v2p_env_pre_physics): one thread per action component
 __global__ void env_pre_kernel(PhysArgs a, PairView pv) {
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t e = tid / NACT;
