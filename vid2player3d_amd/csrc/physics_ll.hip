@@ -1116,10 +1116,9 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                     park_put3(PARK_W0, w);  // the sweep's total delta-velocity of a link = its velocity at the end - these
                     park_put3(PARK_XD0, xd);
                 }
-                // (per-group propagation, V2P_LL_WALK=0 only) touched links whose parent is the touched link right before them (ascending):
-                // they continue a group (below)
+                // touched links whose parent is the touched link right before them (ascending): they continue a group (below)
                 unsigned chain0 = 0u, chain1 = 0u;
-                if (!WALK) {
+                {
                     int prev = -1;
                     for (unsigned t = m0; t; t &= t - 1) {
                         const int nn = __ffs(t) - 1;
