@@ -265,8 +265,9 @@ int v2p_env_debug_contacts(v2p_env* e, int32_t* out, void* stream);
 /* the same for every substep of the last control step, [N,substeps*control_freq_inv,24,4] (needs v2p_sim_cfg.debug_contacts == 2) */
 int v2p_env_debug_contacts_substeps(v2p_env* e, int32_t* out, void* stream);
 
-/* diagnostics for tests: the wave-slot -> env order used by the last physics launch (`perm`, [N] int32; envs are handed to
- * waves in descending order of their contact load, see DESIGN.md "pairing") and the load key it was built from (`key`, [N]) */
+/* diagnostics for tests: the wave-slot -> env order the NEXT physics launch will look up (`perm`, [N] int32, written out here from the
+ * tables the last launch left; envs are handed to waves in descending order of their contact load, see DESIGN.md "pairing") and the
+ * load key it is built from (`key`, [N]) */
 int v2p_env_debug_pairing(v2p_env* e, int32_t* perm, int32_t* key, void* stream);
 
 /* ---- racket + ball (vid2player/env/tasks/humanoid_smpl_im_mvae.py:367-442 actors, :711-783 physics step; data/assets/
