@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B of the in-tree library against variants/libv2p_<name>.so (default nowalk) on identical inputs (tools/walk_ab.py)
+# A/B of the in-tree library against variants/libv2p_<name>.so (default nowalk) on identical inputs (tools/walk_ab.py).
+# The variant: V2P_FLAGS_PHYSICS_LL="-O3 -DV2P_LL_WALK=0" python -c "from vid2player3d_amd import build; build.build(force=True, lib_out='variants/libv2p_nowalk.so', tag='_nowalk')"
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 L=vid2player3d_amd/libv2p_rollout.so; V=variants/libv2p_${1:-nowalk}.so
 cp $L /tmp/default.so
