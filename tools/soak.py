@@ -5,7 +5,7 @@ task = bench.build_task(8192, 0, 7)
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 n = task.num_envs
 bad = 0
-for i in range(2000):
+for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 2000):
     if i % 32 == 0:
         task.reset()
     a = bench.make_actions(task, 0.25 * torch.randn((n, 75), device="cuda", generator=g))
