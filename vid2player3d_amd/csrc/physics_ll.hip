@@ -1252,7 +1252,8 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                     LLSUB(14);
                 };
                 // the walk returns to the root (its Lambda answers the total) and one root -> leaves pass moves the links down to depth dlast
-                auto walk_close = [&](int dlast) {
+                // (all of them, or those the sweep reads: the links down to the env's deepest stop)
+                auto walk_close = [&](int dlast, bool all) {
                     const int i0 = ((int)__builtin_amdgcn_readlane(dep, cur0) << 4) | (M.side_depths[cur0] << 12);
                     const int i1 = ((int)__builtin_amdgcn_readlane(dep, 32 + cur1) << 4) | (M.side_depths[cur1] << 12);
                     const int slive = __builtin_amdgcn_readfirstlane((live0 ? 1 : 0) | (live1 ? 2 : 0));
@@ -1268,7 +1269,7 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                     for (int d = 1; d <= dlast; ++d) {
                         const bool nc = (nonchain >> d) & 1;
                         const V3 pdw = pp(ddw, nc), pdv = pp(ddv, nc);
-                        if (dep == d) {
+                        if (dep == d && (all || insweep)) {
                             const V3 av = pdv + cross(pdw, r);
                             ddw = mul(Di, aug * pdw + un_tot) - mul(E, av);
                             ddv = av;
@@ -1481,13 +1482,13 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                         if (any64(bmoved)) moved = true;
                     }
                     if (TGS && (live0 || live1)) {
-                        walk_close(maxd);
+                        walk_close(dneed, false);  // (the links below catch up once, after the last iteration)
                         un_tot = un_new = uf_new = Dw = Dv = V3{0.f, 0.f, 0.f};
                         live0 = live1 = false;
                     }
                     if (!TGS && !moved) break;  // a whole iteration without any change: the remaining ones would repeat it (PGS: fixed biases)
                 }
-                if (!TGS && (live0 || live1)) walk_close(maxd);
+                if (!TGS && (live0 || live1)) walk_close(maxd, true);
                 } else
                 for (int it = 0; it < P.n_iter; ++it) {
                     unsigned t0 = m0, t1 = m1, l0 = lm0, l1 = lm1;
@@ -1744,9 +1745,9 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                     if (!TGS && !moved) break;  // a whole iteration without any change: the remaining ones would repeat it (PGS: fixed biases)
                 }
                 // links below the deepest touched one: one catch-up pass with the accumulated motion of their parents
-                // (the walk moves every link when it closes)
+                // (PGS: the walk moves every link when it closes)
                 V3 accw = w - park_get3(PARK_W0), accv = xd - park_get3(PARK_XD0);
-                for (int d = dmin + 1; d <= (WALK ? 0 : maxd); ++d) {
+                for (int d = dmin + 1; d <= ((WALK && !TGS) ? 0 : maxd); ++d) {
                     const bool nc = (nonchain >> d) & 1;
                     V3 pdw = pp(accw, nc), pdv = pp(accv, nc);
                     if (dep == d && !insweep) {
