@@ -1,0 +1,201 @@
+"""Float64 model of the contact sweep on a floating-base tree of spherical joints, two ways (TEST INFRASTRUCTURE, like everything under
+oracle/: nothing in the product imports it):
+
+  * `sweep_dense`  row-wise projected Gauss-Seidel against the DENSE inverse mass matrix: after every row update the velocity of every
+                   link is corrected with Lambda_ba = J_b M^-1 J_a^T - the definition, and what oracle/phys/v2p_phys_oracle.c does;
+  * `sweep_walk`   the same row updates, but the link velocities are kept current by WALKING the tree between the touched links with the
+                   O(n) recursion only (articulated inertias, per-joint maps Y_j, operational-space inverse inertias Lambda_jj): up to
+                   the lowest common ancestor, which answers what arrives with its Lambda, and down again; one root -> leaves pass at
+                   the end.  This is the schedule of vid2player3d_amd/csrc/physics_ll.hip (`WALK`), restated with 6-vectors.
+
+tests/test_walk_algorithm.py checks that the two agree to rounding on the SMPL tree: the walk is an exact reorganisation of the sweep.
+Spatial vectors are [angular; linear] at the link's origin, world axes.  A child's origin sits at r_j from its parent's.
+"""
+import numpy as np
+
+
+def skew(r):
+    return np.array([[0.0, -r[2], r[1]], [r[2], 0.0, -r[0]], [-r[1], r[0], 0.0]])
+
+
+class Tree:
+    def __init__(self, parents, rng, aug=0.05):
+        self.parents = list(parents)
+        n = self.n = len(parents)
+        self.depth = [0] * n
+        for j in range(1, n):
+            self.depth[j] = self.depth[parents[j]] + 1
+        self.r = rng.normal(size=(n, 3)) * 0.3
+        # spatial inertia of every link at its origin: random symmetric positive definite 6x6
+        self.I = []
+        for _ in range(n):
+            a = rng.normal(size=(6, 6))
+            self.I.append(a @ a.T + 0.5 * np.eye(6))
+        self.aug = aug
+        self.S = np.vstack([np.eye(3), np.zeros((3, 3))])  # joint motion subspace: the three angular components
+        # X_j: velocity of link j from its parent's (rigid carry-over): w_j = w_p, v_j = v_p + w_p x r_j
+        self.X = [np.eye(6) for _ in range(n)]
+        for j in range(1, n):
+            self.X[j][3:, :3] = -skew(self.r[j])
+        self._recursions()
+        self._dense()
+
+    def ancestors(self, j):
+        out = [j]
+        while self.parents[j] >= 0:
+            j = self.parents[j]
+            out.append(j)
+        return out  # j ... root
+
+    def lca(self, a, b):
+        pa = self.ancestors(a)
+        sb = set(self.ancestors(b))
+        for x in pa:
+            if x in sb:
+                return x
+        raise AssertionError
+
+    def _recursions(self):
+        n, S = self.n, self.S
+        IA = [m.copy() for m in self.I]
+        self.Dinv, self.Y = [None] * n, [None] * n
+        order = sorted(range(n), key=lambda j: -self.depth[j])
+        for j in order:  # leaves -> root: articulated inertias
+            if j == 0:
+                continue
+            D = S.T @ IA[j] @ S + self.aug * np.eye(3)
+            Dinv = np.linalg.inv(D)
+            Ia = IA[j] - IA[j] @ S @ Dinv @ S.T @ IA[j]
+            IA[self.parents[j]] += self.X[j].T @ Ia @ self.X[j]
+            self.Dinv[j] = Dinv
+            # Delta v_j = Y_j Delta v_parent + S Dinv S^T (impulse collected at j)
+            self.Y[j] = (np.eye(6) - S @ Dinv @ S.T @ IA[j]) @ self.X[j]
+        self.IA = IA
+        # operational-space inverse inertia of every link, root -> leaves
+        self.Lam = [None] * n
+        self.Lam[0] = np.linalg.inv(IA[0])
+        for j in sorted(range(1, n), key=lambda j: self.depth[j]):
+            self.Lam[j] = self.Y[j] @ self.Lam[self.parents[j]] @ self.Y[j].T + S @ self.Dinv[j] @ S.T
+
+    def _dense(self):
+        """link Jacobians J_j [6, 6 + 3 (n-1)] and the inverse of the augmented mass matrix"""
+        n = self.n
+        nd = 6 + 3 * (n - 1)
+        J = [np.zeros((6, nd)) for _ in range(n)]
+        J[0][:, :6] = np.eye(6)
+        for j in sorted(range(1, n), key=lambda j: self.depth[j]):
+            J[j] = self.X[j] @ J[self.parents[j]]
+            J[j][:3, 6 + 3 * (j - 1):6 + 3 * j] += np.eye(3)
+        M = sum(J[j].T @ self.I[j] @ J[j] for j in range(n))
+        M[6:, 6:] += self.aug * np.eye(nd - 6)
+        self.J, self.Minv = J, np.linalg.inv(M)
+
+    def lam_dense(self, b, a):
+        return self.J[b] @ self.Minv @ self.J[a].T
+
+
+def _solve_row(row, v, lam, Laa, mu):
+    """one projected row update at a link: row = (d [6], bias, kind, normal index); returns d_lambda"""
+    d, bias, kind, nidx = row["d"], row["bias"], row["kind"], row["normal"]
+    rel = d @ v + bias
+    new = lam[row["id"]] - rel / (d @ Laa @ d)
+    if kind == "n":
+        new = max(new, 0.0)
+    else:
+        lim = mu * lam[nidx]
+        new = min(max(new, -lim), lim)
+    dl = new - lam[row["id"]]
+    lam[row["id"]] = new
+    return dl
+
+
+def sweep_dense(tree, v0, rows_of, n_iter, mu=1.0):
+    v = [x.copy() for x in v0]
+    lam = {}
+    for a in rows_of:
+        for row in rows_of[a]:
+            lam[row["id"]] = 0.0
+    for _ in range(n_iter):
+        for a in sorted(rows_of):
+            for row in rows_of[a]:
+                dl = _solve_row(row, v[a], lam, tree.Lam[a], mu)
+                if dl != 0.0:
+                    p = row["d"] * dl
+                    for b in range(tree.n):
+                        v[b] = v[b] + tree.lam_dense(b, a) @ p
+    return v, lam
+
+
+def sweep_walk(tree, v0, rows_of, n_iter, mu=1.0, count=None):
+    """count: optional dict that receives the number of up / down level steps and turns (the cost model of DESIGN.md)"""
+    n, S = tree.n, tree.S
+    dlt = [np.zeros(6) for _ in range(n)]    # velocity change of a link since the start of the sweep, valid where the walk stands
+    p_tot = [np.zeros(6) for _ in range(n)]  # impulse a link's subtree has collected so far
+    p_new = [np.zeros(6) for _ in range(n)]  # ... since the link last handed it to its parent
+    lam = {}
+    for a in rows_of:
+        for row in rows_of[a]:
+            lam[row["id"]] = 0.0
+    stat = {"up": 0, "down": 0, "turn": 0}
+
+    def move(cur, nxt):
+        c = tree.lca(cur, nxt)
+        j = cur
+        while j != c:  # up: every link hands what it has collected to its parent
+            p = tree.parents[j]
+            t = tree.X[j].T @ (p_new[j] - tree.IA[j] @ S @ tree.Dinv[j] @ (S.T @ p_new[j]))
+            p_new[j] = np.zeros(6)
+            p_new[p] = p_new[p] + t
+            p_tot[p] = p_tot[p] + t
+            stat["up"] += 1
+            if p == c:  # the lowest common ancestor answers what arrives with its own Lambda
+                dlt[c] = dlt[c] + tree.Lam[c] @ t
+                stat["turn"] += 1
+            j = p
+        path = []
+        j = nxt
+        while j != c:
+            path.append(j)
+            j = tree.parents[j]
+        for j in reversed(path):  # down: the parent's change carried over the joint + the joint's answer to what its subtree holds
+            dlt[j] = tree.Y[j] @ dlt[tree.parents[j]] + S @ tree.Dinv[j] @ (S.T @ p_tot[j])
+            stat["down"] += 1
+
+    touched = sorted(rows_of)
+    cur, live = None, False
+    for _ in range(n_iter):
+        for a in touched:
+            if live and cur is not None and cur != a:
+                move(cur, a)
+            cur = a
+            for row in rows_of[a]:
+                dl = _solve_row(row, v0[a] + dlt[a], lam, tree.Lam[a], mu)
+                if dl != 0.0:
+                    p = row["d"] * dl
+                    dlt[a] = dlt[a] + tree.Lam[a] @ p
+                    p_tot[a] = p_tot[a] + p
+                    p_new[a] = p_new[a] + p
+                    live = True
+    if live:
+        move(cur, 0)
+        for j in sorted(range(1, n), key=lambda j: tree.depth[j]):  # one root -> leaves pass moves every link
+            dlt[j] = tree.Y[j] @ dlt[tree.parents[j]] + S @ tree.Dinv[j] @ (S.T @ p_tot[j])
+    if count is not None:
+        count.update(stat)
+    return [v0[j] + dlt[j] for j in range(n)], lam
+
+
+def random_rows(tree, touched, rng, points=(1, 4)):
+    """contact-like rows per touched link: per point a normal row (lambda >= 0) and two friction rows (|lambda| <= mu lambda_n)"""
+    rows_of, k = {}, 0
+    for a in touched:
+        rows = []
+        for _ in range(int(rng.integers(points[0], points[1] + 1))):
+            rp = rng.normal(size=3) * 0.1
+            nid = k
+            for kind, dirv in (("n", np.array([0.0, 0.0, 1.0])), ("t", np.array([1.0, 0.0, 0.0])), ("t", np.array([0.0, 1.0, 0.0]))):
+                d = np.concatenate([np.cross(rp, dirv), dirv])  # velocity of the point along dirv = d . [w; v]
+                rows.append({"id": k, "d": d, "bias": float(rng.normal() * 0.5 - 1.5) if kind == "n" else 0.0, "kind": kind, "normal": nid})
+                k += 1
+        rows_of[a] = rows
+    return rows_of

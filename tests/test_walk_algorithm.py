@@ -1,0 +1,69 @@
+"""The contact sweep as a walk over the tree (physics_ll.hip `WALK`) is an exact reorganisation of row-wise
+Gauss-Seidel with a dense inverse mass matrix: float64 model on the SMPL tree (oracle/walk_model.py), CPU only."""
+import numpy as np
+import pytest
+
+from oracle.walk_model import Tree, random_rows, sweep_dense, sweep_walk
+
+SMPL_PARENTS = [-1, 0, 1, 2, 3, 0, 5, 6, 7, 0, 9, 10, 11, 12, 11, 14, 15, 16, 17, 11, 19, 20, 21, 22]  # SURVEY 8 a14 (MJCF body order)
+CASES = {
+    "two feet": [3, 4, 7, 8],
+    "one link": [13],
+    "root only": [0],
+    "root and leaves": [0, 4, 18, 23],
+    "a chain": [14, 15, 16, 17, 18],
+    "fallen, scattered": [2, 4, 6, 13, 18, 21, 23],
+    "everything": list(range(24)),
+    "inside one subtree": [15, 17, 18],
+}
+
+
+def test_recursion_matches_the_dense_inverse():
+    """Lambda_jj from the root -> leaves recursion = J_j M^-1 J_j^T, and Lambda_ba = Z(b<-c) Lambda_cc Z(a<-c)^T through the LCA c"""
+    t = Tree(SMPL_PARENTS, np.random.default_rng(1))
+    for j in (0, 4, 11, 18, 23):
+        assert np.allclose(t.Lam[j], t.lam_dense(j, j), atol=1e-10)
+
+    def z(b, c):  # product of the per-joint maps from c down to b
+        m = np.eye(6)
+        path = t.ancestors(b)[:t.ancestors(b).index(c)]
+        for j in reversed(path):
+            m = t.Y[j] @ m
+        return m
+
+    for a, b in ((4, 8), (18, 23), (13, 18), (2, 4), (17, 4)):
+        c = t.lca(a, b)
+        assert np.allclose(z(b, c) @ t.Lam[c] @ z(a, c).T, t.lam_dense(b, a), atol=1e-10), (a, b)
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_walk_equals_the_dense_sweep(name):
+    rng = np.random.default_rng(7 + len(name))
+    t = Tree(SMPL_PARENTS, rng)
+    v0 = [rng.normal(size=6) for _ in range(t.n)]
+    rows = random_rows(t, CASES[name], rng)
+    vd, ld = sweep_dense(t, v0, rows, n_iter=4)
+    stat = {}
+    vw, lw = sweep_walk(t, v0, rows, n_iter=4, count=stat)
+    assert max(abs(ld[k] - lw[k]) for k in ld) < 1e-9
+    assert max(np.abs(vd[j] - vw[j]).max() for j in range(t.n)) < 1e-9
+    assert any(abs(x) > 1e-3 for x in ld.values()), "the fixture must apply impulses"
+    if name == "two feet":
+        # the cost model of DESIGN.md: per iteration the walk goes up and down every edge of the subtree the touched links span once
+        assert stat["up"] <= 4 * 8 + 4 and stat["down"] <= 4 * 8 + 4
+    if name == "inside one subtree":
+        assert stat["turn"] >= 3 and all(np.isfinite(x).all() for x in vw)
+
+
+def test_random_touched_sets():
+    rng = np.random.default_rng(99)
+    t = Tree(SMPL_PARENTS, rng)
+    for _ in range(12):
+        k = int(rng.integers(1, 12))
+        touched = sorted(rng.choice(24, size=k, replace=False).tolist())
+        v0 = [rng.normal(size=6) for _ in range(t.n)]
+        rows = random_rows(t, touched, rng)
+        vd, ld = sweep_dense(t, v0, rows, n_iter=3)
+        vw, lw = sweep_walk(t, v0, rows, n_iter=3)
+        assert max(abs(ld[k2] - lw[k2]) for k2 in ld) < 1e-9, touched
+        assert max(np.abs(vd[j] - vw[j]).max() for j in range(t.n)) < 1e-9, touched
