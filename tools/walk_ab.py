@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """A/B of two builds of the physics kernel on identical inputs: per-env error against the float64 oracle (forced to the kernel's
-contact vertices) after one control step, for standing / fallen / fast fixtures.  usage: python tools/walk_ab.py out.npz"""
+contact vertices) after one control step, for standing / fallen / fast fixtures.  usage: python tools/walk_ab.py out.npz [envs per fixture]"""
 import os
 import sys
 
@@ -13,12 +13,13 @@ from gpu_util import DEV, synth_tables  # noqa: E402
 from vid2player3d_amd.motion_lib import MotionLib  # noqa: E402
 
 mlib = MotionLib(synth_tables(seed=5, num_clips=8, min_frames=60, max_frames=120), DEV)
+NENV = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 out = {}
 for name, kw in (("standing", dict(seed=11, lift=0.0, vel_sigma=0.5)), ("fallen", dict(seed=3, lift=-0.75, vel_sigma=0.2)),
                  ("fast", dict(seed=13, lift=-0.5, vel_sigma=3.0)), ("low", dict(seed=17, lift=-0.9, vel_sigma=1.0))):
-    (got, ref), = T._run_pair(mlib, 512, contact=True, what=name, **kw)
+    (got, ref), = T._run_pair(mlib, NENV, contact=True, what=name, **kw)
     e_dv = np.abs(got["dvel"] - ref["dvel"]).max(axis=1)
-    e_rv = np.abs(got["rb"][..., 7:] - ref["rb"][..., 7:]).reshape(512, -1).max(axis=1)
+    e_rv = np.abs(got["rb"][..., 7:] - ref["rb"][..., 7:]).reshape(NENV, -1).max(axis=1)
     touched = (got["ids"] >= 0).any(axis=2).sum(axis=1)
     out[name + "_dvel"] = got["dvel"]; out[name + "_edv"] = e_dv; out[name + "_erv"] = e_rv; out[name + "_touched"] = touched
     print("%-9s touched mean %.1f max %d | dof-vel err vs oracle: median %.2e p90 %.2e p99 %.2e max %.2e | rb-vel err: median %.2e p99 %.2e max %.2e"

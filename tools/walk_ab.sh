@@ -4,9 +4,9 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 L=vid2player3d_amd/libv2p_rollout.so; V=variants/libv2p_${1:-nowalk}.so
 cp $L /tmp/default.so
-echo "== in-tree"; python tools/walk_ab.py /tmp/a.npz 2>&1 | grep -v "^\[selection\]\|amdgpu.ids"
+echo "== in-tree"; python tools/walk_ab.py /tmp/a.npz ${NENV:-512} 2>&1 | grep -v "^\[selection\]\|amdgpu.ids"
 cp $V $L
-echo "== $V"; python tools/walk_ab.py /tmp/b.npz 2>&1 | grep -v "^\[selection\]\|amdgpu.ids"
+echo "== $V"; python tools/walk_ab.py /tmp/b.npz ${NENV:-512} 2>&1 | grep -v "^\[selection\]\|amdgpu.ids"
 cp /tmp/default.so $L
 python - <<'PY'
 import numpy as np
