@@ -34,7 +34,7 @@ extern "C" {
 #define V2P_NUM_OBS 461
 #define V2P_MOTION_STATE_DIM 331  /* root_pos3 root_rot4 dof_pos69 root_vel3 root_ang_vel3 dof_vel69 key_pos12 rb_pos72 rb_rot96 */
 #define V2P_CONTEXT_DIM 378       /* body_pos72 body_rot96 dof_pos69 body_pos_gt72 dof_pos_gt69 (humanoid_smpl_im.py:202) */
-#define V2P_ABI_VERSION 7
+#define V2P_ABI_VERSION 8
 
 typedef enum {
     V2P_OK = 0,
@@ -275,8 +275,11 @@ int v2p_env_debug_pairing(v2p_env* e, int32_t* perm, int32_t* key, void* stream)
  * body model handed to v2p_model_create (vid2player3d_amd/racket.py builds it), its two solid cylinders are given here in the link's
  * frame for the ball contacts.  The ball is a free sphere simulated alongside the humanoid (same substeps): gravity, the reference's
  * drag + Magnus force re-evaluated before every simulate() call (apply_external_force_to_ball), ball x ground and ball x racket
- * contacts with restitution and friction (material values combined by averaging, PhysX's default).  Ball x humanoid-hull contacts
- * are not modelled.  Link-per-lane schedule, contacts on, PGS. */
+ * contacts with restitution and friction (material values combined by averaging, PhysX's default), and - body_contacts - the ball
+ * against the convex hulls of the humanoid's links (the ball actor collides with every shape of its env, :367-372, 432): one point per
+ * substep, against the nearest hull; the racket's link is left to its cylinders.  Link-per-lane schedule, contacts on, PGS.
+ * The reference's flag bookkeeping around simulate() (bounce test on the ball height at the start of every call, :731-737; racket-hit
+ * poll after it, :773-779) runs inside the step when the flag buffers are given. */
 typedef struct {
     float radius, mass, inertia;                     /* 0.032, 0.057, 4e-5 */
     float restitution_ground, friction_ground;       /* 0.5, 0.9 */
@@ -288,6 +291,10 @@ typedef struct {
     int32_t num_cylinders;                           /* <= 2 */
     float cylinders[2][8];                           /* centre 3, unit axis 3, half length, radius; racket_link's frame */
     float racket_offset[3];                          /* origin of the racket rigid body (index 24 of the reference's tensor) in that frame */
+    float restitution_body, friction_body;           /* ball x a link's hull: 0.5, 0.9 */
+    int32_t body_contacts;                           /* 1: ball x hull contacts on */
+    float bounce_height;                             /* ball height at the start of a simulate() call at or below which the ball "has bounced" (:733) */
+    int32_t poll_racket_hits;                        /* 1: the racket-hit flags are kept (the reference does so when sim.substeps <= 2, :769) */
 } v2p_ball_cfg;
 typedef struct {                  /* caller-owned DEVICE buffers */
     float* ball_state;            /* [N,13] the ball actor's root state (pos quat linvel angvel): read at the start of every step, written at
@@ -296,6 +303,14 @@ typedef struct {                  /* caller-owned DEVICE buffers */
     float* ball_per_sim;          /* [N,control_freq_inv,13] ball state after each simulate() call (what refresh_actor_root_state_tensor shows) */
     int32_t* racket_hit_per_sim;  /* [N,control_freq_inv] racket-ball contact force non-zero after the call (the reference's poll, :773-779) */
     float* ball_contact;          /* [N,2,3] contact force on the ball from the racket / from the ground after the last call */
+    float* ball_body_contact;     /* [N,3] nullable: contact force on the ball from the humanoid's links after the last call */
+    /* the reference's flags, all five or none (nullable): sticky `has_*` (cleared by the caller when it relaunches a ball), `*_now` = set by
+     * this step; bounce_pos = ball position at the start of the call that saw the bounce */
+    uint8_t* has_bounce;          /* [N] */
+    uint8_t* has_bounce_now;      /* [N] */
+    float* bounce_pos;            /* [N,3] */
+    uint8_t* has_racket_contact;      /* [N] */
+    uint8_t* has_racket_contact_now;  /* [N] */
 } v2p_ball_buffers;
 int v2p_env_attach_ball(v2p_env* e, const v2p_ball_cfg* cfg, const v2p_ball_buffers* buffers);
 

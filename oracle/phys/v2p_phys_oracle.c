@@ -76,17 +76,21 @@ typedef struct {
 
 /* ---- racket + ball (vid2player/env/tasks/humanoid_smpl_im_mvae.py:367-442, 711-783; data/assets/tennis_ball.urdf,
  * smpl_mesh_humanoid_djokovic.xml:188-190).  The racket is welded to a link of the articulation (its mass is part of that link's
- * body model, its two cylinders are given here in the link's frame); the ball is a free sphere.  Modelled contacts: ball-ground
- * and ball-racket (sphere against the two solid cylinders); ball against the humanoid's hulls is NOT modelled. */
+ * body model, its two cylinders are given here in the link's frame); the ball is a free sphere.  Modelled contacts: ball-ground,
+ * ball-racket (sphere against the two solid cylinders) and - body_contacts - ball against the convex hulls of the humanoid's links
+ * (the ball actor's collision filter is 0, the humanoid's 1: every pair collides, humanoid_smpl_im_mvae.py:367-372, 432): ONE point per
+ * substep, against the link whose hull is nearest (the racket's link is left to its cylinders). */
 typedef struct { double center[3], axis[3], half_len, radius; } v2p_ocyl;
 typedef struct {
     double radius, mass, inertia;   /* 0.032, 0.057, 4e-5 (tennis_ball.urdf) */
     double rest_ground, fric_ground; /* ball x plane, PhysX default combine = average: (1.0 + 0.0) / 2, (0.8 + 1.0) / 2 */
     double rest_racket, fric_racket; /* ball x racket head: 1.0, 0.8 (humanoid_smpl_im_mvae.py:414-416, 436-438) */
+    double rest_body, fric_body;     /* ball x a link's hull (shape defaults 0 / 1 on the humanoid's side): (1.0 + 0.0) / 2, (0.8 + 1.0) / 2 */
     double bounce_threshold;         /* 0.2 m/s (sim.physx.bounce_threshold_velocity) */
     double ang_damp, max_ang_vel;    /* AssetOptions defaults of the ball asset: 0.5, 64 */
     int racket_link;                 /* 22 = R_Wrist */
     int ncyl;
+    int body_contacts;               /* 1: ball x hull contacts on */
     v2p_ocyl cyl[2];
 } v2p_oball_params;
 typedef struct { double pos[3], quat[4], vel[3], angvel[3]; } v2p_oball;
@@ -469,9 +473,100 @@ static void tangent_basis(const double n[3], double t1[3], double t2[3]) {
     cross(n, t1, t2);
 }
 
+/* ---- closest point of the convex hull of a vertex list to a point (GJK on the points V_i - c with the closest-point-on-simplex
+ * rules of Ericson, "Real-Time Collision Detection" 5.1): barycentric weights of the closest point of a segment / triangle /
+ * tetrahedron to the origin.  tests/test_oracle_ball_hull.py checks it against a quadratic program solved by scipy. */
+static void seg_weights(const double a[3], const double b[3], double w[2]) {
+    double ab[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+    double den = dot3(ab, ab), t = den > 0 ? -dot3(a, ab) / den : 0.0;
+    t = t < 0 ? 0 : (t > 1 ? 1 : t);
+    w[0] = 1 - t; w[1] = t;
+}
+static void tri_weights(const double a[3], const double b[3], const double c[3], double w[3]) {
+    double ab[3], ac[3];
+    for (int i = 0; i < 3; ++i) { ab[i] = b[i] - a[i]; ac[i] = c[i] - a[i]; }
+    double d1 = -dot3(ab, a), d2 = -dot3(ac, a);
+    w[0] = w[1] = w[2] = 0;
+    if (d1 <= 0 && d2 <= 0) { w[0] = 1; return; }
+    double d3 = -dot3(ab, b), d4 = -dot3(ac, b);
+    if (d3 >= 0 && d4 <= d3) { w[1] = 1; return; }
+    double vc = d1 * d4 - d3 * d2;
+    if (vc <= 0 && d1 >= 0 && d3 <= 0) { double v = d1 / (d1 - d3); w[0] = 1 - v; w[1] = v; return; }
+    double d5 = -dot3(ab, c), d6 = -dot3(ac, c);
+    if (d6 >= 0 && d5 <= d6) { w[2] = 1; return; }
+    double vb = d5 * d2 - d1 * d6;
+    if (vb <= 0 && d2 >= 0 && d6 <= 0) { double u = d2 / (d2 - d6); w[0] = 1 - u; w[2] = u; return; }
+    double va = d3 * d6 - d5 * d4;
+    if (va <= 0 && d4 - d3 >= 0 && d5 - d6 >= 0) { double u = (d4 - d3) / ((d4 - d3) + (d5 - d6)); w[1] = 1 - u; w[2] = u; return; }
+    double den = 1.0 / (va + vb + vc);
+    w[1] = vb * den; w[2] = vc * den; w[0] = 1 - w[1] - w[2];
+}
+/* returns 1 when the origin lies inside the tetrahedron */
+static int tet_weights(const double P[4][3], double w[4]) {
+    static const int F[4][4] = {{0, 1, 2, 3}, {0, 2, 3, 1}, {0, 3, 1, 2}, {1, 3, 2, 0}}; /* face, opposite vertex */
+    double best = 1e300;
+    int any = 0;
+    for (int f = 0; f < 4; ++f) {
+        const double *a = P[F[f][0]], *b = P[F[f][1]], *c = P[F[f][2]], *d = P[F[f][3]];
+        double ab[3], ac[3], n[3], ad[3];
+        for (int i = 0; i < 3; ++i) { ab[i] = b[i] - a[i]; ac[i] = c[i] - a[i]; ad[i] = d[i] - a[i]; }
+        cross(ab, ac, n);
+        double so = -dot3(n, a), sd = dot3(n, ad);
+        if (so * sd < 0 || sd == 0) { /* the origin is on the far side of this face (or the tetrahedron is flat) */
+            double t[3], q[3];
+            tri_weights(a, b, c, t);
+            for (int i = 0; i < 3; ++i) q[i] = t[0] * a[i] + t[1] * b[i] + t[2] * c[i];
+            double dd = dot3(q, q);
+            if (dd < best) { best = dd; any = 1; w[0] = w[1] = w[2] = w[3] = 0; w[F[f][0]] = t[0]; w[F[f][1]] = t[1]; w[F[f][2]] = t[2]; }
+        }
+    }
+    return !any;
+}
+/* distance of c from the hull; p = the closest point (c itself when c is inside: distance 0) */
+static double hull_closest(const double *V /*[nv][3]*/, int nv, const double c[3], double p[3]) {
+    double S[4][3], v[3];
+    int idx[4], n = 1;
+    for (int i = 0; i < 3; ++i) v[i] = S[0][i] = V[i] - c[i];
+    idx[0] = 0;
+    for (int it = 0; it < 64; ++it) {
+        int best = 0;
+        double bd = 1e300;
+        for (int k = 0; k < nv; ++k) {
+            double d = v[0] * (V[3 * k] - c[0]) + v[1] * (V[3 * k + 1] - c[1]) + v[2] * (V[3 * k + 2] - c[2]);
+            if (d < bd) { bd = d; best = k; }
+        }
+        double vv = dot3(v, v);
+        if (vv - bd <= 1e-14 * vv + 1e-26) break; /* no vertex lies closer along -v: v is the closest point */
+        int dup = 0;
+        for (int k = 0; k < n; ++k) dup |= idx[k] == best;
+        if (dup) break;
+        for (int i = 0; i < 3; ++i) S[n][i] = V[3 * best + i] - c[i];
+        idx[n++] = best;
+        double w[4] = {0, 0, 0, 0};
+        int inside = 0;
+        if (n == 2) seg_weights(S[0], S[1], w);
+        else if (n == 3) tri_weights(S[0], S[1], S[2], w);
+        else inside = tet_weights((const double(*)[3])S, w);
+        if (inside) { v[0] = v[1] = v[2] = 0; break; }
+        int m = 0;
+        for (int i = 0; i < 3; ++i) v[i] = 0;
+        for (int k = 0; k < n; ++k)
+            if (w[k] > 0) {
+                for (int i = 0; i < 3; ++i) v[i] += w[k] * S[k][i];
+                if (m != k) { memcpy(S[m], S[k], sizeof(S[0])); idx[m] = idx[k]; }
+                ++m;
+            }
+        n = m;
+        if (dot3(v, v) < 1e-24) { v[0] = v[1] = v[2] = 0; break; }
+    }
+    for (int i = 0; i < 3; ++i) p[i] = c[i] + v[i];
+    return sqrt(dot3(v, v));
+}
+double v2p_oracle_hull_closest(const double *V, int nv, const double c[3], double p[3]) { return hull_closest(V, nv, c, p); }
+
 #define NDT (ND + 6) /* generalized velocity with the ball appended: [articulation ND | ball linear 3 | ball angular 3] */
 typedef struct {
-    int kind;     /* 0 hull vertex x ground, 1 ball x racket cylinder, 2 ball x ground, 3 joint limit (one row: DOF `vert` of joint `body`) */
+    int kind;     /* 0 hull vertex x ground, 1 ball x racket cylinder, 2 ball x ground, 3 joint limit (one row: DOF `vert` of joint `body`), 4 ball x the hull of link `body` */
     int body, vert;
     double pos[3]; /* contact point, world */
     double n[3], t1[3], t2[3];
@@ -482,7 +577,7 @@ static int substep_impl(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s
                         const double *ext_force /*[3] world, at root COM*/, const double *ext_torque /*[3] world*/,
                         double *contact_force /*[NB*3] out*/, double *dof_force /*[69] out*/, int *contact_ids /*[NB*4] out: body*64+vertex, -1 padded*/,
                         const v2p_osub_io *io, const v2p_oball_params *bp, v2p_oball *ball, const double *ball_force /*[3] world*/,
-                        double *ball_contact /*[6] out: force on the ball from the racket, from the ground*/) {
+                        double *ball_contact /*[9] out: force on the ball from the racket, from the ground, from the humanoid's links*/) {
     double M[ND * ND], C[ND], J[6 * ND];
     double rhs[ND], q[3 * NJ];
     kin_t k;
@@ -522,7 +617,7 @@ static int substep_impl(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s
 
     /* contacts */
     if (contact_force) memset(contact_force, 0, sizeof(double) * NB * 3);
-    if (ball_contact) memset(ball_contact, 0, sizeof(double) * 6);
+    if (ball_contact) memset(ball_contact, 0, sizeof(double) * 9);
     if (contact_ids) for (int i = 0; i < NB * 4; ++i) contact_ids[i] = -1;
     if (p->enable_contact || p->joint_limits) {
         contacts_t cs;
@@ -536,8 +631,51 @@ static int substep_impl(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s
          * to the rate of the exp-map component to first order), sign +1 (lower) / -1 (upper); bias like a contact's normal row
          * (C/h separated - only an approach that would cross the limit within the substep is stopped -, erp C/h violated); impulse
          * >= 0.  Order: the limit rows of joint b right before the hull points of body b. */
-        crow_t rows[NB * MAXC_BODY + 3 + 3 * NJ];
+        crow_t rows[NB * MAXC_BODY + 4 + 3 * NJ];
         int nc = 0, ci = 0;
+        /* ball x humanoid: the hull (convex hull of the link's contact vertices) nearest to the ball carries one point, found at the
+         * start of the substep; activation and bias exactly like a racket point.  A ball centre INSIDE a hull (more than a radius deep:
+         * not reachable through the speculative rows unless it is placed there) is pushed out along the direction from the centre of
+         * the hull's body-frame bounding box. */
+        int hull_link = -1;
+        crow_t hull_row;
+        if (ball && bp->body_contacts && p->enable_contact) {
+            double best = 1e300;
+            for (int b = 0; b < NB; ++b) {
+                if (b == bp->racket_link) continue;
+                const int v0 = m->hull_offsets[b], nv = m->hull_offsets[b + 1] - v0;
+                if (nv <= 0) continue;
+                double d[3] = {ball->pos[0] - k.x[b][0], ball->pos[1] - k.x[b][1], ball->pos[2] - k.x[b][2]}, cb[3], pb[3], pt[3], n[3];
+                for (int i = 0; i < 3; ++i) cb[i] = k.R[b][i] * d[0] + k.R[b][3 + i] * d[1] + k.R[b][6 + i] * d[2]; /* R^T d */
+                double dist = hull_closest(m->hull_verts + 3 * v0, nv, cb, pb);
+                if (dist > 1e-6) for (int i = 0; i < 3; ++i) n[i] = (cb[i] - pb[i]) / dist;
+                else {
+                    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, e[3];
+                    for (int q = 0; q < nv; ++q) for (int i = 0; i < 3; ++i) { double x = m->hull_verts[3 * (v0 + q) + i]; lo[i] = fmin(lo[i], x); hi[i] = fmax(hi[i], x); }
+                    for (int i = 0; i < 3; ++i) e[i] = cb[i] - 0.5 * (lo[i] + hi[i]);
+                    double l = sqrt(dot3(e, e));
+                    if (l > 1e-9) for (int i = 0; i < 3; ++i) n[i] = e[i] / l; else { n[0] = 0; n[1] = 0; n[2] = 1; }
+                    dist = 0.0;
+                    memcpy(pb, cb, sizeof(pb));
+                }
+                double nw[3], rl[3], wr[3];
+                matvec(k.R[b], n, nw);
+                matvec(k.R[b], pb, rl);
+                for (int i = 0; i < 3; ++i) pt[i] = k.x[b][i] + rl[i];
+                cross(k.w[b], rl, wr);
+                double vrel = 0;
+                for (int i = 0; i < 3; ++i) vrel += (ball->vel[i] - k.xd[b][i] - wr[i]) * nw[i];
+                const double gapb = dist - bp->radius;
+                if (gapb < p->contact_offset + h * fmax(0.0, -vrel) && gapb < best) {
+                    best = gapb; hull_link = b;
+                    memset(&hull_row, 0, sizeof(hull_row));
+                    hull_row.kind = 4; hull_row.body = b; hull_row.vert = 0;
+                    memcpy(hull_row.pos, pt, sizeof(pt)); memcpy(hull_row.n, nw, sizeof(nw));
+                    tangent_basis(nw, hull_row.t1, hull_row.t2);
+                    hull_row.gap = gapb; hull_row.mu = bp->fric_body; hull_row.rest = bp->rest_body;
+                }
+            }
+        }
         for (int b = 0; b < NB; ++b) {
             if (p->joint_limits && b >= 1)
                 for (int i = 0; i < 3; ++i) {
@@ -558,6 +696,7 @@ static int substep_impl(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s
                 r->n[0] = 0; r->n[1] = 0; r->n[2] = 1; r->t1[0] = 1; r->t1[1] = 0; r->t1[2] = 0; r->t2[0] = 0; r->t2[1] = 1; r->t2[2] = 0;
                 r->gap = cs.pos[ci][2]; r->mu = p->mu; r->rest = 0.0;
             }
+            if (b == hull_link) rows[nc++] = hull_row;
             if (ball && b == bp->racket_link)
                 for (int j = 0; j < bp->ncyl; ++j) {
                     double cw[3], aw[3], pt[3], n[3];
@@ -595,7 +734,7 @@ static int substep_impl(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s
         double *wii = Tr + (size_t)(nrow > 0 ? nrow : 1) * NDT;
         double *lam = wii + (nrow > 0 ? nrow : 1);
         double *bias = lam + (nrow > 0 ? nrow : 1);
-        double gap[NB * MAXC_BODY + 3 + 3 * NJ];
+        double gap[NB * MAXC_BODY + 4 + 3 * NJ];
         int slot_in_body[NB];
         memset(slot_in_body, 0, sizeof(slot_in_body));
         for (int c = 0; c < nc; ++c) {
@@ -624,10 +763,10 @@ static int substep_impl(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s
                     }
                 } else { /* B = the ball */
                     double rb[3] = {r->pos[0] - ball->pos[0], r->pos[1] - ball->pos[1], r->pos[2] - ball->pos[2]}, rxn[3];
-                    if (r->kind == 1) for (int i = 0; i < 3; ++i) rb[i] = -bp->radius * r->n[i]; /* the ball's own contact point */
+                    if (r->kind == 1 || r->kind == 4) for (int i = 0; i < 3; ++i) rb[i] = -bp->radius * r->n[i]; /* the ball's own contact point */
                     cross(rb, dirs[a], rxn);
                     for (int l = 0; l < 3; ++l) { jr[ND + l] = dirs[a][l]; jr[ND + 3 + l] = rxn[l]; }
-                    if (r->kind == 1) { /* minus the racket point */
+                    if (r->kind == 1 || r->kind == 4) { /* minus the point of the link */
                         double rl[3] = {r->pos[0] - k.x[r->body][0], r->pos[1] - k.x[r->body][1], r->pos[2] - k.x[r->body][2]};
                         cross(rl, dirs[a], rxn);
                         for (int col = 0; col < ND; ++col) {
@@ -647,7 +786,7 @@ static int substep_impl(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s
             double d = r->gap;
             gap[c] = d;
             bias[3 * c] = d >= 0 ? d / h : fmax(p->erp * d / h, -p->max_depen_vel);
-            if (r->kind == 1 || r->kind == 2) { /* restitution (Newton): an approach faster than the bounce threshold that closes the gap within this substep
+            if (r->kind == 1 || r->kind == 2 || r->kind == 4) { /* restitution (Newton): an approach faster than the bounce threshold that closes the gap within this substep
                                  * leaves with rest x the approach speed */
                 double vn0 = 0;
                 for (int col = 0; col < NDT; ++col) vn0 += Jr[3 * c * NDT + col] * v[col];
@@ -698,6 +837,10 @@ static int substep_impl(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s
                 if (contact_force) for (int i = 0; i < 3; ++i) contact_force[3 * r->body + i] -= f[i];
             }
             if (r->kind == 2 && ball_contact) for (int i = 0; i < 3; ++i) ball_contact[3 + i] += f[i];
+            if (r->kind == 4) {
+                if (ball_contact) for (int i = 0; i < 3; ++i) ball_contact[6 + i] += f[i];
+                if (contact_force) for (int i = 0; i < 3; ++i) contact_force[3 * r->body + i] -= f[i];
+            }
         }
         free(Jr);
     }
@@ -772,12 +915,12 @@ void v2p_oracle_ball_aero(const v2p_oball *ball, double spin_scale, double force
 /* one control step with racket + ball: `nsub` substeps in simulate() calls of `sub_per_sim` substeps; the aerodynamic force is
  * re-evaluated at the start of every simulate() call.  ball_per_sim [nsim][13] (pos quat vel angvel after each call),
  * racket_hit_per_sim [nsim] (1 when the racket-ball contact force was non-zero in the call's last substep, as the reference polls the
- * net contact force tensor after each call), ball_contact [6] of the last substep. */
+ * net contact force tensor after each call), ball_contact [9] of the last substep (from the racket, the ground, the humanoid's links). */
 int v2p_oracle_step_ball(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s, const double *pd_target, const double *ext_force,
                          const double *ext_torque, int nsub, int hold, int sub_per_sim, double *contact_force, double *dof_force, int *contact_ids,
                          const v2p_oball_params *bp, v2p_oball *ball, double spin_scale, double *ball_per_sim, int *racket_hit_per_sim,
                          double *ball_contact) {
-    double f[3] = {0, 0, 0}, bc[6];
+    double f[3] = {0, 0, 0}, bc[9];
     for (int i = 0; i < nsub; ++i) {
         if (i % sub_per_sim == 0) v2p_oracle_ball_aero(ball, spin_scale, f);
         int on = i < hold;

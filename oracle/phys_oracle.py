@@ -35,8 +35,9 @@ class OCyl(C.Structure):
 
 class OBallParams(C.Structure):
     _fields_ = [("radius", C.c_double), ("mass", C.c_double), ("inertia", C.c_double), ("rest_ground", C.c_double), ("fric_ground", C.c_double),
-                ("rest_racket", C.c_double), ("fric_racket", C.c_double), ("bounce_threshold", C.c_double), ("ang_damp", C.c_double),
-                ("max_ang_vel", C.c_double), ("racket_link", C.c_int), ("ncyl", C.c_int), ("cyl", OCyl * 2)]
+                ("rest_racket", C.c_double), ("fric_racket", C.c_double), ("rest_body", C.c_double), ("fric_body", C.c_double),
+                ("bounce_threshold", C.c_double), ("ang_damp", C.c_double),
+                ("max_ang_vel", C.c_double), ("racket_link", C.c_int), ("ncyl", C.c_int), ("body_contacts", C.c_int), ("cyl", OCyl * 2)]
 
 
 class OBall(C.Structure):
@@ -99,6 +100,17 @@ def _omodel(body_model, kp=None, kd=None, armature=None):
     return m, hv
 
 
+def hull_closest(verts, c):
+    """(distance, closest point) of the convex hull of `verts` [n,3] to the point c (the GJK the ball x hull contacts use)."""
+    v = np.ascontiguousarray(verts, dtype=np.float64)
+    cc = np.ascontiguousarray(c, dtype=np.float64)
+    p = np.zeros(3)
+    fn = lib().v2p_oracle_hull_closest
+    fn.restype = C.c_double
+    d = fn(_dptr(v), int(len(v)), _dptr(cc), _dptr(p))
+    return float(d), p
+
+
 class PhysOracle:
     """One humanoid per instance; batches are Python loops (small cases only)."""
 
@@ -143,13 +155,13 @@ class PhysOracle:
         return cf, df, ids.reshape(NB, 4)
 
     # ---- racket + ball
-    def attach_ball(self, geom, ball=None, material=None, spin_scale=1.0):
+    def attach_ball(self, geom, ball=None, material=None, spin_scale=1.0, body_contacts=True):
         """geom: the dict vid2player3d_amd.racket.with_racket returns (or None: ball without racket); ball / material: overrides of
-        racket.BALL / racket.BALL_MATERIAL."""
+        racket.BALL / racket.BALL_MATERIAL; body_contacts: ball x hull contacts on."""
         from vid2player3d_amd import racket as R
 
         b, mat = dict(R.BALL, **(ball or {})), dict(R.BALL_MATERIAL, **(material or {}))
-        bp = OBallParams(radius=b["radius"], mass=b["mass"], inertia=b["inertia"], racket_link=-1, ncyl=0, **mat)
+        bp = OBallParams(radius=b["radius"], mass=b["mass"], inertia=b["inertia"], racket_link=-1, ncyl=0, body_contacts=int(body_contacts), **mat)
         if geom is not None:
             bp.racket_link = int(geom["racket_link"])
             bp.ncyl = len(geom["cylinders"])
@@ -171,7 +183,7 @@ class PhysOracle:
         [nsim,13], racket-hit flag per simulate() [nsim], force on the ball from racket / ground in the last substep [2,3])."""
         cf, df, ids = np.zeros((NB, 3)), np.zeros(69), np.full(NB * 4, -1, dtype=np.int32)
         nsim = nsub // sub_per_sim
-        per_sim, hit, bc = np.zeros((nsim, 13)), np.zeros(nsim, dtype=np.int32), np.zeros(6)
+        per_sim, hit, bc = np.zeros((nsim, 13)), np.zeros(nsim, dtype=np.int32), np.zeros(9)
         tar = None if pd_target is None else np.ascontiguousarray(pd_target, dtype=np.float64)
         f = None if ext_force is None else np.ascontiguousarray(ext_force, dtype=np.float64)
         t = None if ext_torque is None else np.ascontiguousarray(ext_torque, dtype=np.float64)
@@ -180,7 +192,8 @@ class PhysOracle:
                                            C.c_double(self.spin_scale), _dptr(per_sim), _iptr(hit), _dptr(bc))
         if rc:
             raise RuntimeError("oracle ball step failed (%d)" % rc)
-        return cf, df, ids.reshape(NB, 4), per_sim, hit, bc.reshape(2, 3)
+        self.ball_body_force = bc[6:9].copy()  # force on the ball from the humanoid's links, last substep
+        return cf, df, ids.reshape(NB, 4), per_sim, hit, bc[:6].reshape(2, 3)
 
     def diagnostics(self):
         out = np.zeros(8)

@@ -43,6 +43,23 @@ def _launch(task, rng, mode):
         ball[:, 2] = rng.uniform(0.03, 0.25, n)
         ball[:, 7:10] = np.stack([rng.normal(0, 6, n), rng.normal(0, 6, n), rng.uniform(-12, 1, n)], 1)
         ball[:, 10:13] = rng.normal(0, 60, (n, 3))
+    elif mode == "body":
+        # aimed at the hull of a link of each env (not the racket's), from a random direction
+        bm = task.body_model
+        off = np.asarray(bm.hull_offsets)
+        hv = np.asarray(bm.hull_verts, dtype=np.float64)
+        for e in range(n):
+            b = int(rng.choice([0, 1, 2, 5, 6, 9, 10, 11, 12, 13, 14, 15, 16, 17, 19, 20, 21, 23]))
+            Rw = Rotation.from_quat(rb[e, b, 3:7]).as_matrix()
+            v = hv[off[b]:off[b + 1]]
+            target = rb[e, b, 0:3] + Rw @ (0.5 * (v.min(0) + v.max(0)))
+            d = rng.normal(size=3)
+            d[2] = abs(d[2])
+            d /= np.linalg.norm(d)
+            speed = rng.uniform(4, 30)
+            ball[e, 0:3] = target + rng.uniform(0.2, 0.45) * d
+            ball[e, 7:10] = -speed * d + rng.normal(0, 1, 3) + rb[e, b, 7:10]
+            ball[e, 10:13] = rng.normal(0, 80, 3)
     else:
         geom = task.racket_geometry
         for e in range(n):
@@ -58,12 +75,13 @@ def _launch(task, rng, mode):
     return ball
 
 
-@pytest.mark.parametrize("mode,lift,limits", [("flight", 0.0, False), ("ground", 0.0, False), ("hit", 0.4, False), ("hit", 0.0, False), ("hit", 0.0, True)])
+@pytest.mark.parametrize("mode,lift,limits", [("flight", 0.0, False), ("ground", 0.0, False), ("hit", 0.4, False), ("hit", 0.0, False), ("hit", 0.0, True),
+                                              ("body", 0.4, False), ("body", 0.0, True)])
 def test_ball_step_matches_oracle(mlib, mode, lift, limits):
     """limits: with the joint ranges of the player MJCF's racket arm enforced (v2p_sim_cfg.joint_limits) - the wrist's limit rows, its
     hull points and the ball x racket rows then all belong to the same link."""
     n = 32
-    rng = np.random.default_rng({"flight": 1, "ground": 2, "hit": 3}[mode] + int(10 * lift))
+    rng = np.random.default_rng({"flight": 1, "ground": 2, "hit": 3, "body": 4}[mode] + int(10 * lift))
     task = make_rb_task(n, mlib, joint_limits=limits)
     task.reset_with_times(None, T(rng.uniform(0.1, 1.0, size=n)))
     root = N(task._humanoid_root_states).copy()
@@ -86,7 +104,7 @@ def test_ball_step_matches_oracle(mlib, mode, lift, limits):
     task._rigid_body_state[:] = T(np.stack([o.get_state()[3] for o in oracles]).reshape(n * 24, 13))
     ball = _launch(task, rng, mode)
     task._ball_root_states[:] = T(ball)
-    hits_total, ground_total = 0, 0
+    hits_total, ground_total, body_total = 0, 0, 0
     for step in range(2):
         act = np.concatenate([N(task._target_dof_pos) + rng.normal(0, 0.17, (n, 69)), rng.normal(0, 0.17, (n, 6))], axis=1).astype(np.float32)
         rb0 = N(task._rigid_body_state).reshape(n, 24, 13).copy()
@@ -97,12 +115,12 @@ def test_ball_step_matches_oracle(mlib, mode, lift, limits):
         task._physics_step()
         torch.cuda.synchronize()
         _, pd, _, force, torque = O.pre_physics(act, N(task.reset_buf), dpos_before, rb0[:, 0, 3:7], bm.kp.astype(np.float32))
-        per_sim, hit, bc, rbs, ids, cf = [], [], [], [], [], []
+        per_sim, hit, bc, rbs, ids, cf, bbf = [], [], [], [], [], [], []
         for e in range(n):
             oracles[e].set_ball(ball_before[e])
             c, _, i, ps, h, b = oracles[e].step_ball(pd_target=pd[e], ext_force=force[e], ext_torque=torque[e], nsub=4, hold=2, sub_per_sim=2)
-            per_sim.append(ps); hit.append(h); bc.append(b); rbs.append(oracles[e].get_state()[3]); ids.append(i); cf.append(c)
-        per_sim, hit, bc, rbs, ids, cf = map(np.stack, (per_sim, hit, bc, rbs, ids, cf))
+            per_sim.append(ps); hit.append(h); bc.append(b); rbs.append(oracles[e].get_state()[3]); ids.append(i); cf.append(c); bbf.append(oracles[e].ball_body_force)
+        per_sim, hit, bc, rbs, ids, cf, bbf = map(np.stack, (per_sim, hit, bc, rbs, ids, cf, bbf))
         assert np.array_equal(N(task.debug_contacts()), ids), "hull contact vertices differ"
         got_ps = N(task._ball_states_per_sim)
         close(got_ps[..., 0:3], per_sim[..., 0:3], 2e-5, "%s ball pos (step %d)" % (mode, step))
@@ -113,6 +131,7 @@ def test_ball_step_matches_oracle(mlib, mode, lift, limits):
         assert np.array_equal(N(task._ball_root_states), got_ps[:, -1])
         assert np.array_equal(N(task._racket_ball_contact_per_sim), hit), "racket hit flags"
         close(N(task._ball_contact_forces), bc, 2e-2, "contact forces on the ball")
+        close(N(task._ball_body_contact_force), bbf, 2e-2, "contact force on the ball from the humanoid's links")
         rb = N(task._rigid_body_state).reshape(n, 24, 13)
         close(rb[..., 0:3], rbs[..., 0:3], 2e-5, "rb pos")
         close(rb[..., 7:13], rbs[..., 7:13], 1e-3, "rb vel")
@@ -124,11 +143,14 @@ def test_ball_step_matches_oracle(mlib, mode, lift, limits):
         close(N(task._racket_rb_state)[:, 7:10], rbs[:, 22, 7:10] + np.cross(rbs[:, 22, 10:13], off), 1e-3, "racket vel")
         hits_total += int(hit.sum())
         ground_total += int(((ball_before[:, 9] < -0.5) & (got_ps[:, -1, 9] > 0)).sum())  # balls that bounced within this control step
+        body_total += int(((np.linalg.norm(got_ps[:, -1, 7:10] - ball_before[:, 7:10], axis=1) > 3.0) & (hit.sum(1) == 0) & (got_ps[:, -1, 2] > 0.1)).sum())  # deflected by a hull
         task.post_physics_step()
     if mode == "hit":
         assert hits_total >= n // 4, "the fixture must produce racket hits (%d)" % hits_total
     if mode == "ground":
         assert ground_total >= n // 4, ground_total
+    if mode == "body":
+        assert body_total >= n // 4, "the fixture must produce ball x hull hits (%d)" % body_total
     task.close()
 
 

@@ -126,3 +126,45 @@ def test_racket_hit_exchanges_momentum(models):
     # (test_phys_oracle.py::test_free_flight_conserves_momentum_and_energy quantifies that drift)
     assert np.abs(p1 - p0).max() < 2e-2
     assert np.linalg.norm(o.get_state()[3][22, 7:10]) > 0.05  # the wrist was pushed
+
+
+def test_ball_bounces_off_a_link(models):
+    """Ball x hull contacts: a ball thrown at the chest of a floating, limp humanoid bounces off with about half its approach speed
+    (restitution (1 + 0) / 2 against a link that is far heavier than the ball), total linear momentum is conserved, and the racket-hit
+    flags stay clear; with body_contacts off the same ball flies through."""
+    _, (m, geom) = models
+    zeros = np.zeros(69)
+    out = {}
+    for on in (True, False):
+        o = PhysOracle(m, default_params(gravity_z=0.0, ang_damp=0.0), kp=zeros, kd=zeros)
+        root = np.zeros(13); root[2] = 3.0; root[3:7] = BASE
+        o.set_state(root, zeros, zeros)
+        o.attach_ball(geom, material={"ang_damp": 0.0}, body_contacts=on)
+        rb = o.get_state()[3]
+        from scipy.spatial.transform import Rotation
+
+        b = 11  # Chest
+        off = np.asarray(m.hull_offsets)
+        v = np.asarray(m.hull_verts)[off[b]:off[b + 1]]
+        centre = rb[b, 0:3] + Rotation.from_quat(rb[b, 3:7]).as_matrix() @ (0.5 * (v.min(0) + v.max(0)))
+        d = np.array([1.0, 0.0, 0.0])  # the humanoid faces +x in this pose
+        ball = np.zeros(13); ball[6] = 1
+        ball[0:3] = centre + 0.5 * d
+        ball[7:10] = -8.0 * d
+        o.set_ball(ball)
+        p0 = o.diagnostics()["P"] + 0.057 * ball[7:10]
+        hits, force = [], 0.0
+        for _ in range(4):
+            *_, per_sim, hit, bc = o.step_ball(nsub=4, hold=0, sub_per_sim=2)
+            hits += hit.tolist()
+            force = max(force, np.abs(o.ball_body_force).max())
+        bb = o.get_ball()
+        p1 = o.diagnostics()["P"] + 0.057 * bb[7:10]
+        out[on] = (bb, p0, p1, hits, o.get_state()[3][b, 7:10].copy())
+    bb, p0, p1, hits, vchest = out[True]
+    assert sum(hits) == 0
+    assert bb[7] > 1.0 and 3.0 < np.linalg.norm(bb[7:10]) < 5.0, bb[7:10]  # came back, off an oblique surface, with ~ half of 8 m/s (friction and the limp torso take a little more)
+    assert np.abs(p1 - p0).max() < 2e-2         # (drag on the ball + the first-order drift of the limp chain, see the racket test)
+    assert vchest[0] < -1e-3                    # the chest was pushed back
+    bb_off = out[False][0]
+    assert bb_off[7] < -7.0                     # without the hull contacts the ball keeps flying (only drag)

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "libv2p_rollout.so")
 
 NUM_BODIES, NUM_DOF, NUM_ACTIONS, NUM_OBS = 24, 69, 75, 461
 MOTION_STATE_DIM, CONTEXT_DIM = 331, 378
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_f = C.POINTER(C.c_float)
 c_i32 = C.POINTER(C.c_int32)
@@ -55,11 +55,15 @@ class BallCfg(C.Structure):
     _fields_ = [("radius", C.c_float), ("mass", C.c_float), ("inertia", C.c_float), ("restitution_ground", C.c_float), ("friction_ground", C.c_float),
                 ("restitution_racket", C.c_float), ("friction_racket", C.c_float), ("bounce_threshold_velocity", C.c_float),
                 ("angular_damping", C.c_float), ("max_angular_velocity", C.c_float), ("spin_scale", C.c_float), ("racket_link", C.c_int32),
-                ("num_cylinders", C.c_int32), ("cylinders", (C.c_float * 8) * 2), ("racket_offset", C.c_float * 3)]
+                ("num_cylinders", C.c_int32), ("cylinders", (C.c_float * 8) * 2), ("racket_offset", C.c_float * 3),
+                ("restitution_body", C.c_float), ("friction_body", C.c_float), ("body_contacts", C.c_int32), ("bounce_height", C.c_float),
+                ("poll_racket_hits", C.c_int32)]
 
 
 class BallBuffers(C.Structure):
-    _fields_ = [("ball_state", vp), ("racket_state", vp), ("ball_per_sim", vp), ("racket_hit_per_sim", vp), ("ball_contact", vp)]
+    _fields_ = [("ball_state", vp), ("racket_state", vp), ("ball_per_sim", vp), ("racket_hit_per_sim", vp), ("ball_contact", vp),
+                ("ball_body_contact", vp), ("has_bounce", vp), ("has_bounce_now", vp), ("bounce_pos", vp), ("has_racket_contact", vp),
+                ("has_racket_contact_now", vp)]
 
 
 _lib = None

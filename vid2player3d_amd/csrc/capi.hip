@@ -499,6 +499,10 @@ int v2p_env_attach_ball(v2p_env* e, const v2p_ball_cfg* c, const v2p_ball_buffer
         set_error("v2p_env_attach_ball: bad ball parameters");
         return V2P_ERR_INVALID;
     }
+    {
+        const int nflags = (b->has_bounce != nullptr) + (b->has_bounce_now != nullptr) + (b->bounce_pos != nullptr) + (b->has_racket_contact != nullptr) + (b->has_racket_contact_now != nullptr);
+        if (nflags != 0 && nflags != 5) { set_error("v2p_env_attach_ball: give all five flag buffers or none"); return V2P_ERR_INVALID; }
+    }
     if (e->schedule != 0 || !e->p.enable_contact || e->p.solver_type != 0) {
         set_error("v2p_env_attach_ball: racket + ball needs the link-per-lane schedule, contacts on and the PGS solver");
         return V2P_ERR_UNSUPPORTED;
@@ -514,6 +518,11 @@ int v2p_env_attach_ball(v2p_env* e, const v2p_ball_cfg* c, const v2p_ball_buffer
     memcpy(d.cyl, c->cylinders, sizeof(d.cyl));
     memcpy(d.racket_off, c->racket_offset, sizeof(d.racket_off));
     d.state = b->ball_state; d.racket_state = b->racket_state; d.per_sim = b->ball_per_sim; d.hit_per_sim = b->racket_hit_per_sim; d.contact = b->ball_contact;
+    d.rest_body = c->restitution_body; d.fric_body = c->friction_body; d.body_contacts = c->body_contacts ? 1 : 0;
+    d.bounce_height = c->bounce_height; d.poll_hits = c->poll_racket_hits ? 1 : 0;
+    d.body_contact = b->ball_body_contact;
+    d.has_bounce = b->has_bounce; d.has_bounce_now = b->has_bounce_now; d.bounce_pos = b->bounce_pos;
+    d.has_hit = b->has_racket_contact; d.has_hit_now = b->has_racket_contact_now;
     return V2P_OK;
 }
 

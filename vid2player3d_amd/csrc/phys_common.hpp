@@ -28,6 +28,11 @@ struct BallDev {
     float* per_sim;        // [N,nsim,13] ball state after each simulate() call
     int32_t* hit_per_sim;  // [N,nsim] racket-ball contact force non-zero in the call's last substep
     float* contact;        // [N,2,3] force on the ball from the racket / from the ground, last substep
+    float rest_body, fric_body, bounce_height;
+    int32_t body_contacts, poll_hits;
+    float* body_contact;   // [N,3] or NULL: force on the ball from the humanoid's links, last substep
+    uint8_t *has_bounce, *has_bounce_now, *has_hit, *has_hit_now;  // the reference's flags (all or none)
+    float* bounce_pos;     // [N,3]
 };
 
 // post-physics fused into the physics launch (v2p_env_step, link-per-lane schedule): what env_post_kernel takes

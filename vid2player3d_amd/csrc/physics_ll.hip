@@ -44,6 +44,7 @@
 #define PHYS_RCP(x) __builtin_amdgcn_rcpf(x)
 #endif
 #include "phys_common.hpp"
+#include "hull_gjk.hpp"
 
 namespace v2p {
 
@@ -241,10 +242,11 @@ constexpr int PARK_TAR = 0, PARK_W0 = 3, PARK_XD0 = 6, PARK_Q = 9, PARK_X = 13, 
               PARK_SCR = PARK3 ? 44 : 16,  // (one row of 64 dwords per wave: lane of the k-th near link)
               PARK_SLOTS = PARK_SCR + 1;  // LDS parking slots (dwords per lane)
 constexpr int ROOTLAM_FLOATS = 2 * 24;  // (PARK2) Lambda of the two root links while the contacts are generated
-// ball block (64 floats per env, after the parking area of the wave): state 13 | aero force 3 | ground contact: active gap bias lambda3 |
-// racket point j at BL_RK + 16 j: active gap bias rl3 n3 lambda3
+// ball block (80 floats per env, after the parking area of the wave): state 13 | aero force 3 | ground contact: active gap bias lambda3 |
+// point j at BL_RK + 16 j: active gap bias rl3 n3 lambda3 (j = 0, 1: against the racket's cylinders; j = 2: against the hull of link
+// BL_HLINK, stored + 1, 0 = none) | velocity at the start of the substep 3
 constexpr int BL_POS = 0, BL_QUAT = 3, BL_VEL = 7, BL_ANG = 10, BL_F = 13, BL_GA = 16, BL_GGAP = 17, BL_GBIAS = 18, BL_GLAM = 19, BL_RK = 24,
-              RK_A = 0, RK_GAP = 1, RK_BIAS = 2, RK_RL = 3, RK_N = 6, RK_LAM = 9, BL_SLOTS = 64;
+              RK_A = 0, RK_GAP = 1, RK_BIAS = 2, RK_RL = 3, RK_N = 6, RK_LAM = 9, BL_V0 = 72, BL_HLINK = 75, BL_SLOTS = 80;
 constexpr int LDS_FLOATS_PER_WAVE = PARK_SLOTS * 64 + 2 * BL_SLOTS + ROOTLAM_FLOATS;
 // contact records of this lane's link: registers, or (PARK3) the lane's LDS column
 template <bool LDS>
@@ -607,7 +609,20 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
             const V3 wx = pull(x, src), ww = pull(w, src), wxd = pull(xd, src);
             if (ball_lane) {
                 const V3 bp{bl[BL_POS], bl[BL_POS + 1], bl[BL_POS + 2]}, bv{bl[BL_VEL], bl[BL_VEL + 1], bl[BL_VEL + 2]}, bw{bl[BL_ANG], bl[BL_ANG + 1], bl[BL_ANG + 2]};
+                bl[BL_V0] = bv.x; bl[BL_V0 + 1] = bv.y; bl[BL_V0 + 2] = bv.z;  // (the hull points' activation test reads the velocity of the start of the substep)
+                bl[BL_HLINK] = 0.f;
+                bl[BL_RK + 32 + RK_A] = 0.f;
+                bl[BL_RK + 32 + RK_LAM] = 0.f; bl[BL_RK + 32 + RK_LAM + 1] = 0.f; bl[BL_RK + 32 + RK_LAM + 2] = 0.f;
                 if (sub % BP.sub_per_sim == 0) {
+                    // the reference's bounce test on the ball height at the start of every simulate() call (apply_external_force_to_ball, :731-737)
+                    if (BP.has_bounce && live_env) {
+                        if (sub == 0) BP.has_bounce_now[e] = 0;
+                        if (bp.z <= BP.bounce_height && !BP.has_bounce[e]) {
+                            BP.has_bounce[e] = 1;
+                            BP.has_bounce_now[e] = 1;
+                            BP.bounce_pos[e * 3] = bp.x; BP.bounce_pos[e * 3 + 1] = bp.y; BP.bounce_pos[e * 3 + 2] = bp.z;
+                        }
+                    }
                     // aerodynamic force, re-evaluated before every simulate() call (humanoid_smpl_im_mvae.py:711-739, utils/tennis_ball.py)
                     const float kf = 1.21f * 3.14159265358979f * 0.032f * 0.032f * 0.5f, cd = 0.55f;
                     const float sp = PHYS_SQRT(dot(bv, bv)), vs = sp == 0.f ? 1.f : sp;
@@ -660,6 +675,61 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                     }
                     rk[RK_A] = on ? 1.f : 0.f;
                     rk[RK_LAM] = 0.f; rk[RK_LAM + 1] = 0.f; rk[RK_LAM + 2] = 0.f;
+                }
+            }
+            if (CONTACT && BP.body_contacts) {
+                // ---- ball x the hulls of the links (every shape of the humanoid collides with the ball actor): each link lane tests its
+                // own hull - bounding box first -, the nearest hull that the ball can reach within this substep carries the point
+                const V3 bp{bl[BL_POS], bl[BL_POS + 1], bl[BL_POS + 2]}, bv0{bl[BL_V0], bl[BL_V0 + 1], bl[BL_V0 + 2]};
+                const float coff = P.contact_offset;
+                bool near = false;
+                V3 cb{0.f, 0.f, 0.f};
+                const M3 R = q2mat(q);
+                if (valid && lb != BP.racket_link) {
+                    cb = mulT(R, bp - x);  // ball centre, body frame
+                    const V3 ac{S->aabb_c[bo][0], S->aabb_c[bo][1], S->aabb_c[bo][2]}, ae{S->aabb_e[bo][0], S->aabb_e[bo][1], S->aabb_e[bo][2]};
+                    const V3 ex{fmaxf(fabsf(cb.x - ac.x) - ae.x, 0.f), fmaxf(fabsf(cb.y - ac.y) - ae.y, 0.f), fmaxf(fabsf(cb.z - ac.z) - ae.z, 0.f)};
+                    const V3 dv = bv0 - xd;
+                    const float vmax = PHYS_SQRT(dot(dv, dv)) + PHYS_SQRT(dot(w, w)) * (PHYS_SQRT(dot(ac, ac)) + PHYS_SQRT(dot(ae, ae)));
+                    const float reach = BP.radius + coff + h * vmax;
+                    near = dot(ex, ex) < reach * reach;
+                }
+                if (any64(near)) {
+                    float gap = 3.0e38f;
+                    V3 rlw{0.f, 0.f, 0.f}, nw{0.f, 0.f, 1.f};
+                    if (near) {
+                        const int hv0 = S->hull_offsets[bo], hnv = S->hull_count[bo];
+                        V3 pb;
+                        float dist = hull_closest([&](int k) { return V3{S->hull_verts[hv0 + k][0], S->hull_verts[hv0 + k][1], S->hull_verts[hv0 + k][2]}; }, hnv, cb, pb);
+                        V3 nb;
+                        if (dist > 1e-6f) nb = PHYS_RCP(dist) * (cb - pb);
+                        else {  // centre inside the hull: out along the direction from the centre of the bounding box
+                            const V3 ev = cb - V3{S->aabb_c[bo][0], S->aabb_c[bo][1], S->aabb_c[bo][2]};
+                            const float l = PHYS_SQRT(dot(ev, ev));
+                            nb = l > 1e-9f ? PHYS_RCP(l) * ev : V3{0.f, 0.f, 1.f};
+                            dist = 0.f;
+                            pb = cb;
+                        }
+                        nw = mul(R, nb);
+                        rlw = mul(R, pb);
+                        const float vrel = dot(bv0 - xd - cross(w, rlw), nw);
+                        const float g = dist - BP.radius;
+                        if (g < coff + h * fmaxf(0.f, -vrel)) gap = g;
+                    }
+                    // the nearest of the env's candidates (ties: the lower link)
+                    float gmin = gap;
+#pragma unroll
+                    for (int sh = 1; sh < 32; sh <<= 1) gmin = fminf(gmin, __shfl_xor(gmin, sh));
+                    const unsigned long long wb = __ballot(gap == gmin && gap < 3.0e38f);
+                    const unsigned wmine = half ? (unsigned)(wb >> 32) : (unsigned)wb;
+                    if (wmine && lb == __ffs(wmine) - 1) {
+                        volatile float* rk = bl + BL_RK + 32;
+                        rk[RK_A] = 1.f;
+                        rk[RK_GAP] = gap;
+                        rk[RK_RL] = rlw.x; rk[RK_RL + 1] = rlw.y; rk[RK_RL + 2] = rlw.z;
+                        rk[RK_N] = nw.x; rk[RK_N + 1] = nw.y; rk[RK_N + 2] = nw.z;
+                        bl[BL_HLINK] = (float)(lb + 1);
+                    }
                 }
             }
         }
@@ -989,7 +1059,10 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                 Lam.C = Sym3{lv[15], lv[16], lv[17], lv[18], lv[19], lv[20]};
             }
             // (with a ball: the racket's link joins the touched links while the ball is in contact with a cylinder)
-            const bool ballhit = BALL && valid && lb == BP.racket_link && (bl[BL_RK + RK_A] != 0.f || bl[BL_RK + 16 + RK_A] != 0.f);
+            const int hlink = BALL ? (int)bl[BL_HLINK] - 1 : -1;  // link whose hull the ball touches (-1: none)
+            // (point j of the ball block belongs to this lane's link: j = 0, 1 the racket's cylinders, j = 2 the hull point)
+            auto ball_rec_mine = [&](int j) -> bool { return j < 2 ? lb == BP.racket_link : lb == hlink; };
+            const bool ballhit = BALL && valid && ((lb == BP.racket_link && (bl[BL_RK + RK_A] != 0.f || bl[BL_RK + 16 + RK_A] != 0.f)) || lb == hlink);
             const bool ballground = BALL && ball_lane && bl[BL_GA] != 0.f;
             const unsigned long long tb = __ballot(valid && (cnt > 0 || ballhit));
             const unsigned m0 = (unsigned)tb, m1 = (unsigned)(tb >> 32);
@@ -1099,14 +1172,14 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                     const V3 bv{bl[BL_VEL], bl[BL_VEL + 1], bl[BL_VEL + 2]}, bw{bl[BL_ANG], bl[BL_ANG + 1], bl[BL_ANG + 2]};
                     const float ih = PHYS_RCP(h);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
+                    for (int j = 0; j < 3; ++j) {
                         volatile float* rk = bl + BL_RK + 16 * j;
-                        if (rk[RK_A] != 0.f) {
+                        if (rk[RK_A] != 0.f && ball_rec_mine(j)) {
                             const V3 n{rk[RK_N], rk[RK_N + 1], rk[RK_N + 2]}, rl{rk[RK_RL], rk[RK_RL + 1], rk[RK_RL + 2]};
                             const float gap = rk[RK_GAP];
                             const float vn0 = dot(bv + cross(bw, -BP.radius * n) - xd - cross(w, rl), n);
                             float bias = gap >= 0.f ? gap * ih : fmaxf(P.erp * gap * ih, -P.max_depen);
-                            if (vn0 < -BP.bounce_thr && gap * ih + vn0 < 0.f) bias = fminf(bias, BP.rest_racket * vn0);
+                            if (vn0 < -BP.bounce_thr && gap * ih + vn0 < 0.f) bias = fminf(bias, (j < 2 ? BP.rest_racket : BP.rest_body) * vn0);
                             rk[RK_BIAS] = bias;
                         }
                     }
@@ -1405,9 +1478,9 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                                 // a free sphere (1/m, 1/I), the link side goes through Lambda_b like every row of this block
                                 V3 bv{bl[BL_VEL], bl[BL_VEL + 1], bl[BL_VEL + 2]}, bw{bl[BL_ANG], bl[BL_ANG + 1], bl[BL_ANG + 2]};
 #pragma unroll 1
-                                for (int j = 0; j < 2; ++j) {
+                                for (int j = 0; j < 3; ++j) {
                                     volatile float* rk = bl + BL_RK + 16 * j;
-                                    if (rk[RK_A] == 0.f) continue;
+                                    if (rk[RK_A] == 0.f || !ball_rec_mine(j)) continue;
                                     const V3 n{rk[RK_N], rk[RK_N + 1], rk[RK_N + 2]}, rl{rk[RK_RL], rk[RK_RL + 1], rk[RK_RL + 2]};
                                     V3 t1v, t2v;
                                     ball_dirs(n, t1v, t2v);
@@ -1424,7 +1497,7 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                                         const float old = rk[RK_LAM + ax];
                                         float nl = old - rel * __builtin_amdgcn_rcpf(wii);
                                         if (ax == 0) nl = fmaxf(nl, 0.f);
-                                        else { const float lim = BP.fric_racket * lamn; nl = fminf(fmaxf(nl, -lim), lim); }
+                                        else { const float lim = (j < 2 ? BP.fric_racket : BP.fric_body) * lamn; nl = fminf(fmaxf(nl, -lim), lim); }
                                         const float dl = nl - old;
                                         rk[RK_LAM + ax] = nl;
                                         if (ax == 0) lamn = nl;
@@ -1608,9 +1681,9 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                                     // a free sphere (1/m, 1/I), the link side goes through Lambda_b like every row of this block
                                     V3 bv{bl[BL_VEL], bl[BL_VEL + 1], bl[BL_VEL + 2]}, bw{bl[BL_ANG], bl[BL_ANG + 1], bl[BL_ANG + 2]};
 #pragma unroll 1
-                                    for (int j = 0; j < 2; ++j) {
+                                    for (int j = 0; j < 3; ++j) {
                                         volatile float* rk = bl + BL_RK + 16 * j;
-                                        if (rk[RK_A] == 0.f) continue;
+                                        if (rk[RK_A] == 0.f || !ball_rec_mine(j)) continue;
                                         const V3 n{rk[RK_N], rk[RK_N + 1], rk[RK_N + 2]}, rl{rk[RK_RL], rk[RK_RL + 1], rk[RK_RL + 2]};
                                         V3 t1, t2;
                                         ball_dirs(n, t1, t2);
@@ -1627,7 +1700,7 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                                             const float old = rk[RK_LAM + ax];
                                             float nl = old - rel * __builtin_amdgcn_rcpf(wii);
                                             if (ax == 0) nl = fmaxf(nl, 0.f);
-                                            else { const float lim = BP.fric_racket * lamn; nl = fminf(fmaxf(nl, -lim), lim); }
+                                            else { const float lim = (j < 2 ? BP.fric_racket : BP.fric_body) * lamn; nl = fminf(fmaxf(nl, -lim), lim); }
                                             const float dl = nl - old;
                                             rk[RK_LAM + ax] = nl;
                                             if (ax == 0) lamn = nl;
@@ -1796,12 +1869,13 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
             }
         }
         if (BALL) {
-            // force on the ball from the racket in this substep (sum over the two cylinders), world axes
-            V3 frk{0.f, 0.f, 0.f};
-            if (ball_lane || (valid && lb == BP.racket_link)) {
+            // force on the ball in this substep from the racket (sum over the two cylinders) and from the hull point, world axes
+            V3 frk{0.f, 0.f, 0.f}, fbd{0.f, 0.f, 0.f};
+            const int hl = (int)bl[BL_HLINK] - 1;
+            if (ball_lane || (valid && (lb == BP.racket_link || lb == hl))) {
                 const float ih = PHYS_RCP(h);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < 3; ++j) {
                     volatile float* rk = bl + BL_RK + 16 * j;
                     if (rk[RK_A] != 0.f) {
                         const V3 n{rk[RK_N], rk[RK_N + 1], rk[RK_N + 2]};
@@ -1810,7 +1884,8 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                         if (dot(t1, t1) < 1e-6f) t1 = cross(n, V3{1.f, 0.f, 0.f});
                         t1 = rsqrtf(dot(t1, t1)) * t1;
                         t2 = cross(n, t1);
-                        frk = frk + ih * (rk[RK_LAM] * n + rk[RK_LAM + 1] * t1 + rk[RK_LAM + 2] * t2);
+                        const V3 f = ih * (rk[RK_LAM] * n + rk[RK_LAM + 1] * t1 + rk[RK_LAM + 2] * t2);
+                        if (j < 2) frk = frk + f; else fbd = fbd + f;
                     }
                 }
             }
@@ -1831,7 +1906,12 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                     float* o = BP.per_sim + (e * nsim + ks) * 13;
                     o[0] = bp.x; o[1] = bp.y; o[2] = bp.z; o[3] = bq.x; o[4] = bq.y; o[5] = bq.z; o[6] = bq.w;
                     o[7] = bv.x; o[8] = bv.y; o[9] = bv.z; o[10] = bw.x; o[11] = bw.y; o[12] = bw.z;
-                    BP.hit_per_sim[e * nsim + ks] = (frk.x != 0.f || frk.y != 0.f || frk.z != 0.f) ? 1 : 0;
+                    const bool hit = frk.x != 0.f || frk.y != 0.f || frk.z != 0.f;
+                    BP.hit_per_sim[e * nsim + ks] = hit ? 1 : 0;
+                    if (BP.has_hit) {  // the reference's poll of the net contact forces after every simulate() call (:773-779)
+                        if (ks == 0) BP.has_hit_now[e] = 0;
+                        if (BP.poll_hits && hit && !BP.has_hit[e]) { BP.has_hit[e] = 1; BP.has_hit_now[e] = 1; }
+                    }
                 }
                 if (last && live_env) {
                     const float ih = PHYS_RCP(h);
@@ -1839,10 +1919,12 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                     oc[0] = frk.x; oc[1] = frk.y; oc[2] = frk.z;
                     oc[3] = bl[BL_GA] != 0.f ? bl[BL_GLAM + 1] * ih : 0.f; oc[4] = bl[BL_GA] != 0.f ? bl[BL_GLAM + 2] * ih : 0.f;
                     oc[5] = bl[BL_GA] != 0.f ? bl[BL_GLAM] * ih : 0.f;
+                    if (BP.body_contact) { float* ob = BP.body_contact + e * 3; ob[0] = fbd.x; ob[1] = fbd.y; ob[2] = fbd.z; }
                 }
             }
-            if (last && valid && live_env && !frozen && lb == BP.racket_link) {  // the reaction on the racket's link enters its net contact force below
-                park[PARK_W0 * 64] = frk.x; park[(PARK_W0 + 1) * 64] = frk.y; park[(PARK_W0 + 2) * 64] = frk.z;
+            if (last && valid && live_env && !frozen) {  // the reaction on the touched link enters its net contact force below
+                const V3 fr = mask(lb == BP.racket_link, frk) + mask(lb == hl, fbd);
+                park[PARK_W0 * 64] = fr.x; park[(PARK_W0 + 1) * 64] = fr.y; park[(PARK_W0 + 2) * 64] = fr.z;
             }
         }
         if (last && valid && live_env && !frozen) {
@@ -1853,7 +1935,7 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
                     if (c < cnt) { const V3 lc = CS.lam(c); cforce.z += lc.x * ih; cforce.x += lc.y * ih; cforce.y += lc.z * ih; }
-                if (BALL && lb == BP.racket_link) cforce = cforce - park_get3(PARK_W0);
+                if (BALL) cforce = cforce - park_get3(PARK_W0);
             }
             float* oc = a.x_contact + (env_here() * NB + b) * 3;
             oc[0] = cforce.x; oc[1] = cforce.y; oc[2] = cforce.z;

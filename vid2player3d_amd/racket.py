@@ -20,6 +20,7 @@ BALL = {"radius": 0.032, "mass": 0.057, "inertia": 4e-5}  # tennis_ball.urdf
 # contact material (humanoid_smpl_im_mvae.py:414-416, 436-438; plane: amass_im / djokovic yaml restitution 0, friction 1): PhysX combines
 # the two shapes' values by averaging (its default combine mode)
 BALL_MATERIAL = {"rest_ground": 0.5 * (1.0 + 0.0), "fric_ground": 0.5 * (0.8 + 1.0), "rest_racket": 0.5 * (1.0 + 1.0), "fric_racket": 0.5 * (0.8 + 0.8),
+                 "rest_body": 0.5 * (1.0 + 0.0), "fric_body": 0.5 * (0.8 + 1.0),  # ball x a link's hull (shape defaults on the humanoid's side)
                  "bounce_threshold": 0.2, "ang_damp": 0.5, "max_ang_vel": 64.0}  # the last two: gymapi.AssetOptions defaults (the ball asset sets none)
 
 

@@ -47,6 +47,7 @@ class HumanoidSMPLIMRacketBall(HumanoidSMPLIM):
         self._ball_states_per_sim = torch.zeros((n, nsim, 13), **f)
         self._racket_ball_contact_per_sim = torch.zeros((n, nsim), dtype=torch.int32, device=dev)
         self._ball_contact_forces = torch.zeros((n, 2, 3), **f)
+        self._ball_body_contact_force = torch.zeros((n, 3), **f)  # on the ball from the humanoid's links (ball x hull contacts)
         self._has_bounce = torch.zeros(n, dtype=torch.bool, device=dev)
         self._has_bounce_now = torch.zeros(n, dtype=torch.bool, device=dev)
         self._bounce_pos = torch.zeros((n, 3), **f)
@@ -63,13 +64,17 @@ class HumanoidSMPLIMRacketBall(HumanoidSMPLIM):
                          restitution_ground=mat["rest_ground"], friction_ground=mat["fric_ground"], restitution_racket=mat["rest_racket"],
                          friction_racket=mat["fric_racket"], bounce_threshold_velocity=self.sim_params.physx.bounce_threshold_velocity,
                          angular_damping=mat["ang_damp"], max_angular_velocity=mat["max_ang_vel"], spin_scale=self.cfg_v2p.get("spin_scale", 1.0),
-                         racket_link=g["racket_link"], num_cylinders=len(g["cylinders"]))
+                         racket_link=g["racket_link"], num_cylinders=len(g["cylinders"]),
+                         restitution_body=mat["rest_body"], friction_body=mat["fric_body"], body_contacts=int(env.get("ball_body_contacts", True)),
+                         bounce_height=BALL_R * (6 if self.sim_params.substeps > 2 else 4), poll_racket_hits=int(self.sim_params.substeps <= 2))
         for k, cy in enumerate(g["cylinders"]):
             c.cylinders[k][:] = [float(x) for x in list(cy["center"]) + list(cy["axis"]) + [cy["half_len"], cy["radius"]]]
         c.racket_offset[:] = [float(x) for x in g["racket_offset"]]
         b = _lib.BallBuffers(ball_state=self._ball_root_states.data_ptr(), racket_state=self._racket_rb_state.data_ptr(),
                              ball_per_sim=self._ball_states_per_sim.data_ptr(), racket_hit_per_sim=self._racket_ball_contact_per_sim.data_ptr(),
-                             ball_contact=self._ball_contact_forces.data_ptr())
+                             ball_contact=self._ball_contact_forces.data_ptr(), ball_body_contact=self._ball_body_contact_force.data_ptr(),
+                             has_bounce=self._has_bounce.data_ptr(), has_bounce_now=self._has_bounce_now.data_ptr(), bounce_pos=self._bounce_pos.data_ptr(),
+                             has_racket_contact=self._has_racket_ball_contact.data_ptr(), has_racket_contact_now=self._has_racket_ball_contact_now.data_ptr())
         _lib.check(self._lib.v2p_env_attach_ball(self._h_env, C.byref(c), C.byref(b)), "v2p_env_attach_ball")
         self.ball_material = mat
 
@@ -85,36 +90,6 @@ class HumanoidSMPLIMRacketBall(HumanoidSMPLIM):
         self._bounce_pos[ids] = 0
         self._has_racket_ball_contact[ids] = False
 
-    def _ball_flags_before(self):
-        self._ball_start = self._ball_root_states[:, 0:3].clone()
-
-    def _ball_flags_after(self):
-        """apply_external_force_to_ball's bounce test on the ball position at the START of each simulate() call (:731-737) and the
-        contact-force poll after it (:773-779), for all calls of the step at once (a handful of elementwise kernels)."""
-        thresh = BALL_R * (6 if self.sim_params.substeps > 2 else 4)
-        starts = torch.cat([self._ball_start.unsqueeze(1), self._ball_states_per_sim[:, :-1, 0:3]], dim=1)  # [N, nsim, 3]
-        low = starts[..., 2] <= thresh
-        first = low & (torch.cumsum(low.int(), dim=1) == 1)            # the first call of this step that sees the ball low
-        now = first.any(dim=1) & ~self._has_bounce
-        self._has_bounce_now = now
-        self._bounce_pos = torch.where(now.unsqueeze(-1), (starts * first.unsqueeze(-1)).sum(dim=1), self._bounce_pos)
-        self._has_bounce = self._has_bounce | now
-        if self.sim_params.substeps <= 2:
-            hit = (self._racket_ball_contact_per_sim != 0).any(dim=1) & ~self._has_racket_ball_contact
-            self._has_racket_ball_contact_now = hit
-            self._has_racket_ball_contact = self._has_racket_ball_contact | hit
-
-    def step(self, actions):
-        self._ball_flags_before()
-        super().step(actions)
-        self._ball_flags_after()
-
-    def step_fused(self, actions):
-        self._ball_flags_before()
-        super().step_fused(actions)
-        self._ball_flags_after()
-
-    def _physics_step(self):
-        if not hasattr(self, "_ball_start"):
-            self._ball_flags_before()
-        super()._physics_step()
+    # The reference's flag bookkeeping around every simulate() call - the bounce test on the ball height at the START of the call
+    # (apply_external_force_to_ball, :731-737: threshold 4 ball radii, 6 with more than 2 substeps) and the contact-force poll after it
+    # (:773-779, only with sim.substeps <= 2) - runs inside the physics launch: the flag tensors above are the buffers it writes.
