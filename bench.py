@@ -300,6 +300,7 @@ def main():
     ap.add_argument("--joint-limits", type=int, default=None, choices=(0, 1),
                     help="enforce the MJCF joint ranges as limit rows (only the racket arm of --racket-ball has any; default: on with --racket-ball, else off)")
     ap.add_argument("--racket-ball", action="store_true", help="BASELINE config 4 as worded: racket welded to the wrist + free ball with drag / Magnus lift, ball-ground and ball-racket contacts (implies --djokovic)")
+    ap.add_argument("--ball-body-contacts", type=int, default=1, choices=(0, 1), help="--racket-ball: ball x link-hull contacts (0: only ball x racket and ball x ground, for A/B)")
     ap.add_argument("--per-clip-shapes", action="store_true", help="one body shape per clip (64 scaled bodies) instead of one shape for all envs")
     ap.add_argument("--ppo", action="store_true", help="BASELINE config 5 loop: device-resident rollout (play_steps) + GAE + PPO update per epoch; prints the reference's fps step / fps total")
     ap.add_argument("--ppo-epochs", type=int, default=4, help="timed PPO epochs (after one untimed warm-up epoch)")
@@ -345,7 +346,7 @@ def main():
         task = build_task(n, local_rank, seed=7 + rank, contact=not args.no_contact, per_clip_shapes=args.per_clip_shapes, djokovic=args.djokovic or args.racket_ball,
                           freeze=args.freeze_terminated, solver=args.solver, racket_ball=args.racket_ball, substep_jobs=bool(args.substep_jobs) and not args.racket_ball,
                           joint_limits=args.joint_limits,
-                          env_extra={k: v for k, v in (("job_mono_permille", args.job_mono), ("pair_mix_permille", args.pair_mix)) if v is not None})  # per-rank seed like run.py:37
+                          env_extra={k: v for k, v in (("job_mono_permille", args.job_mono), ("pair_mix_permille", args.pair_mix), ("ball_body_contacts", None if args.ball_body_contacts else False)) if v is not None})  # per-rank seed like run.py:37
     if args.ppo:
         return run_ppo(args, task, dist, world, rank)
     dev = task.device

@@ -105,6 +105,7 @@ def test_ball_step_matches_oracle(mlib, mode, lift, limits):
     ball = _launch(task, rng, mode)
     task._ball_root_states[:] = T(ball)
     hits_total, ground_total, body_total = 0, 0, 0
+    has_hit = np.zeros(n, dtype=bool)
     for step in range(2):
         act = np.concatenate([N(task._target_dof_pos) + rng.normal(0, 0.17, (n, 69)), rng.normal(0, 0.17, (n, 6))], axis=1).astype(np.float32)
         rb0 = N(task._rigid_body_state).reshape(n, 24, 13).copy()
@@ -130,6 +131,10 @@ def test_ball_step_matches_oracle(mlib, mode, lift, limits):
         close(got_ps[..., 10:13], per_sim[..., 10:13], 5e-4, "%s ball spin (step %d)" % (mode, step))
         assert np.array_equal(N(task._ball_root_states), got_ps[:, -1])
         assert np.array_equal(N(task._racket_ball_contact_per_sim), hit), "racket hit flags"
+        # the reference's sticky flag and its per-step edge (humanoid_smpl_im_mvae.py:773-779), kept by the physics launch itself
+        now = hit.any(axis=1) & ~has_hit
+        has_hit |= now
+        assert np.array_equal(N(task._has_racket_ball_contact_now), now) and np.array_equal(N(task._has_racket_ball_contact), has_hit)
         close(N(task._ball_contact_forces), bc, 2e-2, "contact forces on the ball")
         close(N(task._ball_body_contact_force), bbf, 2e-2, "contact force on the ball from the humanoid's links")
         rb = N(task._rigid_body_state).reshape(n, 24, 13)

@@ -248,6 +248,11 @@ constexpr int ROOTLAM_FLOATS = 2 * 24;  // (PARK2) Lambda of the two root links 
 constexpr int BL_POS = 0, BL_QUAT = 3, BL_VEL = 7, BL_ANG = 10, BL_F = 13, BL_GA = 16, BL_GGAP = 17, BL_GBIAS = 18, BL_GLAM = 19, BL_RK = 24,
               RK_A = 0, RK_GAP = 1, RK_BIAS = 2, RK_RL = 3, RK_N = 6, RK_LAM = 9, BL_V0 = 72, BL_HLINK = 75, BL_SLOTS = 80;
 constexpr int LDS_FLOATS_PER_WAVE = PARK_SLOTS * 64 + 2 * BL_SLOTS + ROOTLAM_FLOATS;
+// ball x hull narrow phase, out of line: it runs on the few substeps in which a ball is within reach of a link, and inlined its
+// registers would be spilled around on every substep
+__device__ __noinline__ float ball_hull_distance(ConstShape* S, int v0, int nv, V3 c, V3& p) {
+    return hull_closest([&](int k) { return V3{S->hull_verts[v0 + k][0], S->hull_verts[v0 + k][1], S->hull_verts[v0 + k][2]}; }, nv, c, p);
+}
 // contact records of this lane's link: registers, or (PARK3) the lane's LDS column
 template <bool LDS>
 struct ContactStore;
@@ -700,7 +705,7 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                     if (near) {
                         const int hv0 = S->hull_offsets[bo], hnv = S->hull_count[bo];
                         V3 pb;
-                        float dist = hull_closest([&](int k) { return V3{S->hull_verts[hv0 + k][0], S->hull_verts[hv0 + k][1], S->hull_verts[hv0 + k][2]}; }, hnv, cb, pb);
+                        float dist = ball_hull_distance(S, hv0, hnv, cb, pb);
                         V3 nb;
                         if (dist > 1e-6f) nb = PHYS_RCP(dist) * (cb - pb);
                         else {  // centre inside the hull: out along the direction from the centre of the bounding box
