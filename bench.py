@@ -344,7 +344,7 @@ def main():
         if dist is not None:
             dist.barrier()
         task = build_task(n, local_rank, seed=7 + rank, contact=not args.no_contact, per_clip_shapes=args.per_clip_shapes, djokovic=args.djokovic or args.racket_ball,
-                          freeze=args.freeze_terminated, solver=args.solver, racket_ball=args.racket_ball, substep_jobs=bool(args.substep_jobs) and not args.racket_ball,
+                          freeze=args.freeze_terminated, solver=args.solver, racket_ball=args.racket_ball, substep_jobs=bool(args.substep_jobs),
                           joint_limits=args.joint_limits,
                           env_extra={k: v for k, v in (("job_mono_permille", args.job_mono), ("pair_mix_permille", args.pair_mix), ("ball_body_contacts", None if args.ball_body_contacts else False)) if v is not None})  # per-rank seed like run.py:37
     if args.ppo:

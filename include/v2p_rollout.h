@@ -180,7 +180,7 @@ typedef struct {
                                  * what either means here).  Link-per-lane schedule only. */
     int32_t substep_jobs;       /* 1: the physics launch of the link-per-lane schedule is cut into (substep, env pair) jobs that hand the
                                  * state over through memory - 4x finer load balancing of the launch; results are bit-identical to 0
-                                 * (one workgroup per env pair runs all substeps).  PGS, contacts on, no ball. */
+                                 * (one workgroup per env pair runs all substeps).  PGS, contacts on (with or without racket + ball, joint limits). */
     int32_t job_mono_permille;  /* substep_jobs: share of the env pairs (the heaviest) whose substeps stay in one workgroup; -1 = default (250) */
     int32_t pair_mix_permille;  /* pair_envs_by_load: share of the envs (the heaviest) that share their wave with one of the lightest envs
                                  * instead of with an equally heavy one (a wave costs the union of its two envs' contact structure, and the

@@ -177,3 +177,38 @@ def test_bounce_and_hit_flags(mlib):
     assert not task._has_racket_ball_contact.any()
     assert task._ball_root_states[:, 2].min() > 0.0  # the ball did not tunnel
     task.close()
+
+
+@pytest.mark.parametrize("n", [3, 2048])
+def test_substep_jobs_are_invisible_with_ball(mlib, n):
+    """Racket + ball + joint limits through substep jobs (the ball's state and its aerodynamic force are handed over with the
+    humanoid's; the flags are kept through system-scope accesses): bit-identical to one workgroup per env pair, step after step."""
+    outs = []
+    for jobs in (False, True):
+        task = make_rb_task(n, mlib, substep_jobs=jobs, debug_contacts=0)
+        g = torch.Generator(device=DEV)
+        g.manual_seed(23)
+        task.reset_with_times(None, torch.rand(n, device=DEV, generator=g) * 0.8)
+        root = task._humanoid_root_states[:, 0:3]
+        jit = torch.rand((n, 3), device=DEV, generator=g)
+        # served at the players from 2.5 m: body hits, racket hits and ground bounces all occur within the steps below
+        task.reset_balls(torch.arange(n, device=DEV), root + torch.tensor([2.5, 0.0, 0.3], device=DEV) + jit * 0.6,
+                         torch.tensor([-20.0, 0.0, 1.0], device=DEV) + (jit - 0.5) * torch.tensor([6.0, 4.0, 4.0], device=DEV),
+                         torch.tensor([0.0, -120.0, 0.0], device=DEV).expand(n, 3))
+        snaps = []
+        for k in range(10):
+            a = torch.cat([task._target_dof_pos + 0.4 * torch.randn((n, 69), device=DEV, generator=g), 0.3 * torch.randn((n, 6), device=DEV, generator=g)], dim=1).contiguous()
+            task.step(a)
+            snaps.append([N(task._rigid_body_state).copy(), N(task._ball_root_states).copy(), N(task._ball_states_per_sim).copy(), N(task._contact_forces).copy(),
+                          N(task._ball_contact_forces).copy(), N(task._ball_body_contact_force).copy(), N(task._racket_ball_contact_per_sim).copy(),
+                          N(task._has_bounce).copy(), N(task._has_bounce_now).copy(), N(task._bounce_pos).copy(), N(task._has_racket_ball_contact).copy(),
+                          N(task.rew_buf).copy(), N(task.reset_buf).copy()])
+        task.check()
+        outs.append(snaps)
+        task.close()
+    if n > 100:
+        assert any(np.abs(s[5]).max() > 0 for s in outs[0]), "the fixture must produce ball x hull contacts"
+        assert outs[0][-1][7].any(), "... and bounces"
+    for k, (sa, sb) in enumerate(zip(*outs)):
+        for j, (x, y) in enumerate(zip(sa, sb)):
+            assert np.array_equal(x, y), "step %d, tensor %d: %d of %d values differ" % (k, j, int((x != y).sum()), x.size)

@@ -82,6 +82,8 @@ constexpr int LPE = 32;  // lanes per environment
 __device__ __forceinline__ bool any64(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 // hand-off of a job's results to another workgroup (possibly on another XCD: per-XCD L2s are not coherent, a CU's L1 is never refreshed):
 // system-scope relaxed atomics = `sc0 sc1` loads / stores on both sides (MI355X_MICROARCH.md, inter-workgroup visibility, valid forms)
+__device__ __forceinline__ uint8_t flag_ld(const uint8_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void flag_st(uint8_t* p, uint8_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ float cload(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void cstore(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 // the same in 16-byte pieces (MI355X_MICROARCH.md: a dword `sc1` store is its own fabric write, ~6x the time per byte of a dwordx4 one;
@@ -494,10 +496,24 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
     const BallDev& BP = a.ball;
     const bool ball_lane = BALL && lb == NB;  // the first idle lane of the env carries the ball
     if (ball_lane) {
+        // (JOBS: state and aerodynamic force - held over a simulate() call - come from the job of the substep before: chunks 50 .. 53)
+        bool bgot = false;
+        if constexpr (JOBS) if (handed) {
+            f4 c0, c1, c2, c3;
+            cload4x2(hand + 4 * 50, hand + 4 * 51, c0, c1);
+            cload4x2(hand + 4 * 52, hand + 4 * 53, c2, c3);
+            bl[0] = c0.x; bl[1] = c0.y; bl[2] = c0.z; bl[3] = c0.w; bl[4] = c1.x; bl[5] = c1.y; bl[6] = c1.z; bl[7] = c1.w;
+            bl[8] = c2.x; bl[9] = c2.y; bl[10] = c2.z; bl[11] = c2.w; bl[12] = c3.x; bl[13] = c3.y; bl[14] = c3.z; bl[15] = c3.w;
+            bgot = true;
+        }
+        if (!bgot) {
 #pragma unroll
-        for (int k = 0; k < 13; ++k) bl[k] = BP.state[e * 13 + k];
+            for (int k = 0; k < 13; ++k) bl[k] = BP.state[e * 13 + k];
 #pragma unroll
-        for (int k = 13; k < BL_SLOTS; ++k) bl[k] = 0.f;
+            for (int k = 13; k < 16; ++k) bl[k] = 0.f;
+        }
+#pragma unroll
+        for (int k = 16; k < BL_SLOTS; ++k) bl[k] = 0.f;
     }
     long long tprev = DIAG && a.prof ? clock64() : 0;
     const long long wt0 = DIAG && a.wave_times ? wall_clock64() : 0;
@@ -620,11 +636,12 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                 bl[BL_RK + 32 + RK_LAM] = 0.f; bl[BL_RK + 32 + RK_LAM + 1] = 0.f; bl[BL_RK + 32 + RK_LAM + 2] = 0.f;
                 if (sub % BP.sub_per_sim == 0) {
                     // the reference's bounce test on the ball height at the start of every simulate() call (apply_external_force_to_ball, :731-737)
+                    // (system-scope accesses: with substep jobs the calls of one step run in different workgroups)
                     if (BP.has_bounce && live_env) {
-                        if (sub == 0) BP.has_bounce_now[e] = 0;
-                        if (bp.z <= BP.bounce_height && !BP.has_bounce[e]) {
-                            BP.has_bounce[e] = 1;
-                            BP.has_bounce_now[e] = 1;
+                        if (sub == 0) flag_st(&BP.has_bounce_now[e], 0);
+                        if (bp.z <= BP.bounce_height && !flag_ld(&BP.has_bounce[e])) {
+                            flag_st(&BP.has_bounce[e], 1);
+                            flag_st(&BP.has_bounce_now[e], 1);
                             BP.bounce_pos[e * 3] = bp.x; BP.bounce_pos[e * 3 + 1] = bp.y; BP.bounce_pos[e * 3 + 2] = bp.z;
                         }
                     }
@@ -1914,8 +1931,8 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                     const bool hit = frk.x != 0.f || frk.y != 0.f || frk.z != 0.f;
                     BP.hit_per_sim[e * nsim + ks] = hit ? 1 : 0;
                     if (BP.has_hit) {  // the reference's poll of the net contact forces after every simulate() call (:773-779)
-                        if (ks == 0) BP.has_hit_now[e] = 0;
-                        if (BP.poll_hits && hit && !BP.has_hit[e]) { BP.has_hit[e] = 1; BP.has_hit_now[e] = 1; }
+                        if (ks == 0) flag_st(&BP.has_hit_now[e], 0);
+                        if (BP.poll_hits && hit && !flag_ld(&BP.has_hit[e])) { flag_st(&BP.has_hit[e], 1); flag_st(&BP.has_hit_now[e], 1); }
                     }
                 }
                 if (last && live_env) {
@@ -2041,6 +2058,13 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                 cstore4(ho + 8 * bo2, jq.x, jq.y, jq.z, jq.w);
                 cstore4(ho + 8 * bo2 + 4, wt.x, wt.y, wt.z, 0.f);
             }
+        }
+        if (BALL && ball_lane && live_env) {
+            float* const ho = a.job_hand + e * HAND_FLOATS;
+            cstore4(ho + 4 * 50, bl[0], bl[1], bl[2], bl[3]);
+            cstore4(ho + 4 * 51, bl[4], bl[5], bl[6], bl[7]);
+            cstore4(ho + 4 * 52, bl[8], bl[9], bl[10], bl[11]);
+            cstore4(ho + 4 * 53, bl[12], bl[13], bl[14], bl[15]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (inline asm: the compiler must not drop or move this drain)
         if (lane == 0) {
@@ -2259,20 +2283,48 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s, float* actions, int* fuse
     const bool diag = a.prof || a.wave_times;
 #endif
     if (env->ball) a.ball = *env->ball;
+    // ONE instantiation whether the launch is cut into substep jobs or not (job_mono = every pair: whole control steps per workgroup,
+    // nothing handed over): "substep jobs are invisible" holds by construction - two instantiations of the template are two
+    // compilations, and under -fassociative-math nothing makes them round alike
+    a.job_blocks = (int)blocks;
+    a.job_progress = env->job_progress;
+    a.job_hand = env->job_hand;
+    a.job_mono = (int)blocks;
+    auto job_grid = [&](int& rc) -> dim3 {
+        rc = V2P_OK;
+        const bool cut = env->substep_jobs && env->job_progress && blocks > 1;
+        if (cut) {
+            // substep jobs: one launch of job_mono + nsub x (blocks - job_mono) workgroups, substep-major
+            a.job_epoch = ++env->job_epoch;
+            if (env->job_epoch > (1 << 26)) env->job_epoch = 0;  // (wraps before the progress words overflow; a wrap needs them cleared)
+            if (env->job_epoch == 0) {
+                rc = check_hip(hipMemsetAsync(env->job_progress, 0, sizeof(int) * (blocks * LL_WPB + 1), s), "hipMemsetAsync(job_progress)");
+                a.job_epoch = env->job_epoch = 1;
+            }
+            a.job_mono = (int)(blocks * (unsigned)env->job_mono_permille / 1000u);
+        }
+        return dim3((unsigned)a.job_mono + (blocks - (unsigned)a.job_mono) * (unsigned)env->p.nsub);
+    };
     if (env->p.joint_limits && env->p.enable_contact && !tgs) {  // joint-limit rows: their own instantiations (PGS, with contacts, +- ball)
+        int rc0;
+        const dim3 jgrid = job_grid(rc0);
+        if (rc0 != V2P_OK) return rc0;
         if (env->ball) {
-            if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, false, false, true, false, true>), grid, block, lds, s, a);
-            else hipLaunchKernelGGL((physics_ll_kernel<true, false, false, false, true, false, true>), grid, block, lds, s, a);
+            if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, false, false, true, true, true>), jgrid, block, lds, s, a);
+            else hipLaunchKernelGGL((physics_ll_kernel<true, false, false, false, true, true, true>), jgrid, block, lds, s, a);
         } else {
-            if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, false, false, false, false, true>), grid, block, lds, s, a);
-            else hipLaunchKernelGGL((physics_ll_kernel<true, false, false, false, false, false, true>), grid, block, lds, s, a);
+            if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, false, false, false, true, true>), jgrid, block, lds, s, a);
+            else hipLaunchKernelGGL((physics_ll_kernel<true, false, false, false, false, true, true>), jgrid, block, lds, s, a);
         }
     } else if (env->p.joint_limits) {
         set_error("physics: joint limits run with contacts on and the PGS solver");
         return V2P_ERR_UNSUPPORTED;
     } else if (env->ball && env->p.enable_contact && !tgs) {  // racket + ball: its own instantiation (PGS, with contacts)
-        if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, false, false, true, false, false>), grid, block, lds, s, a);
-        else hipLaunchKernelGGL((physics_ll_kernel<true, false, false, false, true, false, false>), grid, block, lds, s, a);
+        int rc0;
+        const dim3 jgrid = job_grid(rc0);
+        if (rc0 != V2P_OK) return rc0;
+        if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, false, false, true, true, false>), jgrid, block, lds, s, a);
+        else hipLaunchKernelGGL((physics_ll_kernel<true, false, false, false, true, true, false>), jgrid, block, lds, s, a);
     } else if (env->ball) {
         set_error("physics: racket + ball runs with contacts on and the PGS solver");
         return V2P_ERR_UNSUPPORTED;
@@ -2282,26 +2334,9 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s, float* actions, int* fuse
         if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, true, false, false, false, false>), grid, block, lds, s, a);
         else hipLaunchKernelGGL((physics_ll_kernel<true, false, true, false, false, false, false>), grid, block, lds, s, a);
     } else if (env->p.enable_contact) {
-        // ONE instantiation whether the launch is cut into substep jobs or not (job_mono = every pair: whole control steps per
-        // workgroup, nothing handed over): "substep jobs are invisible" holds by construction - two instantiations of the template
-        // are two compilations, and under -fassociative-math nothing makes them round alike
-        const bool cut = env->substep_jobs && env->job_progress && blocks > 1;
-        a.job_blocks = (int)blocks;
-        a.job_progress = env->job_progress;
-        a.job_hand = env->job_hand;
-        a.job_mono = (int)blocks;
-        if (cut) {
-            // substep jobs: one launch of job_mono + nsub x (blocks - job_mono) workgroups, substep-major
-            a.job_epoch = ++env->job_epoch;
-            if (env->job_epoch > (1 << 26)) env->job_epoch = 0;  // (wraps before the progress words overflow; a wrap needs them cleared)
-            if (env->job_epoch == 0) {
-                int rc0 = check_hip(hipMemsetAsync(env->job_progress, 0, sizeof(int) * (blocks * LL_WPB + 1), s), "hipMemsetAsync(job_progress)");
-                if (rc0 != V2P_OK) return rc0;
-                a.job_epoch = env->job_epoch = 1;
-            }
-            a.job_mono = (int)(blocks * (unsigned)env->job_mono_permille / 1000u);
-        }
-        const dim3 jgrid((unsigned)a.job_mono + (blocks - (unsigned)a.job_mono) * (unsigned)env->p.nsub);
+        int rc0;
+        const dim3 jgrid = job_grid(rc0);
+        if (rc0 != V2P_OK) return rc0;
         if (fused_post && actions && env->mlib) {  // v2p_env_step: post-physics runs in the epilogue of every env's last job
             a.post.b = env->buf;
             a.post.t = env->mlib->t;

@@ -32,7 +32,6 @@ class HumanoidSMPLIMRacketBall(HumanoidSMPLIM):
             raise NotImplementedError("racket + ball with per-clip body shapes is not built")
         model, self.racket_geometry = racket.with_racket(base)
         env["body_model"] = model
-        env["substep_jobs"] = False  # the ball's state lives in LDS across the substeps of a step: one workgroup per env pair
         # the player MJCF's racket-arm ranges (R_Wrist +-10 / +-45 / +-90 deg, R_Elbow_x <= 90 deg) are enforced like Isaac Gym does
         env.setdefault("joint_limits", True)
         self.cfg_v2p = dict(cfg.get("v2p") or {})

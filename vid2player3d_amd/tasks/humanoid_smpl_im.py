@@ -401,10 +401,8 @@ class HumanoidSMPLIM:
         c.job_mono_permille = int(env.get("job_mono_permille", -1))  # -1: the engine's defaults
         c.pair_mix_permille = int(env.get("pair_mix_permille", -1))
         # joint ranges of the MJCF enforced as limit rows (Isaac Gym always enforces them; only the racket arm of the player MJCFs has
-        # DOFs narrower than a full turn, the amass MJCF has none); runs whole control steps per workgroup
+        # DOFs narrower than a full turn, the amass MJCF has none)
         c.joint_limits = int(env.get("joint_limits", False))
-        if c.joint_limits:
-            c.substep_jobs = 0
         c.debug_contacts = int(env.get("debug_contacts", 0))  # 0 off, 1 last substep's contact vertices kept, 2 every substep's
         hold = env.get("residual_force_hold", "first_sim")
         c.residual_hold_sims = 1 if hold == "first_sim" else self.control_freq_inv
