@@ -366,7 +366,9 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
     e->substep_jobs = c->substep_jobs ? 1 : 0;
     // (mixing trades total work for a shorter critical path: it pays while the launch is as long as its heaviest pair, i.e. up to
     // ~4 env pairs per wave slot; beyond that the launch is throughput bound and pairs of equals are cheaper)
-    e->pair_mix_permille = c->pair_mix_permille < 0 ? (n <= 12288 ? 250 : 0) : c->pair_mix_permille;
+    // (the kernels with joint-limit rows or a ball run 2 waves per SIMD: there pairs of equals measured best, profiles/r02g_racket_ball_sweep.txt)
+    e->pair_mix_default = c->pair_mix_permille < 0 ? 1 : 0;
+    e->pair_mix_permille = c->pair_mix_permille < 0 ? ((n <= 12288 && !c->joint_limits) ? 250 : 0) : c->pair_mix_permille;
     e->job_mono_permille = c->job_mono_permille < 0 ? 250 : c->job_mono_permille;  // defaults: measured best (profiles/r02_job_mono_sweep.txt)
     if (e->pair_mix_permille > 500 || e->job_mono_permille > 1000) { set_error("v2p_env_create: pair_mix_permille <= 500, job_mono_permille <= 1000"); v2p_env_destroy(e); return V2P_ERR_INVALID; }
     if (rc == V2P_OK && e->substep_jobs) {
@@ -523,6 +525,7 @@ int v2p_env_attach_ball(v2p_env* e, const v2p_ball_cfg* c, const v2p_ball_buffer
     d.body_contact = b->ball_body_contact;
     d.has_bounce = b->has_bounce; d.has_bounce_now = b->has_bounce_now; d.bounce_pos = b->bounce_pos;
     d.has_hit = b->has_racket_contact; d.has_hit_now = b->has_racket_contact_now;
+    if (e->pair_mix_default) e->pair_mix_permille = 0;
     return V2P_OK;
 }
 

@@ -147,6 +147,7 @@ struct v2p_env {
     float* job_hand;          // [N][HAND_FLOATS] the state as one substep job hands it to the next (16-byte chunks)
     int job_epoch;
     int pair_mix_permille;    // share of the envs (the heaviest) that are paired with the lightest ones instead of with each other
+    int pair_mix_default;     // pair_mix_permille was left to the engine (-1)
     int job_mono_permille;    // share of the env pairs (the heaviest) whose substeps stay in one workgroup
     v2p::BallDev* ball;       // racket + ball attached (v2p_env_attach_ball), else NULL
     hipEvent_t* prof_ev;      // 2 events per measured physics launch (v2p_env_profile_begin), else NULL
