@@ -1,7 +1,10 @@
+"""Long-run sanity of the engine on the GPU box: python tools/soak.py [steps] [racket]  (racket: the racket + ball task, a ball served at
+every player each epoch: ball x hull / racket / ground contacts, joint limits, substep jobs)."""
 import sys, torch
 sys.path.insert(0, ".")
 import bench
-task = bench.build_task(8192, 0, 7)
+RACKET = len(sys.argv) > 2 and sys.argv[2] == "racket"
+task = bench.build_task(8192, 0, 7, djokovic=RACKET, racket_ball=RACKET, substep_jobs=True)
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 n = task.num_envs
 bad = 0
@@ -22,6 +25,12 @@ for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 2000):
         perm, key = task.debug_pairing()
         okp = bool((torch.sort(perm.long()).values == torch.arange(n, device="cuda")).all())
         zmin = float(task._rigid_body_state.view(n, 24, 13)[..., 2].min())
-        print(i + 1, "finite", ok, "perm ok", okp, "zmin %.3f" % zmin, "alive %.3f" % float((task.reset_buf == 0).float().mean()))
+        extra = ""
+        if RACKET:
+            bs = task._ball_root_states
+            ok = ok and bool(torch.isfinite(bs).all()) and float(bs[:, 2].min()) > 0.0 and float(bs[:, 7:10].norm(dim=1).max()) < 120.0
+            extra = " ball z %.3f..%.2f |v|max %.1f bounced %.2f hit %.3f" % (float(bs[:, 2].min()), float(bs[:, 2].max()), float(bs[:, 7:10].norm(dim=1).max()),
+                                                                            float(task._has_bounce.float().mean()), float(task._has_racket_ball_contact.float().mean()))
+        print(i + 1, "finite", ok, "perm ok", okp, "zmin %.3f" % zmin, "alive %.3f" % float((task.reset_buf == 0).float().mean()) + extra)
         bad += (not ok) + (not okp)
 print("SOAK", "OK" if bad == 0 else "FAILED")
