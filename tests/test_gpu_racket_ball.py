@@ -62,9 +62,10 @@ def _launch(task, rng, mode):
             ball[e, 10:13] = rng.normal(0, 80, 3)
     else:
         geom = task.racket_geometry
+        rl = geom["racket_link"]
         for e in range(n):
-            Rw = Rotation.from_quat(rb[e, 22, 3:7]).as_matrix()
-            centre = rb[e, 22, 0:3] + Rw @ geom["cylinders"][1]["center"]
+            Rw = Rotation.from_quat(rb[e, rl, 3:7]).as_matrix()
+            centre = rb[e, rl, 0:3] + Rw @ geom["cylinders"][1]["center"]
             normal = Rw @ geom["cylinders"][1]["axis"] * (1 if e % 2 else -1)
             side = np.cross(normal, [0.3, 0.5, 0.8])
             side /= np.linalg.norm(side)
@@ -75,14 +76,17 @@ def _launch(task, rng, mode):
     return ball
 
 
-@pytest.mark.parametrize("mode,lift,limits", [("flight", 0.0, False), ("ground", 0.0, False), ("hit", 0.4, False), ("hit", 0.0, False), ("hit", 0.0, True),
-                                              ("body", 0.4, False), ("body", 0.0, True)])
-def test_ball_step_matches_oracle(mlib, mode, lift, limits):
+@pytest.mark.parametrize("mode,lift,limits,player", [("flight", 0.0, False, "djokovic"), ("ground", 0.0, False, "djokovic"), ("hit", 0.4, False, "djokovic"),
+                                                     ("hit", 0.0, False, "djokovic"), ("hit", 0.0, True, "djokovic"), ("body", 0.4, False, "djokovic"),
+                                                     ("body", 0.0, True, "federer"), ("hit", 0.0, True, "nadal")])
+def test_ball_step_matches_oracle(mlib, mode, lift, limits, player):
     """limits: with the joint ranges of the player MJCF's racket arm enforced (v2p_sim_cfg.joint_limits) - the wrist's limit rows, its
-    hull points and the ball x racket rows then all belong to the same link."""
+    hull points and the ball x racket rows then all belong to the same link.  player: the asset (nadal = left-handed: racket on L_Wrist)."""
     n = 32
     rng = np.random.default_rng({"flight": 1, "ground": 2, "hit": 3, "body": 4}[mode] + int(10 * lift))
-    task = make_rb_task(n, mlib, joint_limits=limits)
+    task = make_rb_task(n, mlib, joint_limits=limits, player=player)
+    rl = task.racket_geometry["racket_link"]
+    assert rl == (17 if player == "nadal" else 22)
     task.reset_with_times(None, T(rng.uniform(0.1, 1.0, size=n)))
     root = N(task._humanoid_root_states).copy()
     root[:, 2] += lift
@@ -142,10 +146,10 @@ def test_ball_step_matches_oracle(mlib, mode, lift, limits):
         close(rb[..., 7:13], rbs[..., 7:13], 1e-3, "rb vel")
         close(N(task._contact_forces), cf, 2e-2, "net contact forces (the racket's link carries the reaction of the ball)")
         # the racket rigid body = the wrist frame moved by the weld offset
-        Rw = Rotation.from_quat(rbs[:, 22, 3:7]).as_matrix()
+        Rw = Rotation.from_quat(rbs[:, rl, 3:7]).as_matrix()
         off = np.einsum("nij,j->ni", Rw, task.racket_geometry["racket_offset"])
-        close(N(task._racket_rb_state)[:, 0:3], rbs[:, 22, 0:3] + off, 2e-5, "racket pos")
-        close(N(task._racket_rb_state)[:, 7:10], rbs[:, 22, 7:10] + np.cross(rbs[:, 22, 10:13], off), 1e-3, "racket vel")
+        close(N(task._racket_rb_state)[:, 0:3], rbs[:, rl, 0:3] + off, 2e-5, "racket pos")
+        close(N(task._racket_rb_state)[:, 7:10], rbs[:, rl, 7:10] + np.cross(rbs[:, rl, 10:13], off), 1e-3, "racket vel")
         hits_total += int(hit.sum())
         ground_total += int(((ball_before[:, 9] < -0.5) & (got_ps[:, -1, 9] > 0)).sum())  # balls that bounced within this control step
         body_total += int(((np.linalg.norm(got_ps[:, -1, 7:10] - ball_before[:, 7:10], axis=1) > 3.0) & (hit.sum(1) == 0) & (got_ps[:, -1, 2] > 0.1)).sum())  # deflected by a hull

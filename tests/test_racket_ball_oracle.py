@@ -168,3 +168,24 @@ def test_ball_bounces_off_a_link(models):
     assert vchest[0] < -1e-3                    # the chest was pushed back
     bb_off = out[False][0]
     assert bb_off[7] < -7.0                     # without the hull contacts the ball keeps flying (only drag)
+
+
+def test_left_handed_player_is_the_mirror_image(models):
+    """data/assets/smpl_mesh_humanoid_nadal.xml: the racket on L_Wrist at (+0.5, 0, 0), handle towards +x; the racket arm's ranges on the
+    left elbow / wrist (Wrist_x -90 .. 10 like federer's); same racket mass."""
+    base, (mr, gr) = models
+    ml, gl = R.with_racket(base, player="nadal")
+    b = base.body_index("L_Wrist")
+    assert gl["racket_link"] == b == 17 and gl["player"] == "nadal"
+    assert abs(gl["racket_mass"] - gr["racket_mass"]) < 1e-12
+    assert np.allclose(gl["cylinders"][0]["center"], [0.175, 0, 0]) and np.allclose(gl["cylinders"][1]["center"], [0.5, 0, 0])
+    assert np.allclose(gl["racket_offset"], [0.5, 0, 0])
+    assert ml.com[b][0] > base.com[b][0] + 0.2 and np.array_equal(ml.mass[22], base.mass[22])
+    j = 3 * (b - 1)
+    assert np.allclose(np.rad2deg(ml.limit_lower[j:j + 3]), [-90, -45, -90]) and np.allclose(np.rad2deg(ml.limit_upper[j:j + 3]), [10, 45, 90])
+    je = 3 * (base.body_index("L_Elbow") - 1)
+    assert np.allclose(np.rad2deg([ml.limit_lower[je], ml.limit_upper[je]]), [-180, 90])
+    jr = 3 * (22 - 1)
+    assert np.all(ml.limit_upper[jr:jr + 3] - ml.limit_lower[jr:jr + 3] >= 6.28)   # the right arm is free
+    mf, _ = R.with_racket(base, player="federer")
+    assert np.allclose(np.rad2deg([mf.limit_lower[jr], mf.limit_upper[jr]]), [-90, 10])

@@ -16,6 +16,17 @@ from .model import BodyModel
 
 RACKET_PARENT = "R_Wrist"
 RACKET_OFFSET = np.array([-0.5, 0.0, 0.0])  # body "Racket" pos in the wrist frame
+# the three player assets (data/assets/smpl_mesh_humanoid_{djokovic,federer,nadal}.xml): the link the racket is welded to, the racket
+# body's position in that link's frame, the handle's end points in the RACKET frame, and the joint ranges of the racket arm in degrees
+# (djokovic :173, 178-180; federer :178 differs in Wrist_x; nadal :143, 148-150, 158-160 is left-handed: the mirror image along x)
+PLAYERS = {
+    "djokovic": {"parent": "R_Wrist", "offset": (-0.5, 0.0, 0.0), "handle": ((0.5, 0, 0), (0.15, 0, 0)),
+                 "limits": {"R_Elbow": ((-180.0, 90.0), None, None), "R_Wrist": ((-10.0, 10.0), (-45.0, 45.0), (-90.0, 90.0))}},
+    "federer": {"parent": "R_Wrist", "offset": (-0.5, 0.0, 0.0), "handle": ((0.5, 0, 0), (0.15, 0, 0)),
+                "limits": {"R_Elbow": ((-180.0, 90.0), None, None), "R_Wrist": ((-90.0, 10.0), (-45.0, 45.0), (-90.0, 90.0))}},
+    "nadal": {"parent": "L_Wrist", "offset": (0.5, 0.0, 0.0), "handle": ((-0.5, 0, 0), (-0.15, 0, 0)),
+              "limits": {"L_Elbow": ((-180.0, 90.0), None, None), "L_Wrist": ((-90.0, 10.0), (-45.0, 45.0), (-90.0, 90.0))}},
+}
 BALL = {"radius": 0.032, "mass": 0.057, "inertia": 4e-5}  # tennis_ball.urdf
 # contact material (humanoid_smpl_im_mvae.py:414-416, 436-438; plane: amass_im / djokovic yaml restitution 0, friction 1): PhysX combines
 # the two shapes' values by averaging (its default combine mode)
@@ -24,11 +35,13 @@ BALL_MATERIAL = {"rest_ground": 0.5 * (1.0 + 0.0), "fric_ground": 0.5 * (0.8 + 1
                  "bounce_threshold": 0.2, "ang_damp": 0.5, "max_ang_vel": 64.0}  # the last two: gymapi.AssetOptions defaults (the ball asset sets none)
 
 
-def racket_cylinders():
+def racket_cylinders(player="djokovic"):
     """[(centre, unit axis, half length, radius, density)] of handle and head in the WRIST frame."""
     out = []
-    for a, b, radius, density in (((0.5, 0, 0), (0.15, 0, 0), 0.016, 500.0), ((0, -0.015, -0.015), (0, 0.015, 0.015), 0.15, 150.0)):
-        a, b = np.array(a, float) + RACKET_OFFSET, np.array(b, float) + RACKET_OFFSET
+    spec = PLAYERS[player]
+    offset = np.array(spec["offset"], float)
+    for a, b, radius, density in ((spec["handle"][0], spec["handle"][1], 0.016, 500.0), ((0, -0.015, -0.015), (0, 0.015, 0.015), 0.15, 150.0)):
+        a, b = np.array(a, float) + offset, np.array(b, float) + offset
         axis = b - a
         out.append((0.5 * (a + b), axis / np.linalg.norm(axis), 0.5 * np.linalg.norm(axis), radius, density))
     return out
@@ -52,24 +65,26 @@ def _cylinder_vertices(centre, axis, half_len, radius, n_ring):
     return np.concatenate([centre + half_len * axis + ring, centre - half_len * axis + ring])
 
 
-# joint ranges of the racket arm in the player MJCFs, degrees (smpl_mesh_humanoid_djokovic.xml:173, 178-180); every other DOF is +-180 / +-720
-PLAYER_ARM_LIMITS = {"R_Elbow": ((-180.0, 90.0), None, None), "R_Wrist": ((-10.0, 10.0), (-45.0, 45.0), (-90.0, 90.0))}
+# joint ranges of the racket arm in the djokovic MJCF, degrees (every other DOF is +-180 / +-720)
+PLAYER_ARM_LIMITS = PLAYERS["djokovic"]["limits"]
 
 
-def with_racket(base, wrist_vertex_budget=30, arm_limits=True, **model_kw):
-    """(BodyModel with the racket folded into R_Wrist, geometry dict for the ball contacts).  arm_limits: carry the player MJCF's joint
-    ranges of the racket arm (enforced when cfg['env']['joint_limits'] is on)."""
-    b = base.body_index(RACKET_PARENT)
+def with_racket(base, wrist_vertex_budget=30, arm_limits=True, player="djokovic", **model_kw):
+    """(BodyModel with the racket folded into the player's racket wrist, geometry dict for the ball contacts).  arm_limits: carry the
+    player MJCF's joint ranges of the racket arm (enforced when cfg['env']['joint_limits'] is on).  player: djokovic / federer (right
+    hand) or nadal (left hand: the reference's cfg_v2p righthand = False)."""
+    spec = PLAYERS[player]
+    b = base.body_index(spec["parent"])
     blob = dict(base.blob)
     if arm_limits:
         lo, hi = base.limit_lower.copy(), base.limit_upper.copy()
-        for name, ranges in PLAYER_ARM_LIMITS.items():
+        for name, ranges in spec["limits"].items():
             j = 3 * (base.body_index(name) - 1)
             for i, rg in enumerate(ranges):
                 if rg is not None:
                     lo[j + i], hi[j + i] = np.deg2rad(rg[0]), np.deg2rad(rg[1])
         blob["limit_lower"], blob["limit_upper"] = lo, hi
-    cyls = racket_cylinders()
+    cyls = racket_cylinders(player)
     # composite rigid body: wrist + handle + head
     parts = [(base.mass[b], base.com[b], base.inertia[b])] + [_cylinder_mass_properties(*c) for c in cyls]
     mass = sum(p[0] for p in parts)
@@ -94,7 +109,7 @@ def with_racket(base, wrist_vertex_budget=30, arm_limits=True, **model_kw):
     noff = off.copy()
     noff[b + 1:] += len(new) - (off[b + 1] - off[b])
     blob["hull_offsets"] = noff.astype(np.int32)
-    geom = {"racket_link": b, "racket_offset": RACKET_OFFSET.copy(),
+    geom = {"racket_link": b, "racket_offset": np.array(spec["offset"], float), "player": player,
             "cylinders": [{"center": c[0], "axis": c[1], "half_len": c[2], "radius": c[3]} for c in cyls],
             "racket_mass": float(sum(p[0] for p in parts[1:]))}
     return BodyModel(blob, **model_kw), geom

@@ -30,7 +30,12 @@ class HumanoidSMPLIMRacketBall(HumanoidSMPLIM):
                                                          kd_scale=env.get("kd_scale", env.get("kp_scale", 1.0)))
         if isinstance(base, (list, tuple)):
             raise NotImplementedError("racket + ball with per-clip body shapes is not built")
-        model, self.racket_geometry = racket.with_racket(base)
+        # the player asset: djokovic / federer (right hand) or nadal (left hand); cfg_v2p righthand = False selects the left-handed one
+        # like the reference (humanoid_smpl_im_mvae.py:73-78).  The exposed rigid-body order is the canonical one either way (racket =
+        # rigid body 24: the reference permutes the left-handed asset's tensor into it, :67, 197-201).
+        v2p = dict(cfg.get("v2p") or {})
+        player = env.get("player", "djokovic" if v2p.get("righthand", True) else "nadal")
+        model, self.racket_geometry = racket.with_racket(base, player=player)
         env["body_model"] = model
         # the player MJCF's racket-arm ranges (R_Wrist +-10 / +-45 / +-90 deg, R_Elbow_x <= 90 deg) are enforced like Isaac Gym does
         env.setdefault("joint_limits", True)
