@@ -111,6 +111,16 @@ def hull_closest(verts, c):
     return float(d), p
 
 
+def ball_aero(state13, spin_scale=1.0):
+    """Aerodynamic force on the ball (drag + Magnus lift) for a ball root state [13], as the oracle evaluates it before a simulate() call."""
+    b = OBall()
+    r = np.asarray(state13, dtype=np.float64)
+    b.pos[:], b.quat[:], b.vel[:], b.angvel[:] = r[0:3].tolist(), r[3:7].tolist(), r[7:10].tolist(), r[10:13].tolist()
+    f = np.zeros(3)
+    lib().v2p_oracle_ball_aero(C.byref(b), C.c_double(spin_scale), _dptr(f))
+    return f
+
+
 class PhysOracle:
     """One humanoid per instance; batches are Python loops (small cases only)."""
 

@@ -216,3 +216,41 @@ def test_substep_jobs_are_invisible_with_ball(mlib, n):
     for k, (sa, sb) in enumerate(zip(*outs)):
         for j, (x, y) in enumerate(zip(sa, sb)):
             assert np.array_equal(x, y), "step %d, tensor %d: %d of %d values differ" % (k, j, int((x != y).sum()), x.size)
+
+
+def test_aero_force_and_bounce_flags_match_reference_vectors(mlib):
+    """tests/golden/ball_aero.npz: inputs and outputs of the reference's own apply_external_force_to_ball (drag + Magnus force, bounce flags
+    from the ball height at the start of a simulate() call).  The kernel holds the force over a simulate() call, so a ball in free flight
+    changes its velocity by 2 h (g + F / m) in the first call of the step."""
+    import os
+
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "ball_aero.npz"))
+    st, had, want_f = G["state_a"].copy(), G["has_bounce_in_a"], G["force_a"]
+    n = len(st)
+    task = make_rb_task(n, mlib, debug_contacts=0)
+    assert task.sim_params.substeps == int(G["substeps_a"]) and task.cfg_v2p.get("spin_scale", 1.0) == float(G["spin_scale_a"])
+    task.reset_with_times(None, torch.full((n,), 0.3, device=DEV))
+    st[:, 0:2] += 40.0  # away from the humanoids (neither force nor flags depend on x, y)
+    task._ball_root_states[:] = T(st)
+    task._has_bounce[:] = torch.as_tensor(had, device=DEV)
+    a = torch.cat([task._target_dof_pos.clone(), torch.zeros((n, 6), device=DEV)], dim=1).contiguous()
+    task.step(a)
+    torch.cuda.synchronize()
+    ps = N(task._ball_states_per_sim)
+    h, m, R = 1.0 / 120.0, 0.057, 0.032
+    # ---- force, from the balls that stay clear of the ground during the first call
+    free = (st[:, 2] > R + 0.06) & (st[:, 2] + 2 * h * st[:, 9] > R + 0.06)
+    assert free.sum() > 20
+    got_f = m * ((ps[:, 0, 7:10].astype(np.float64) - st[:, 7:10]) / (2 * h) - np.array([0.0, 0.0, -9.81]))
+    err = np.abs(got_f - want_f)[free].max()
+    assert err < 2e-3 * np.abs(want_f).max(), (err, np.abs(want_f).max())  # (float32 velocities differenced over 1/60 s)
+    # ---- flags: the first call of the step sees the recorded states, the second the state after the first
+    thr = np.float32(4 * R)
+    now1 = G["has_bounce_now_a"]
+    assert np.array_equal(now1, ~had & (st[:, 2] <= thr))
+    now2 = ~had & ~now1 & (ps[:, 0, 2] <= thr)
+    assert np.array_equal(N(task._has_bounce_now), now1 | now2)
+    assert np.array_equal(N(task._has_bounce), had | now1 | now2)
+    bp = N(task._bounce_pos)
+    assert np.array_equal(bp[now1], st[now1, 0:3]) and np.array_equal(bp[now2], ps[now2, 0, 0:3]) and np.all(bp[~(now1 | now2)] == 0)
+    task.close()
