@@ -2047,16 +2047,26 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
     const int64_t e = e_out;
     if constexpr (JOBS) if (!last_job) {
         // ---- hand the state over to the job of the next substep: system-scope stores, drained, then the progress word of the pair
-        if (valid && live_env) {
+        {
+            // Link b owns the adjacent chunks 2b, 2b + 1 (one 32-byte read per lane on the other side).  Written by their owner, every
+            // store instruction would touch half of each 64-byte line (PMC WRITE_SIZE: +14 MB per launch of partial-line write-throughs);
+            // instead lane l of an env writes chunk 24 k + l in instruction k = 0, 1 - 24 adjacent chunks = six full lines -, fetching
+            // the values from the lane that owns them (link 12 k + l / 2, its first or second chunk).
+            const bool root = b == 0;
+            const float A0 = root ? q.x : jq.x, A1 = root ? q.y : jq.y, A2 = root ? q.z : jq.z, A3 = root ? q.w : jq.w;
+            const float B0 = root ? x.x : wt.x, B1 = root ? x.y : wt.y, B2 = root ? x.z : wt.z, B3 = root ? xd.x : 0.f;
             float* const ho = a.job_hand + e * HAND_FLOATS;
-            if (b == 0) {
-                cstore4(ho, q.x, q.y, q.z, q.w);
-                cstore4(ho + 4, x.x, x.y, x.z, xd.x);
+            const bool second = lb & 1;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int src = base + 12 * k + ((lb >> 1) < 12 ? (lb >> 1) : 0);
+                const float a0 = pull(A0, src), a1 = pull(A1, src), a2 = pull(A2, src), a3 = pull(A3, src);
+                const float b0 = pull(B0, src), b1 = pull(B1, src), b2 = pull(B2, src), b3 = pull(B3, src);
+                if (valid && live_env) cstore4(ho + 4 * (24 * k + lb), second ? b0 : a0, second ? b1 : a1, second ? b2 : a2, second ? b3 : a3);
+            }
+            if (root && valid && live_env) {
                 cstore4(ho + 4 * 48, xd.y, xd.z, w.x, w.y);
                 cstore4(ho + 4 * 49, w.z, 0.f, 0.f, 0.f);
-            } else {
-                cstore4(ho + 8 * bo2, jq.x, jq.y, jq.z, jq.w);
-                cstore4(ho + 8 * bo2 + 4, wt.x, wt.y, wt.z, 0.f);
             }
         }
         if (BALL && ball_lane && live_env) {
