@@ -1282,21 +1282,33 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                     // a resting env: empty ranges that do not widen the loops (LCA depth 15, depths 0)
                     // (readfirstlane: the compiler must see wave-uniform loop bounds, or it runs the level loops with per-lane exits)
                     const int pk0 = __builtin_amdgcn_readfirstlane(mv0 ? info0 : 0x00f), pk1 = __builtin_amdgcn_readfirstlane(mv1 ? info1 : 0x00f);
-                    const int du0 = (pk0 >> 4) & 15, dl0 = pk0 & 15, dn0 = (pk0 >> 8) & 15;
-                    const int du1 = (pk1 >> 4) & 15, dl1 = pk1 & 15, dn1 = (pk1 >> 8) & 15;
+                    const int dl0 = pk0 & 15, dn0 = (pk0 >> 8) & 15;
+                    const int dl1 = pk1 & 15, dn1 = (pk1 >> 8) & 15;
                     const int selc = half ? cur1 : cur0, seln = half ? nx1 : nx0, mydl = half ? dl1 : dl0;
                     const bool onc = valid && ((desc >> selc) & 1), onn = valid && ((desc >> seln) & 1);  // ancestors (or self) of cur / of next
+                    // LIMITS: a way up on which no link holds anything to hand over is not walked (the stops at joints whose limit rows
+                    // do not act - most of them - leave nothing behind; the lowest common ancestor has been current since the walk came
+                    // down through it): that env's way up counts as resting
+                    int uk0 = pk0, uk1 = pk1;
+                    if constexpr (LIMITS) {
+                        const bool pend = onc && dep > mydl && (un_new.x != 0.f || un_new.y != 0.f || un_new.z != 0.f || uf_new.x != 0.f || uf_new.y != 0.f || uf_new.z != 0.f ||
+                                                                jt_new.x != 0.f || jt_new.y != 0.f || jt_new.z != 0.f);
+                        const unsigned long long pb = __ballot(pend);
+                        uk0 = __builtin_amdgcn_readfirstlane((unsigned)pb ? pk0 : 0x00f);
+                        uk1 = __builtin_amdgcn_readfirstlane((unsigned)(pb >> 32) ? pk1 : 0x00f);
+                    }
+                    const int du0 = (uk0 >> 4) & 15, du1 = (uk1 >> 4) & 15, ul0 = uk0 & 15, ul1 = uk1 & 15, myul = half ? ul1 : ul0;
                     // depth of this lane's link if it is on the way up (cur .. LCA + 1) / on the way down (LCA + 1 .. next), else -1
-                    const int updep = (onc && dep > mydl) ? dep : -1, dndep = (onn && dep > mydl) ? dep : -1;
-                    const int turndep = (onc && dep == mydl) ? dep : -2;  // the LCA itself: where this env's move turns
-                    const int dlmin = dl0 < dl1 ? dl0 : dl1;
+                    const int updep = (onc && dep > myul) ? dep : -1, dndep = (onn && dep > mydl) ? dep : -1;
+                    const int turndep = (onc && dep == myul) ? dep : -2;  // the LCA itself: where this env's move turns
+                    const int ulmin = ul0 < ul1 ? ul0 : ul1, dlmin = dl0 < dl1 ? dl0 : dl1;
                     // levels (bit d = the links at depth d hand over) that need the long form: a walk turns at their parent, or a path link
                     // is not the first child of its parent (it does not sit in the lane next to it)
-                    const unsigned sideb = ((unsigned)(pk0 >> 12) | (unsigned)(pk1 >> 12)) & 0xfffu;
-                    const unsigned longb = sideb | (dl0 < 15 ? 2u << dl0 : 0u) | (dl1 < 15 ? 2u << dl1 : 0u);
+                    const unsigned sideb = ((unsigned)(uk0 >> 12) | (unsigned)(uk1 >> 12)) & 0xfffu;
+                    const unsigned longb = sideb | (ul0 < 15 ? 2u << ul0 : 0u) | (ul1 < 15 ? 2u << ul1 : 0u);
                     // ---- up  (levels in a gap between the two envs' ranges run idle: a range test here makes the compiler run the whole
                     // loop with per-lane exits and d in a VGPR)
-                    for (int d = du0 > du1 ? du0 : du1; d > dlmin; --d) {
+                    for (int d = du0 > du1 ? du0 : du1; d > ulmin; --d) {
                         V3 cn{0.f, 0.f, 0.f}, cf{0.f, 0.f, 0.f};
                         if (updep == d) {
                             const V3 na = aug * mul(Di, un_new);
