@@ -714,7 +714,7 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                     const V3 dv = bv0 - xd;
                     const float vmax = PHYS_SQRT(dot(dv, dv)) + PHYS_SQRT(dot(w, w)) * (PHYS_SQRT(dot(ac, ac)) + PHYS_SQRT(dot(ae, ae)));
                     const float reach = BP.radius + coff + h * vmax;
-                    near = dot(ex, ex) < reach * reach;
+                    near = dot(ex, ex) < reach * reach && S->hull_count[bo] > 0;
                 }
                 if (any64(near)) {
                     float gap = 3.0e38f;
