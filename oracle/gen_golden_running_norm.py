@@ -5,6 +5,9 @@ before each normalisation), the outputs and the buffers after every batch.  Run 
 """
 import importlib.util
 import os
+import sys
+
+sys.dont_write_bytecode = True  # never leave __pycache__ in the read-only reference mount
 
 import numpy as np
 import torch

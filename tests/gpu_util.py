@@ -32,10 +32,11 @@ def synth_tables(seed=7, num_clips=16, min_frames=60, max_frames=200):
     return motion_tables.build_tables(clips, m.parents, m.local_pos)
 
 
-def make_task(num_envs, motion_lib, motion_ids=None, **env_overrides):
+def make_task(num_envs, motion_lib, motion_ids=None, sim_overrides=None, **env_overrides):
     env_overrides.setdefault("debug_contacts", 1)  # tests look at the selected contact vertices
     env_overrides.setdefault("body_shape_mismatch", "ignore")  # the golden libraries carry per-clip betas over one baked body on purpose
     cfg = default_cfg(num_envs, motion_lib=motion_lib, **env_overrides)
+    cfg["sim"].update(sim_overrides or {})
     if motion_ids is None:
         cfg["env"]["sample_first_motions"] = True
     task = HumanoidSMPLIM(cfg, device_type="cuda", device_id=0)

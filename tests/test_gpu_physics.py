@@ -394,6 +394,32 @@ def test_substep_jobs_are_invisible(mlib, n):
             assert np.array_equal(x, y), "step %d, tensor %d: %d of %d values differ (max %.3e)" % (k, j, int((x != y).sum()), x.size, float(np.abs(x.astype(np.float64) - y).max()))
 
 
+def test_substep_jobs_with_twelve_substeps_per_control_step(mlib):
+    """sim.substeps 6 x controlFrequencyInv 2 = 12 substeps per control step (vid2player's controller configs,
+    vid2player/cfg/*.yaml `substeps: 6`): the progress word of a pair counts launch x (nsub + 1) + substep, so the hand-overs of one
+    launch can never satisfy the waits of the next (with the stride fixed at 8 they did from nsub = 9 on).  Jobs on == jobs off, bit
+    for bit, over several launches."""
+    n = 4096
+    outs = []
+    for jobs in (False, True):
+        task = make_task(n, mlib, sim_overrides={"substeps": 6}, substep_jobs=jobs)
+        assert task.sim_params.substeps * task.control_freq_inv == 12
+        g = torch.Generator(device=DEV)
+        g.manual_seed(23)
+        task.reset_with_times(None, torch.rand(n, device=DEV, generator=g) * 0.8)
+        snaps = []
+        for k in range(6):
+            a = torch.cat([task._target_dof_pos + 0.4 * torch.randn((n, 69), device=DEV, generator=g), 0.3 * torch.randn((n, 6), device=DEV, generator=g)], dim=1).contiguous()
+            task.step(a)
+            snaps.append([N(task._rigid_body_state).copy(), N(task._dof_state).copy(), N(task._contact_forces).copy(), N(task.rew_buf).copy(), N(task.reset_buf).copy()])
+        task.check()
+        outs.append(snaps)
+        task.close()
+    for k, (sa, sb) in enumerate(zip(*outs)):
+        for j, (x, y) in enumerate(zip(sa, sb)):
+            assert np.array_equal(x, y), "step %d, tensor %d: %d of %d values differ (max %.3e)" % (k, j, int((x != y).sum()), x.size, float(np.abs(x.astype(np.float64) - y).max()))
+
+
 @pytest.mark.parametrize("n,mix", [(2, 0), (3, 250), (1000, 0), (1000, 250), (8195, 250), (8195, 500)])
 def test_pairing_order_is_a_descending_permutation(mlib, n, mix):
     """The wave order for the next launch is a permutation of the envs; read by RANK it has non-increasing contact-load keys (counting

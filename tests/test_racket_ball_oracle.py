@@ -189,3 +189,20 @@ def test_left_handed_player_is_the_mirror_image(models):
     assert np.all(ml.limit_upper[jr:jr + 3] - ml.limit_lower[jr:jr + 3] >= 6.28)   # the right arm is free
     mf, _ = R.with_racket(base, player="federer")
     assert np.allclose(np.rad2deg([mf.limit_lower[jr], mf.limit_upper[jr]]), [-90, 10])
+
+
+def test_racket_model_inherits_gain_scales_and_refuses_a_second_racket():
+    """cfg env kp_scale / kd_scale / default_humanoid_mass reach the racket model (the task takes its PD gains from it), and a model that
+    already carries a racket is not folded again (mass, inertia and rim vertices would double)."""
+    from vid2player3d_amd.model import load_baked_model
+
+    plain = load_baked_model()
+    scaled = load_baked_model(default_humanoid_mass=75.0, kp_scale=1.5, kd_scale=0.5)
+    m0, _ = R.with_racket(plain)
+    m1, _ = R.with_racket(scaled)
+    r = m1.total_mass / m0.total_mass  # (same bodies: 1)
+    assert abs(r - 1.0) < 1e-12
+    assert np.allclose(m1.kp, m0.kp * 1.5 * 90.0 / 75.0) and np.allclose(m1.kd, m0.kd * 0.5 * 90.0 / 75.0)
+    with pytest.raises(ValueError):
+        R.with_racket(m1)
+    assert np.allclose(scaled.scaled(1.1).kp / plain.scaled(1.1).kp, 1.5 * 90.0 / 75.0)

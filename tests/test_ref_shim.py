@@ -49,11 +49,13 @@ def test_against_scipy():
 
 @pytest.mark.skipif(not os.path.exists("/root/reference/poselib/poselib/core/rotation3d.py"), reason="the reference tree is only present in the build container")
 def test_against_the_references_own_quaternion_library():
+    prev, sys.dont_write_bytecode = sys.dont_write_bytecode, True  # never leave __pycache__ in the read-only reference mount
     sys.path.insert(0, "/root/reference/poselib")
     try:
         from poselib.core import rotation3d as R3
     finally:
         sys.path.pop(0)
+        sys.dont_write_bytecode = prev
     a, b = torch.tensor(_rand_quats(100), dtype=torch.float32), torch.tensor(_rand_quats(100), dtype=torch.float32)
     assert torch.allclose(S.quat_mul(a, b), R3.quat_mul(a, b), atol=1e-6)
     assert torch.allclose(S.quat_conjugate(a), R3.quat_conjugate(a))

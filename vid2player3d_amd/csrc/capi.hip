@@ -372,7 +372,7 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
     e->job_mono_permille = c->job_mono_permille < 0 ? 250 : c->job_mono_permille;  // defaults: measured best (profiles/r02_job_mono_sweep.txt)
     if (e->pair_mix_permille > 500 || e->job_mono_permille > 1000) { set_error("v2p_env_create: pair_mix_permille <= 500, job_mono_permille <= 1000"); v2p_env_destroy(e); return V2P_ERR_INVALID; }
     if (rc == V2P_OK && e->substep_jobs) {
-        const size_t words = (N + 1) / 2 + 2;
+        const size_t words = (size_t)v2p::job_wave_slots(N) + 2;
         rc = check_hip(hipMalloc((void**)&e->job_progress, sizeof(int32_t) * words), "hipMalloc(job_progress)");
         if (rc == V2P_OK) rc = check_hip(hipMemset(e->job_progress, 0, sizeof(int32_t) * words), "hipMemset(job_progress)");
         // the state as the jobs hand it over: 50 16-byte chunks per env (see physics_ll.hip)
@@ -434,6 +434,7 @@ void v2p_env_destroy(v2p_env* e) {
     if (e->contact_ids_sub) (void)hipFree(e->contact_ids_sub);
     if (e->job_progress) (void)hipFree(e->job_progress);
     if (e->job_hand) (void)hipFree(e->job_hand);
+    delete e->ball;
     profile_free(e);
     if (e->shapes_dev) (void)hipFree(e->shapes_dev);
     if (e->shape_aug_dev) (void)hipFree(e->shape_aug_dev);
@@ -535,7 +536,7 @@ int v2p_env_check(v2p_env* e, void* stream) {
     int rc = check_hip(hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize");
     if (rc != V2P_OK || !e->job_progress) return rc;
     int32_t flag = 0;
-    int32_t* word = e->job_progress + (e->n + 1) / 2;
+    int32_t* word = e->job_progress + v2p::job_wave_slots(e->n);
     rc = check_hip(hipMemcpy(&flag, word, sizeof(flag), hipMemcpyDeviceToHost), "hipMemcpy(job error word)");
     if (rc == V2P_OK && flag) {
         (void)hipMemset(word, 0, sizeof(flag));

@@ -210,9 +210,7 @@ __device__ __forceinline__ void grp_argmax(float& v, int& k) {
 #define LLSUB(k) do { if (DIAG && a.prof) { long long t_ = clock64(); if (((a.prof_heavy ? blockIdx.x < 8u : (blockIdx.x & 63) == 0)) && lane == 0) atomicAdd((unsigned long long*)&a.prof[k], (unsigned long long)(t_ - tsub)); tsub = t_; } } while (0)
 #define LLPH(k) do { if (DIAG && a.prof) { long long t_ = clock64(); if (((a.prof_heavy ? blockIdx.x < 8u : (blockIdx.x & 63) == 0)) && lane == 0) atomicAdd((unsigned long long*)&a.prof[k], (unsigned long long)(t_ - tprev)); tprev = t_; } } while (0)
 
-#ifndef V2P_LL_WPB
-#define V2P_LL_WPB 1   // waves per workgroup (they share the LDS hull copy)
-#endif
+// (V2P_LL_WPB, waves per workgroup, is defined in v2p_internal.hpp: the host sizes the progress words with it)
 #ifndef V2P_LL_WPS
 #define V2P_LL_WPS 3   // waves per SIMD the register budget is set for (168 VGPRs; 2 = 256 VGPRs with everything in registers)
 #endif
@@ -324,7 +322,10 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
     int* const progress = JOBS ? a.job_progress + (bid * LL_WPB + (threadIdx.x >> 6)) : nullptr;
     if constexpr (JOBS) if (handed) {
         // wait for the previous substep of this env pair (dispatched before this job: it is running or done)
-        const int want = a.job_epoch * 8 + sjob;
+        // progress word of a pair = launch number x (nsub + 1) + substeps handed over: the last hand-over of launch E stores
+        // E (nsub + 1) + nsub - 1, below every value a job of launch E + 1 waits for, whatever nsub is (vid2player's controller
+        // configs run substeps 6 x controlFrequencyInv 2 = 12 per control step)
+        const int want = a.job_epoch * (a.p.nsub + 1) + sjob;
         if (lane == 0) {
             int* const errword = a.job_progress + a.job_blocks * LL_WPB;
             long spins = 0;
@@ -2092,7 +2093,7 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
         if (lane == 0) {
             int bid_here = bid;  // (the address of the progress word is formed here: kept from the prologue it is a spilled 64-bit pointer)
             asm volatile("" : "+s"(bid_here));
-            __hip_atomic_store(a.job_progress + (bid_here * LL_WPB + (threadIdx.x >> 6)), a.job_epoch * 8 + sjob + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(a.job_progress + (bid_here * LL_WPB + (threadIdx.x >> 6)), a.job_epoch * (a.p.nsub + 1) + sjob + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         timeline();
         return;
@@ -2318,9 +2319,9 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s, float* actions, int* fuse
         if (cut) {
             // substep jobs: one launch of job_mono + nsub x (blocks - job_mono) workgroups, substep-major
             a.job_epoch = ++env->job_epoch;
-            if (env->job_epoch > (1 << 26)) env->job_epoch = 0;  // (wraps before the progress words overflow; a wrap needs them cleared)
+            if (env->job_epoch > (1 << 30) / (env->p.nsub + 1) - 2) env->job_epoch = 0;  // (wraps before the progress words overflow; a wrap needs them cleared)
             if (env->job_epoch == 0) {
-                rc = check_hip(hipMemsetAsync(env->job_progress, 0, sizeof(int) * (blocks * LL_WPB + 1), s), "hipMemsetAsync(job_progress)");
+                rc = check_hip(hipMemsetAsync(env->job_progress, 0, sizeof(int) * (size_t)job_wave_slots(env->n), s), "hipMemsetAsync(job_progress)");  // (not the error word behind them)
                 a.job_epoch = env->job_epoch = 1;
             }
             a.job_mono = (int)(blocks * (unsigned)env->job_mono_permille / 1000u);

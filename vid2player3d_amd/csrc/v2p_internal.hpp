@@ -155,7 +155,14 @@ struct v2p_env {
     int pair_have;            // the last physics launch left (key, pos, start) that have not been scattered into perm yet
 };
 
+#ifndef V2P_LL_WPB
+#define V2P_LL_WPB 1   // waves per workgroup of physics_ll_kernel
+#endif
+
 namespace v2p {
+
+// wave slots (env pairs) of a physics_ll launch = progress words of the substep jobs; the error word sits right behind them
+inline int64_t job_wave_slots(int64_t n) { return (n + 2 * V2P_LL_WPB - 1) / (2 * V2P_LL_WPB) * V2P_LL_WPB; }
 
 // state SoA slots
 constexpr int ST_ROOT_POS = 0, ST_ROOT_QUAT = 3, ST_JQUAT = 7, ST_VEL = 7 + 4 * NJ, STATE_SLOTS = 7 + 4 * NJ + 6 + 3 * NJ;  // 174

@@ -144,6 +144,7 @@ class BodyModel:
 
     def __init__(self, blob, default_humanoid_mass=90.0, kp_scale=1.0, kd_scale=1.0):
         self.blob = {k: np.asarray(v) for k, v in blob.items()}
+        self.model_kw = dict(default_humanoid_mass=default_humanoid_mass, kp_scale=kp_scale, kd_scale=kd_scale)  # what derived models inherit
         self.body_names = [str(x) for x in self.blob["body_names"]]
         self.parents = self.blob["parents"].astype(np.int32)
         self.num_bodies = len(self.body_names)
@@ -178,7 +179,7 @@ class BodyModel:
         blob["hull_verts"] = self.blob["hull_verts"] * s
         blob["mass"] = self.blob["mass"] * s ** 3
         blob["inertia"] = self.blob["inertia"] * s ** 5
-        return BodyModel(blob, **kw)
+        return BodyModel(blob, **{**self.model_kw, **kw})
 
     def body_index(self, name):
         return self.body_names.index(name)

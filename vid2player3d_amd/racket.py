@@ -74,8 +74,11 @@ def with_racket(base, wrist_vertex_budget=30, arm_limits=True, player="djokovic"
     player MJCF's joint ranges of the racket arm (enforced when cfg['env']['joint_limits'] is on).  player: djokovic / federer (right
     hand) or nadal (left hand: the reference's cfg_v2p righthand = False)."""
     spec = PLAYERS[player]
+    if "racket_player" in base.blob:
+        raise ValueError("this body model already carries a racket (%s): fold it into the plain body model, once" % str(base.blob["racket_player"]))
     b = base.body_index(spec["parent"])
     blob = dict(base.blob)
+    blob["racket_player"] = np.asarray(player)
     if arm_limits:
         lo, hi = base.limit_lower.copy(), base.limit_upper.copy()
         for name, ranges in spec["limits"].items():
@@ -112,4 +115,5 @@ def with_racket(base, wrist_vertex_budget=30, arm_limits=True, player="djokovic"
     geom = {"racket_link": b, "racket_offset": np.array(spec["offset"], float), "player": player,
             "cylinders": [{"center": c[0], "axis": c[1], "half_len": c[2], "radius": c[3]} for c in cyls],
             "racket_mass": float(sum(p[0] for p in parts[1:]))}
-    return BodyModel(blob, **model_kw), geom
+    # the gain / mass scales the base model was built with carry over (cfg env kp_scale, kd_scale, default_humanoid_mass)
+    return BodyModel(blob, **{**getattr(base, "model_kw", {}), **model_kw}), geom

@@ -25,7 +25,9 @@ BALL_R = racket.BALL["radius"]
 
 class HumanoidSMPLIMRacketBall(HumanoidSMPLIM):
     def __init__(self, cfg, sim_params=None, physics_engine=None, device_type="cuda", device_id=0, headless=True):
-        env = cfg["env"]
+        # (work on a copy: the caller's cfg stays what it was, a second task built from it starts from the plain body model again)
+        cfg = dict(cfg)
+        env = cfg["env"] = dict(cfg["env"])
         base = env.get("body_model") or load_baked_model(default_humanoid_mass=env.get("default_humanoid_mass", 90.0), kp_scale=env.get("kp_scale", 1.0),
                                                          kd_scale=env.get("kd_scale", env.get("kp_scale", 1.0)))
         if isinstance(base, (list, tuple)):
@@ -60,9 +62,10 @@ class HumanoidSMPLIMRacketBall(HumanoidSMPLIM):
         mat = dict(racket.BALL_MATERIAL)
         if "restitution" in self.cfg_v2p:  # cfg_v2p.restitution sets ball AND racket head (:414, :436); the plane keeps 0
             mat["rest_ground"], mat["rest_racket"] = 0.5 * self.cfg_v2p["restitution"], self.cfg_v2p["restitution"]
+            mat["rest_body"] = 0.5 * self.cfg_v2p["restitution"]  # ball x a link's hull: the humanoid's shapes keep restitution 0
         if "ball_friction" in self.cfg_v2p or "racket_friction" in self.cfg_v2p:
             bf, rf = self.cfg_v2p.get("ball_friction", 0.8), self.cfg_v2p.get("racket_friction", 0.8)
-            mat["fric_ground"], mat["fric_racket"] = 0.5 * (bf + 1.0), 0.5 * (bf + rf)
+            mat["fric_ground"], mat["fric_racket"], mat["fric_body"] = 0.5 * (bf + 1.0), 0.5 * (bf + rf), 0.5 * (bf + 1.0)
         g = self.racket_geometry
         c = _lib.BallCfg(radius=racket.BALL["radius"], mass=racket.BALL["mass"], inertia=racket.BALL["inertia"],
                          restitution_ground=mat["rest_ground"], friction_ground=mat["fric_ground"], restitution_racket=mat["rest_racket"],
