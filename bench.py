@@ -247,7 +247,9 @@ def run_ppo(args, task, dist, world, rank):
     (im_agent.py:204-214), whole job = sum over ranks of frames over the slowest rank's time."""
     from vid2player3d_amd.ppo import PPOAgent
 
-    agent = PPOAgent(task, seed=7)
+    tasks = task if isinstance(task, list) else [task]
+    task = tasks[0]
+    agent = PPOAgent(tasks if len(tasks) > 1 else task, seed=7, reuse_next_values=not args.ppo_reference_critic_passes, overlap_critic=not args.ppo_no_overlap)
     agent.train_epoch()  # warm-up epoch (allocator, rocBLAS heuristics, running statistics)
     rows = []
     for _ in range(args.ppo_epochs):
@@ -268,12 +270,15 @@ def run_ppo(args, task, dist, world, rank):
                "steps": args.ppo_epochs * HORIZON, "warmup": HORIZON, "ms_per_step": 1e3 * total / (args.ppo_epochs * HORIZON), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "FULL PPO LOOP (BASELINE config 5 shape, reported separately from the rollout metric): amass_im num_envs=%d per GPU, "
-                                      "horizon 32, actor/critic MLP [1024,1024,512] on the 734-d observation, 6 mini-epochs x minibatches of 512 envs; value = fps total"
-                                      % args.num_envs,
+                                      "horizon 32, actor/critic MLP [1024,1024,512] on the 734-d observation (residual action), 6 mini-epochs x minibatches of 512 envs; "
+                                      "%d rollout group(s) per GPU, critic %s; value = fps total"
+                                      % (args.num_envs, len(tasks), "twice per step like the reference" if args.ppo_reference_critic_passes else "once per step (next_values reused as values)" + ("" if args.ppo_no_overlap else ", on a side stream beside the physics launch")),
                           "num_envs_per_gpu": args.num_envs, "global_envs": world * args.num_envs,
                           "parallelism": "env-sharded x%d; advantage statistics, running norms and gradients all-reduced over RCCL at the update" % world,
                           "fps_step": world * frames / play, "fps_total": world * frames / total,
                           "T_play_s_per_epoch": play / args.ppo_epochs, "T_update_s_per_epoch": (total - play) / args.ppo_epochs,
+                          "rollout_groups": len(tasks),
+                          "step_rewards_by_epoch": [r["step_rewards"] for r in rows], "step_sub_rewards_last_epoch": rows[-1]["step_sub_rewards"],
                           "step_rewards_last_epoch": rows[-1]["step_rewards"], "alive_ratio_last_epoch": rows[-1]["alive_ratio"]},
                "build": build.build_info()}
         line = json.dumps(out)
@@ -304,6 +309,10 @@ def main():
     ap.add_argument("--per-clip-shapes", action="store_true", help="one body shape per clip (64 scaled bodies) instead of one shape for all envs")
     ap.add_argument("--ppo", action="store_true", help="BASELINE config 5 loop: device-resident rollout (play_steps) + GAE + PPO update per epoch; prints the reference's fps step / fps total")
     ap.add_argument("--ppo-epochs", type=int, default=4, help="timed PPO epochs (after one untimed warm-up epoch)")
+    ap.add_argument("--groups", type=int, default=1, help="rollout groups per GPU: the rank's envs as G env batches on G HIP streams (reported separately from the headline; "
+                    "with --ppo the physics of one group overlaps the policy inference of the other)")
+    ap.add_argument("--ppo-no-overlap", action="store_true", help="--ppo: the critic pass on the rollout's own stream instead of a side stream beside the physics (A/B)")
+    ap.add_argument("--ppo-reference-critic-passes", action="store_true", help="--ppo: evaluate the critic twice per step like the reference (A/B of reuse_next_values)")
     ap.add_argument("--stub-task", action="store_true", help=argparse.SUPPRESS)  # launch-logic test without GPUs (gloo, CPU); never a measurement
     args = ap.parse_args()
 
@@ -335,24 +344,32 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     n = args.num_envs
+    G = max(1, args.groups)
+    if n % G:
+        raise SystemExit("--num-envs %d is not a multiple of --groups %d" % (n, G))
     if stub:
         task = StubTask(n)
+        tasks = [task]
     else:
         from vid2player3d_amd import build
         if local_rank == 0:
             build.build()  # no-op when the in-tree .so is current; one rank per node compiles otherwise
         if dist is not None:
             dist.barrier()
-        task = build_task(n, local_rank, seed=7 + rank, contact=not args.no_contact, per_clip_shapes=args.per_clip_shapes, djokovic=args.djokovic or args.racket_ball,
+        tasks = [build_task(n // G, local_rank, seed=7 + rank + 100 * g, contact=not args.no_contact, per_clip_shapes=args.per_clip_shapes, djokovic=args.djokovic or args.racket_ball,
                           freeze=args.freeze_terminated, solver=args.solver, racket_ball=args.racket_ball, substep_jobs=bool(args.substep_jobs),
                           joint_limits=args.joint_limits,
                           env_extra={k: v for k, v in (("job_mono_permille", args.job_mono), ("pair_mix_permille", args.pair_mix), ("ball_body_contacts", None if args.ball_body_contacts else False)) if v is not None})  # per-rank seed like run.py:37
+                 for g in range(G)]
+        task = tasks[0]
     if args.ppo:
-        return run_ppo(args, task, dist, world, rank)
+        return run_ppo(args, tasks if G > 1 else task, dist, world, rank)
     dev = task.device
     gen = torch.Generator(device=dev)
     gen.manual_seed(7 + rank)
+    ng = n // G
     noise = [args.action_noise * torch.randn((n, 75), device=dev, generator=gen) for _ in range(HORIZON)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(G)] if G > 1 else [None]
 
     def sync():
         if not stub:
@@ -365,23 +382,41 @@ def main():
             sync()
 
     def run(nsteps):
+        if G == 1:
+            for i in range(nsteps):
+                if i % HORIZON == 0:
+                    task.reset()
+                task.step_fused(make_actions(task, noise[i % HORIZON]))
+            return
+        # rollout groups: group g's envs on stream g; the launches of the groups interleave on the GPU (each fills the other's tail)
+        main = torch.cuda.current_stream(dev)
+        for st in streams:
+            st.wait_stream(main)
         for i in range(nsteps):
-            if i % HORIZON == 0:
-                task.reset()
-            task.step_fused(make_actions(task, noise[i % HORIZON]))
+            for g, (tk, st) in enumerate(zip(tasks, streams)):
+                with torch.cuda.stream(st):
+                    if i % HORIZON == 0:
+                        tk.reset()
+                    tk.step_fused(make_actions(tk, noise[i % HORIZON][g * ng:(g + 1) * ng]))
+        for st in streams:
+            main.wait_stream(st)
 
     run(args.warmup)
     barrier()
-    task.profile_begin(args.steps)  # events around the physics kernel of every timed step, recorded by the engine on the launch stream
+    for tk in tasks:
+        tk.profile_begin(args.steps)  # events around the physics kernel of every timed step, recorded by the engine on the launch stream
     t0 = time.perf_counter()
     run(args.steps)
     barrier()
     elapsed_local = time.perf_counter() - t0
-    phys_ms_total, launches = task.profile_end()
-    if hasattr(task, "check"):
-        task.check()  # device-side errors (a substep job that timed out) fail the run instead of producing a number
+    phys_ms_total, launches = 0.0, 0
+    for tk in tasks:
+        a_, b_ = tk.profile_end()
+        phys_ms_total, launches = phys_ms_total + a_, launches + b_
+        if hasattr(tk, "check"):
+            tk.check()  # device-side errors (a substep job that timed out) fail the run instead of producing a number
     phys_ms = phys_ms_total / max(launches, 1)
-    alive = float((task.reset_buf == 0).float().mean().item())
+    alive = float(torch.cat([(tk.reset_buf == 0).float() for tk in tasks]).mean().item())
     elapsed, per_rank = elapsed_local, [n * args.steps / elapsed_local]
     world_seen = 1
     if dist is not None:
@@ -395,15 +430,17 @@ def main():
 
     if rank == 0:
         value = world * n * args.steps / elapsed
-        achieved = ALGO_BYTES_PER_ENV_STEP * n / (phys_ms * 1e-3) / 1e9
+        achieved = ALGO_BYTES_PER_ENV_STEP * ng / (phys_ms * 1e-3) / 1e9
         valu, traffic = profiles_view()
         roof = {"bound": "hbm", "kernel": "physics_ll_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None if traffic is None else traffic["bytes_per_launch"],
                 "traffic_source": None if traffic is None else traffic["source"], "kernel_ms": phys_ms, "kernel_launches_timed": launches,
                 "kernel_ms_source": "HIP events recorded by the engine around every physics launch of the timed steps (launch stream)",
-                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n,
+                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * ng,
                 "note": "the kernel is VALU-issue bound, not HBM bound (DESIGN.md): valu_frac is the fraction that says how good it is"}
-        if valu is not None and n == 8192 and not args.no_contact:
+        if G > 1:
+            roof["note"] += "; %d ROLLOUT GROUPS: the launches of the groups overlap on the GPU, kernel_ms is the duration of one group's launch WHILE the others run" % G
+        if valu is not None and n == 8192 and G == 1 and not args.no_contact:
             tflops = valu["flops_per_launch"] / (phys_ms * 1e-3) / 1e12
             roof.update({"valu_tflops": tflops, "valu_peak_tflops": FP32_VECTOR_PEAK_TFLOPS, "valu_frac": tflops / FP32_VECTOR_PEAK_TFLOPS, "valu": valu})
         out = {
@@ -413,6 +450,7 @@ def main():
             "config": {"workload": "amass_im num_envs=%d per GPU, %s, imitation reward, per-epoch reset+context every %d steps, 64 synthetic clips, action noise %.3g%s"
                                    % (n, "PD control only (no contact solve)" if args.no_contact else "full contact %s (4 substeps x 4 iterations)" % args.solver.upper(), HORIZON,
                                       args.action_noise, (", one NON-UNIFORM body shape per clip (64 shapes from vertex clouds)" if args.per_clip_shapes else "") + (", djokovic_im variant" if args.djokovic or args.racket_ball else "") + (", RACKET + BALL in every env (reported separately)" if args.racket_ball else "") + (", joint limits on" if (args.joint_limits if args.joint_limits is not None else args.racket_ball) else "") +
+                                      (", %d ROLLOUT GROUPS of %d envs on %d streams (reported separately from the headline)" % (G, ng, G) if G > 1 else "") +
                                       (", TERMINATED ENVS FROZEN (not reference behaviour)" if args.freeze_terminated else "") + (", STUB TASK (launch-logic test, not a measurement)" if stub else "")),
                        "num_envs_per_gpu": n, "global_envs": world * n, "parallelism": "env-sharded x%d, no data-path collective" % world,
                        "world_size_seen": world_seen, "backend": None if dist is None else ("gloo" if stub else "nccl(rccl)"),

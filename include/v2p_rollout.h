@@ -34,7 +34,7 @@ extern "C" {
 #define V2P_NUM_OBS 461
 #define V2P_MOTION_STATE_DIM 331  /* root_pos3 root_rot4 dof_pos69 root_vel3 root_ang_vel3 dof_vel69 key_pos12 rb_pos72 rb_rot96 */
 #define V2P_CONTEXT_DIM 378       /* body_pos72 body_rot96 dof_pos69 body_pos_gt72 dof_pos_gt69 (humanoid_smpl_im.py:202) */
-#define V2P_ABI_VERSION 8
+#define V2P_ABI_VERSION 9
 
 typedef enum {
     V2P_OK = 0,
@@ -134,6 +134,16 @@ int v2p_obs_imitation(int64_t n, const float* body_pos, const float* body_rot, c
 int v2p_obs_imitation_packed(int64_t rows, int64_t steps, const float* obs /*[rows,461]*/, const float* context_feat /*[rows/steps,ctx_frames,378]*/,
                              int64_t ctx_frames, int64_t first_frame, const float* norm_mean /*nullable*/, const float* norm_std /*nullable*/,
                              float norm_clip, float* out /*[rows,734]*/, void* stream);
+
+/* Policy head of the rollout (ABI 9): what the reference does between the actor MLP and the env step.
+ *   models/im_network_builder.py:219-228 (eval_actor, residual_action = True): mu[:, :69] += cur_context['dof_pos'] - the target DOF
+ *     positions of context frame `frame` (= context_padding + t in the rollout), read straight from context_feat [n,ctx_frames,378];
+ *   models/im_models.py:45-48: action = Normal(mu, sigma).sample() = mu + sigma * noise, neglogp (rl_games ModelA2CContinuousLogStd):
+ *     0.5 sum(((a - mu) / sigma)^2) + 0.5 log(2 pi) * 75 + sum(logstd), sigma = exp(logstd) (fixed_sigma, cfg/amass_im.yaml:76-81).
+ * mu [n,75]: the actor MLP's output on entry, the residual mean on exit; noise [n,75] standard normal (the caller's generator);
+ * action [n,75], sigma [n,75] (nullable), neglogp [n] are written. */
+int v2p_policy_head(int64_t n, float* mu, const float* context_feat, int64_t ctx_frames, int64_t frame, const float* logstd /*[75]*/,
+                    const float* noise, float* action, float* sigma, float* neglogp, void* stream);
 
 /* GAE reverse scan of the PPO rollout, CommonAgent.discount_values (learning/common_agent.py:423-435):
  * fdones [T,N], values / rewards / next_values / advs [T,N,1] (device). */

@@ -1,0 +1,135 @@
+"""The PPO loop on the MI355X against the vectors recorded from the reference's own `ImitatorAgent` methods (oracle/gen_golden_ppo.py):
+`play_steps` with the recorded rollout replayed as the env (network forward in eval mode through the HIP feature kernel, the policy-head
+kernel - residual action, sample, neglogp -, the value normaliser, next-value masking, GAE kernel, alive mask, episode statistics), then
+`prepare_dataset` + `calc_gradients` on the GPU with the HIP features.  And the two restructurings of the rollout that must not change a
+bit: the critic evaluated once per step, and the envs split into two groups on two streams."""
+import numpy as np
+import pytest
+import torch
+
+from tests.gpu_util import DEV, N, make_task
+from tests.test_ppo_reference import G, PAD, T, TR, check_update_against_golden, make_agent
+
+pytestmark = pytest.mark.gpu
+
+
+class TraceTask:
+    """the recorded reference rollout (tests/golden/env_trace.npz, epoch 0) as a VecTask: whatever the actions, step k shows what the
+    reference's task showed after its step k"""
+
+    def __init__(self):
+        t = lambda x, dt=torch.float32: torch.as_tensor(np.asarray(x)).to(device=DEV, dtype=dt).contiguous()  # noqa: E731
+        self.device, self.num_envs, self.num_obs, self.num_actions, self.context_padding = DEV, 6, 461, 75, PAD
+        self.context_feat = t(TR["e0_context_feat"])
+        self.context_mask = t(TR["e0_context_mask"], torch.bool)
+        self._obs = t(G["env/obs"])
+        self._rew, self._done, self._term, self._sub = t(G["env/rewards"]), t(G["env/dones"], torch.long), t(G["env/terminate"], torch.long), t(G["env/sub_rewards"])
+        self.obs_buf, self.rew_buf = torch.zeros((6, 461), device=DEV), torch.zeros(6, device=DEV)
+        self.reset_buf = torch.zeros(6, dtype=torch.long, device=DEV)
+        self.extras = {}
+        self.k = 0
+
+    def reset(self):
+        self.k = 0
+        self.obs_buf.copy_(self._obs[0])
+        self.reset_buf.zero_()
+
+    def step(self, actions):
+        k = self.k
+        self.obs_buf.copy_(self._obs[k + 1])
+        self.rew_buf.copy_(self._rew[k])
+        self.reset_buf.copy_(self._done[k])
+        self.extras = {"terminate": self._term[k], "sub_rewards": self._sub[k]}
+        self.k = k + 1
+
+
+def test_play_steps_matches_the_references_method():
+    agent = make_agent(TraceTask())
+    mus, sig, act = (torch.as_tensor(G["play/" + k]).to(DEV) for k in ("mus", "sigmas", "actions"))
+    agent.noise_fn = lambda n: ((act[:, n] - mus[:, n]) / sig[:, n]).contiguous()  # the draws the reference's Normal.sample() made
+    batch = agent.play_steps()
+    torch.cuda.synchronize()
+    for k, tol in (("values", 2e-5), ("mus", 2e-5), ("sigmas", 1e-6), ("actions", 2e-5), ("neglogpacs", 2e-4), ("returns", 5e-5)):
+        np.testing.assert_allclose(N(batch[k]), G["play/" + k], rtol=tol, atol=tol, err_msg=k)
+    np.testing.assert_allclose(N(batch["next_values"]), G["play/next_values"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(N(batch["rewards"]), G["play/rewards"], rtol=0, atol=0)
+    assert np.array_equal(N(batch["dones"]), G["play/dones"].astype(np.float32)) and np.array_equal(N(batch["alive"]), G["play/alive"])
+    assert np.array_equal(N(batch["obses"]), G["play/obses"]) and np.array_equal(N(batch["next_obses"]), G["play/next_obses"])
+    assert batch["played_frames"] == int(G["play/played_frames"])
+    # the residual action is in the means: without it they would be off by the context's target DOF positions (O(1) rad)
+    tgt = TR["e0_context_feat"][:, PAD:PAD + T, 168:237]
+    assert np.abs(tgt).max() > 0.3
+    # episode statistics: device accumulators == the reference's host-side meters
+    acc, sub = (x.cpu().numpy() for x in batch["stats"])
+    assert acc[0] == len(G["play/game_rewards"])
+    np.testing.assert_allclose(acc[1], G["play/game_rewards"].sum(), rtol=1e-5)
+    np.testing.assert_allclose(acc[2], G["play/game_lengths"].sum(), rtol=0)
+    assert acc[3] == float(G["play/step_count"])
+    np.testing.assert_allclose(acc[4] / acc[3], float(G["play/step_rewards_avg"][0]), rtol=1e-5)
+    np.testing.assert_allclose(sub / acc[3], G["play/step_sub_rewards_avg"], rtol=1e-5)
+    np.testing.assert_allclose(float(batch["alive"].mean()), float(G["play/alive_ratio"]), rtol=1e-6)
+
+
+def test_update_on_the_gpu_matches_the_references_methods():
+    """prepare_dataset (HIP feature kernel, training flavour) + calc_gradients on cuda tensors"""
+    agent = make_agent(TraceTask())
+    check_update_against_golden(agent, None, device=DEV, tol=2.0)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from vid2player3d_amd import motion_tables, synth
+    from vid2player3d_amd.model import load_baked_model
+    from vid2player3d_amd.motion_lib import MotionLib
+
+    bm = load_baked_model()
+    tabs = motion_tables.build_tables(synth.make_clips(11, 8, 90, 160), bm.parents, bm.local_pos)
+    return MotionLib(tabs, DEV)
+
+
+def _rollout(lib, n, groups, reuse, seed=9, flat_heads=False, overlap=True):
+    from vid2player3d_amd.ppo import PPOAgent
+
+    rng = np.random.default_rng(seed)
+    ids = rng.integers(0, 8, size=n)
+    times = torch.as_tensor(rng.uniform(0.05, 1.2, size=n).astype(np.float32)).to(DEV)
+    bounds = np.linspace(0, n, groups + 1).astype(int)
+    tasks = [make_task(int(bounds[g + 1] - bounds[g]), lib, motion_ids=ids[bounds[g]:bounds[g + 1]]) for g in range(groups)]
+    agent = PPOAgent(tasks if groups > 1 else tasks[0], units=(64, 32), seed=3, sigma_init=-0.7, reuse_next_values=reuse, overlap_critic=overlap)
+    agent.model.running_obs.update(torch.randn(512, 734, device=DEV) * 2.0 + 0.3)  # (a normaliser that does something)
+    if flat_heads:
+        # the output layers answer with their bias whatever the input: a GEMM library may sum a row in a different order when the batch
+        # has another number of rows (96 vs 192), and one ulp in an action is a different trajectory 32 contact-rich steps later
+        with torch.no_grad():
+            agent.model.mu.weight.zero_()
+            agent.model.value.weight.zero_()
+            agent.model.mu.bias.copy_(torch.linspace(-0.1, 0.1, 75))
+    batch = agent.play_steps(reset_fn=lambda task, g: task.reset_with_times(None, times[bounds[g]:bounds[g + 1]].contiguous()))
+    torch.cuda.synchronize()
+    out = {k: N(v).copy() for k, v in agent.experience_buffer.tensor_dict.items()}
+    out["returns"] = N(batch["returns"]).copy()
+    out["stats"] = np.concatenate([N(x) for x in batch["stats"]])
+    out["context"] = N(batch["context_feat"]).copy()
+    for t in tasks:
+        t.close()
+    return out
+
+
+def test_one_critic_pass_per_step_beside_the_physics_is_bit_identical(lib):
+    """the reference's two critic passes per step == one pass whose result serves both == that pass on a side stream next to the physics"""
+    a, b, c = _rollout(lib, 192, 1, False), _rollout(lib, 192, 1, True, overlap=False), _rollout(lib, 192, 1, True, overlap=True)
+    assert a["dones"].sum() > 0 and np.abs(a["values"]).max() > 0 and np.abs(a["next_values"]).max() > 0
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+        assert np.array_equal(a[k], c[k]), k
+
+
+def test_two_rollout_groups_fill_the_same_buffer(lib):
+    """192 envs as one batch on one stream == 96 + 96 on two streams (same clips, same start times, same noise per env)"""
+    a, b = _rollout(lib, 192, 1, True, flat_heads=True), _rollout(lib, 192, 2, True, flat_heads=True)
+    assert a["dones"].sum() > 0 and np.abs(a["actions"]).max() > 0.5
+    for k in a:
+        if k == "stats":
+            np.testing.assert_allclose(a[k], b[k], rtol=1e-6)  # (float32 partial sums taken in two halves)
+        else:
+            assert np.array_equal(a[k], b[k]), k

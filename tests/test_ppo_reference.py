@@ -1,0 +1,178 @@
+"""The PPO update of vid2player3d_amd/ppo.py against vectors recorded by running the reference's OWN methods (oracle/gen_golden_ppo.py ->
+tests/golden/ppo_trace.npz): `_calc_advs`, `prepare_dataset` (value normaliser in training mode) and four `calc_gradients` calls (losses,
+masked KL, clip fraction, per-minibatch RunningNorm update, residual action in the training-mode forward, gradient-norm clip, Adam) on a
+real recorded rollout of 6 envs x 32 steps.  Pure torch on the CPU: the one HIP op of the update (the raw 734-d features) is supplied by
+the numpy oracle here and compared with the kernel in tests/test_gpu_ppo_reference.py.  Plus: two data-parallel ranks (gloo) == one
+process on the concatenated batch."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import task_oracle as O
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "ppo_trace.npz"))
+TR = np.load(os.path.join(os.path.dirname(__file__), "golden", "env_trace.npz"))
+N_ENV, T, PAD = 6, 32, 8
+
+
+def stub_task(n=N_ENV, device="cpu"):
+    return types.SimpleNamespace(device=device, num_envs=n, num_obs=461, num_actions=75, context_padding=PAD)
+
+
+def reference_weights(prefix="w0/"):
+    return {k[len(prefix):]: torch.as_tensor(G[k]) for k in G.files if k.startswith(prefix)}
+
+
+def oracle_features(obses, context_feat):
+    """[N,T,461] + [N,L,378] -> raw [N,T,734] (preprocess_input, flatten=True: row (e, k) pairs with context frame PAD + k)"""
+    n, t = obses.shape[:2]
+    o = obses.reshape(n * t, 461)
+    c = context_feat[:, PAD:PAD + t].reshape(n * t, 378)
+    f = O.obs_imitation_734(o[:, 0:72].reshape(-1, 24, 3), o[:, 72:168].reshape(-1, 24, 4), c[:, 0:72].reshape(-1, 24, 3), c[:, 72:168].reshape(-1, 24, 4),
+                            o[:, 168:237], o[:, 237:306], c[:, 168:237], o[:, 306:378].reshape(-1, 24, 3), o[:, 378:450].reshape(-1, 24, 3), o[:, 450:461])
+    return f.reshape(n, t, 734).astype(np.float32)
+
+
+def make_agent(task=None, **kw):
+    from vid2player3d_amd.ppo import PPOAgent
+
+    agent = PPOAgent(task or stub_task(), horizon_length=T, units=tuple(int(u) for u in G["units"]), minibatch_envs=3, learning_rate=float(G["grad/lr"]), **kw)
+    agent.model.load_reference_state_dict(reference_weights())
+    agent.value_mean_std.running_mean.fill_(float(G["vms0"][0]))
+    agent.value_mean_std.running_var.fill_(float(G["vms0"][1]))
+    agent.value_mean_std.count.fill_(float(G["vms0"][2]))
+    return agent
+
+
+def golden_batch(device="cpu"):
+    t = lambda k: torch.as_tensor(G[k]).to(device)  # noqa: E731
+    obses = np.stack([G["env/obs"][k] for k in range(T)], axis=1)  # [N,T,461]: the observation BEFORE step k
+    return {"obses": torch.as_tensor(obses).to(device), "values": t("play/values"), "returns": t("play/returns"), "alive": t("play/alive"),
+            "neglogpacs": t("play/neglogpacs"), "actions": t("play/actions"), "mus": t("play/mus"), "sigmas": t("play/sigmas"),
+            "dones": t("play/dones").float(), "context_feat": torch.as_tensor(TR["e0_context_feat"]).to(device)}
+
+
+def test_calc_advs_matches_the_references_method():
+    agent = make_agent()
+    b = golden_batch()
+    np.testing.assert_allclose(agent._calc_advs(b).numpy(), G["advs/normalized"], rtol=2e-5, atol=2e-6)
+    agent.normalize_advantage = False
+    np.testing.assert_allclose(agent._calc_advs(b).numpy(), G["advs/raw"], rtol=1e-6, atol=1e-7)
+
+
+def check_update_against_golden(agent, feat_raw, device="cpu", tol=1.0):
+    """prepare_dataset + the four recorded calc_gradients calls; tol scales the tolerances (GPU GEMMs sum in another order)"""
+    b = golden_batch(device)
+    agent.set_train()
+    ds = agent.prepare_dataset(b, feat_raw=feat_raw)
+    for k in ("old_values", "returns", "advantages", "old_logp_actions"):
+        np.testing.assert_allclose(ds[k].cpu().numpy(), G["data/" + k], rtol=2e-5 * tol, atol=5e-6 * tol, err_msg=k)
+    v = agent.value_mean_std
+    np.testing.assert_allclose([float(v.running_mean), float(v.running_var), float(v.count)], G["vms1"], rtol=1e-6)
+    perms = G["grad/perms"]
+    call = 0
+    for perm in perms:
+        for i in range(2):
+            idx = torch.as_tensor(perm[3 * i:3 * i + 3]).to(device)
+            agent.grad_norm = float(G["grad/%d/grad_norm_clip" % call])
+            r = agent.calc_gradients({k: x[idx] for k, x in ds.items()})
+            for k in ("actor_loss", "critic_loss", "entropy", "kl"):
+                np.testing.assert_allclose(float(r[k]), float(G["grad/%d/%s" % (call, k)]), rtol=2e-4 * tol, atol=2e-6 * tol, err_msg="call %d %s" % (call, k))
+            assert abs(float(r["actor_clip_frac"]) - float(G["grad/%d/actor_clip_frac" % call])) <= 2.1 / 96, call  # (a count over 96 samples)
+            rn = agent.model.running_obs
+            assert int(rn.n) == int(G["grad/%d/rn_n" % call])
+            np.testing.assert_allclose(rn.mean.cpu().numpy(), G["grad/%d/rn_mean" % call], rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(rn.std.cpu().numpy(), G["grad/%d/rn_std" % call], rtol=1e-5, atol=1e-6)
+            sd = agent.model.state_dict()
+            for k, w in sd.items():
+                ref = G["grad/%d/w/a2c_network.%s" % (call, k)]
+                # Adam's first steps move every weight by ~lr whatever the gradient's size: compare in units of the step
+                assert np.abs(w.cpu().numpy() - ref).max() <= 0.02 * float(G["grad/lr"]) * (call + 1) * tol + 1e-7, "call %d weight %s" % (call, k)
+            call += 1
+    assert call == int(G["grad/calls"])
+
+
+def test_prepare_dataset_and_calc_gradients_match_the_references_methods():
+    agent = make_agent()
+    feat = torch.as_tensor(oracle_features(golden_batch()["obses"].numpy(), TR["e0_context_feat"]))
+    check_update_against_golden(agent, feat)
+    # the four updates moved the weights by far more than the comparison allows (the test has teeth)
+    w_first = G["grad/0/w/a2c_network.mu.weight"]
+    assert np.abs(agent.model.mu.weight.detach().numpy() - w_first).max() > 20 * 0.02 * float(G["grad/lr"]) * 4
+
+
+def test_masked_mean_divides_by_the_number_of_elements():
+    from vid2player3d_amd.ppo import masked_mean
+
+    x, m = torch.tensor([[1.0], [3.0], [5.0], [7.0]]), torch.tensor([[1.0], [0.0], [1.0], [0.0]])
+    assert float(masked_mean(x, m)) == 1.5  # (1 + 5) / 4, like (kl_dist * alive).sum() / alive.numel() at im_agent.py:573
+
+
+def test_reference_checkpoint_names_load():
+    agent = make_agent()
+    sd = reference_weights()
+    assert set(k for k in sd if "running_obs" not in k) == set("a2c_network." + k for k in agent.model.state_dict())
+    assert int(agent.model.running_obs.n) == 1000
+
+
+# ---------------------------------------------------------------- two data-parallel ranks == one process on the concatenated batch
+def _rank_main(rank, world, port, q):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    b = golden_batch()
+    feat = torch.as_tensor(oracle_features(b["obses"].numpy(), TR["e0_context_feat"]))
+    lo, hi = rank * 3, rank * 3 + 3
+    agent = make_agent(stub_task(3))
+    shard = {k: (v[lo:hi] if k != "context_feat" else v[lo:hi]) for k, v in b.items()}
+    agent.set_train()
+    ds = agent.prepare_dataset(shard, feat_raw=feat[lo:hi])
+    adv = ds["advantages"].clone()
+    for order in ([0, 1, 2], [2, 0, 1]):
+        for i in range(3):  # minibatches of one env per rank
+            j = order[i]
+            agent.minibatch_envs = 1
+            agent.calc_gradients({k: x[j:j + 1] for k, x in ds.items()})
+    q.put((rank, adv.numpy(), {k: v.numpy() for k, v in agent.model.state_dict().items()}, agent.model.running_obs.mean.numpy(),
+           [float(agent.value_mean_std.running_mean), float(agent.value_mean_std.running_var), float(agent.value_mean_std.count)]))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_process_on_the_concatenated_batch():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single process, 6 envs, minibatch k = {env order[k] of rank 0, env order[k] of rank 1}
+    b = golden_batch()
+    feat = torch.as_tensor(oracle_features(b["obses"].numpy(), TR["e0_context_feat"]))
+    agent = make_agent()
+    agent.set_train()
+    ds = agent.prepare_dataset(b, feat_raw=feat)
+    for order in ([0, 1, 2], [2, 0, 1]):
+        for i in range(3):
+            idx = torch.tensor([order[i], 3 + order[i]])
+            agent.calc_gradients({k: x[idx] for k, x in ds.items()})
+    adv_two = np.concatenate([got[0][1], got[1][1]], axis=0)
+    np.testing.assert_allclose(adv_two, ds["advantages"].numpy(), rtol=1e-5, atol=1e-6)  # global advantage statistics
+    for k, w in agent.model.state_dict().items():
+        assert np.array_equal(got[0][2][k], got[1][2][k]), "ranks hold different weights: " + k
+        assert np.abs(got[0][2][k] - w.numpy()).max() <= 0.02 * float(G["grad/lr"]) * 6 + 1e-7, k
+    assert np.array_equal(got[0][3], got[1][3])
+    np.testing.assert_allclose(got[0][3], agent.model.running_obs.mean.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(got[0][4], got[1][4])
+    v = agent.value_mean_std
+    np.testing.assert_allclose(got[0][4], [float(v.running_mean), float(v.running_var), float(v.count)], rtol=1e-9)

@@ -227,6 +227,50 @@ int launch_gae(int64_t horizon, int64_t n, const float* fdones, const float* val
 }
 
 // ------------------------------------------------------------------------------------------
+// policy head of the rollout (models/im_network_builder.py:219-228 `eval_actor`: residual action, mu[:, :69] += the context's dof_pos of
+// step t; models/im_models.py:45-48: action = Normal(mu, sigma).sample(), neglogp): one wave per env, the 75 action components on lanes
+// k and k + 64, the two sums of neglogp as wave reductions.  `noise` is the standard-normal draw (torch's generator stays the source
+// of randomness), `mu` holds the network's output on entry and the residual mean on exit.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void policy_head_kernel(int64_t n, float* __restrict__ mu, const float* __restrict__ context_feat, int64_t ctx_frames,
+                                                          int64_t frame, const float* __restrict__ logstd, const float* __restrict__ noise,
+                                                          float* __restrict__ action, float* __restrict__ sigma_out, float* __restrict__ neglogp) {
+    const int lane = threadIdx.x & 63;
+    const int64_t e = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= n) return;
+    const float* tgt = context_feat + (e * ctx_frames + frame) * V2P_CONTEXT_DIM + 168;  // dof_pos block of the context frame
+    float quad = 0.f, lsum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int k = lane + 64 * r;
+        if (k < NACT) {
+            const int64_t i = e * NACT + k;
+            float m = mu[i];
+            if (k < NDOF) m += tgt[k];
+            const float ls = logstd[k], sg = expf(ls);
+            const float a = m + sg * noise[i];
+            const float z = (a - m) / sg;
+            mu[i] = m;
+            action[i] = a;
+            if (sigma_out) sigma_out[i] = sg;
+            quad += z * z;
+            lsum += ls;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { quad += __shfl_xor(quad, o); lsum += __shfl_xor(lsum, o); }
+    if (lane == 0) neglogp[e] = 0.5f * quad + 0.5f * 1.8378770664093453f * (float)NACT + lsum;  // log(2 pi)
+}
+
+int launch_policy_head(int64_t n, float* mu, const float* context_feat, int64_t ctx_frames, int64_t frame, const float* logstd, const float* noise,
+                       float* action, float* sigma_out, float* neglogp, hipStream_t s) {
+    if (n <= 0) return V2P_OK;
+    hipLaunchKernelGGL(policy_head_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, n, mu, context_feat, ctx_frames, frame, logstd, noise, action,
+                       sigma_out, neglogp);
+    return check_hip(hipGetLastError(), "policy_head_kernel");
+}
+
+// ------------------------------------------------------------------------------------------
 // env kernels
 // ------------------------------------------------------------------------------------------
 struct EnvView {

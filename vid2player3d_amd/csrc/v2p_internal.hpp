@@ -195,6 +195,8 @@ int launch_obs_imitation(int64_t n, const float* body_pos, const float* body_rot
                          hipStream_t s);
 int launch_obs_imitation_packed(int64_t rows, int64_t steps, const float* obs461, const float* context_feat, int64_t ctx_frames, int64_t first_frame,
                                 const float* nmean, const float* nstd, float nclip, float* obs, hipStream_t s);
+int launch_policy_head(int64_t n, float* mu, const float* context_feat, int64_t ctx_frames, int64_t frame, const float* logstd, const float* noise,
+                       float* action, float* sigma_out, float* neglogp, hipStream_t s);
 int launch_gae(int64_t horizon, int64_t n, const float* fdones, const float* values, const float* rewards, const float* next_values, float gamma,
                float tau, float* advs, hipStream_t s);
 int launch_env_reset(v2p_env* e, const int64_t* env_ids, int64_t n, const float* motion_times, hipStream_t s);

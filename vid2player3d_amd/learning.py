@@ -20,10 +20,17 @@ def _chk(t, shape_tail, name):
 
 
 class RunningNorm:
-    """models/running_norm.py:5-43: y = clamp((x - mean) / (std + 1e-8)) with running estimates.  Same buffers (n mean var std), same
-    update rule and the same order (training mode updates the statistics with the batch BEFORE normalising it; nothing is normalised
-    while n == 0).  Plain torch on whatever device the buffers live on: the statistics of a batch depend on the whole batch, so the
-    training-mode pass cannot be fused into the per-row observation kernel; eval mode is what `ImitationObs` fuses."""
+    """The policy's observation normaliser (models/running_norm.py:5-43): y = clamp((x - mean) / (std + 1e-8)) with running estimates;
+    buffers `n mean var std` as in the reference's module (so its checkpoints load), training mode takes the batch into the
+    statistics BEFORE normalising it, nothing is normalised while n == 0.
+
+    The statistics are kept the way a data-parallel learner needs them: a batch enters as its sufficient statistics (count, sum, sum of
+    squares in float64) - one all-reduce merges the batches of all ranks - and is folded into the running moments with the pairwise
+    update of Chan et al. (mean += delta m / (n + m); M2 += M2_batch + delta^2 n m / (n + m)).  In exact arithmetic this is the
+    reference's weighted form (running_norm.py:22-31: biased batch variance, weight n / (n + m)); pinned to vectors recorded from the
+    reference's module (tests/test_running_norm.py).  Plain torch on whatever device the buffers live on: the statistics of a batch
+    depend on the whole batch, so the training-mode pass cannot be fused into the per-row observation kernel; eval mode is what
+    `ImitationObs` fuses."""
 
     def __init__(self, dim, demean=True, destd=True, clip=5.0, device=None):
         self.dim, self.demean, self.destd, self.clip = int(dim), demean, destd, clip
@@ -32,6 +39,7 @@ class RunningNorm:
         self.var = torch.zeros(dim, device=device)
         self.std = torch.zeros(dim, device=device)
         self.training = True
+        self._seen = False  # host-side "n > 0" (None = unknown: ask the device once)
 
     def train(self, mode=True):
         self.training = bool(mode)
@@ -40,18 +48,46 @@ class RunningNorm:
     def eval(self):
         return self.train(False)
 
+    def state_dict(self):
+        return {"n": self.n, "mean": self.mean, "var": self.var, "std": self.std}
+
+    def load_state_dict(self, sd):
+        for k in ("n", "mean", "var", "std"):
+            getattr(self, k).copy_(torch.as_tensor(sd[k]).to(getattr(self, k).device))
+        self._seen = None
+
     @torch.no_grad()
-    def update(self, x):
-        var_x, mean_x = torch.var_mean(x, dim=0, unbiased=False)
-        m = x.shape[0]
-        w = self.n.to(x.dtype) / (m + self.n).to(x.dtype)
-        self.var[:] = w * self.var + (1 - w) * var_x + w * (1 - w) * (mean_x - self.mean).pow(2)
-        self.mean[:] = w * self.mean + (1 - w) * mean_x
-        self.std[:] = torch.sqrt(self.var)
-        self.n += m
+    def update(self, x, group=None):
+        """x [m, dim]: the batch of this rank; with `group` (or an initialised default group of more than one rank) the batches of all
+        ranks enter as one."""
+        import torch.distributed as dist
+
+        x64 = x.detach().double()
+        stats = torch.cat([x64.sum(0), (x64 * x64).sum(0), torch.full((1,), float(x.shape[0]), dtype=torch.float64, device=x.device)])
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(stats, group=group)
+        d = self.dim
+        m = stats[2 * d]
+        ok = (m > 0).double()
+        msafe = torch.clamp(m, min=1.0)
+        mean_x = stats[:d] / msafe
+        m2_x = torch.clamp(stats[d:2 * d] - msafe * mean_x * mean_x, min=0.0)  # sum of squared deviations of the batch
+        n = self.n.double()
+        tot = torch.clamp(n + m, min=1.0)
+        delta = mean_x - self.mean.double()
+        mean = self.mean.double() + ok * delta * (m / tot)
+        m2 = self.var.double() * n + ok * (m2_x + delta * delta * (n * m / tot))
+        self.mean.copy_(mean.float())
+        self.var.copy_((m2 / tot).float())
+        self.std.copy_(torch.sqrt(self.var))
+        self.n += m.long()
+        if x.shape[0] > 0:
+            self._seen = True
 
     def normalize(self, x):
-        if int(self.n) > 0:
+        if self._seen is None:
+            self._seen = int(self.n) > 0
+        if self._seen:
             if self.demean:
                 x = x - self.mean
             if self.destd:
@@ -60,9 +96,9 @@ class RunningNorm:
                 x = torch.clamp(x, -self.clip, self.clip)
         return x
 
-    def __call__(self, x):
+    def __call__(self, x, group=None):
         if self.training:
-            self.update(x)
+            self.update(x, group)
         return self.normalize(x)
 
 

@@ -1,19 +1,38 @@
-"""PPO rollout bookkeeping on the device: what `embodied_pose/agents/im_agent.py:305-409` (`play_steps`),
-`:412-473` (`prepare_dataset`, `_calc_advs`) and `learning/common_agent.py:146-216` (`train_epoch`) do around the VecTask, with
+"""The PPO loop of the imitation task around the rollout engine, method for method what the reference's agent does:
 
-  * the experience buffer resident on the GPU as [T, N, ...] tensors written in place (rl_games' ExperienceBuffer.update_data),
-  * NO host synchronisation inside the 32-step rollout: the reference's `.nonzero()` bookkeeping of finished episodes
-    (`im_agent.py:366-386`) and its `torch.all(self.dones == 1)` early exit (`:388`) become masked device reductions accumulated
-    over the epoch and read once at its end,
-  * the GAE reverse scan as the HIP kernel (`v2p_gae`), the advantage statistics as a 3-number all-reduce over RCCL
-    (`dist.global_advantage_stats`; the reference normalises rank-locally), gradients averaged over the ranks,
-  * the 734-d in-network observation + RunningNorm (eval) as the fused HIP kernel (`learning.ImitationObs`).
+    get_action_values / _eval_critic    embodied_pose/agents/im_agent.py:271-303
+    play_steps                          :305-409
+    prepare_dataset / _calc_advs        :411-473
+    calc_gradients                      :475-587  (losses: learning/common_agent.py:442-450, 491-520)
+    train_epoch                         learning/common_agent.py:146-216, minibatches as learning/amp_datasets.py:17-35
 
-The policy / value networks are the dense MLPs of `cfg/amass_im.yaml:86-88` (units [1024, 1024, 512], relu; fixed sigma
-exp(-1.756), `:76-81`) through torch (rocBLAS): they are NOT part of the accelerated path, and the reference's context encoder
-(`im_network_builder.py`, pose_im_rnn) is not rebuilt - the actor and critic here read the 734-d observation only.  This is what
-BASELINE config 5 ("full PPO train loop") needs to run and to print the reference's `fps step / fps total`
-(`im_agent.py:204-214`); it is not a reimplementation of rl_games.
+with the network of cfg/amass_im.yaml (`ImitatorNetwork` = models/im_network_builder.py:28-245 for that config + models/im_models.py:20-58)
+and these differences in HOW, none in WHAT (pinned to vectors recorded from the reference's own methods: oracle/gen_golden_ppo.py,
+tests/test_gpu_ppo_reference.py):
+
+  * the experience buffer is resident on the GPU as [T, N, ...] tensors written in place; nothing inside the 32-step rollout reads a value
+    back to the host: the reference's `.nonzero()` bookkeeping of finished episodes (:366-386) and its `torch.all(self.dones == 1)` early
+    exit (:388) become masked device reductions read once per epoch (finished envs are masked out of every statistic and of the loss by
+    `alive`, so running the remaining steps changes no result.  Where the reference leaves the loop early, the rows it did not reach keep
+    whatever the previous epoch wrote, `dones` included; here they hold dones = 1),
+  * between the actor MLP and the env step sits ONE kernel (`v2p_policy_head`): residual action (mu[:, :69] += the context's target DOF
+    positions, im_network_builder.py:226-228), sample, neglogp; the 734-d in-network observation + RunningNorm (eval) is the fused HIP
+    kernel (`learning.ImitationObs`), the GAE reverse scan the HIP kernel `v2p_gae`,
+  * the critic runs ONCE per step: the reference evaluates it on the observation after step n for `next_values` (`_eval_critic`, t = n + 1)
+    and again on the very same observation, same t, same eval-mode weights for `values` of step n + 1 (`get_action_values`); the second
+    evaluation is the first one's result (`reuse_next_values`; bit-identical, tested).  And it runs BESIDE the physics (`overlap_critic`):
+    the value of an observation goes to the buffer only - the next env step needs the actor alone - so the critic pass of step n + 1 is
+    issued on a side stream and fills the SIMDs the latency-bound physics launch of step n + 1 leaves idle (same numbers, tested),
+  * ROLLOUT GROUPS: the agent takes one task or several (env batches of one GPU).  Each group runs its steps on its own HIP stream: while
+    the physics launch of one group is in flight the MLP passes of the other run, and each fills the tail of the other's launches.  Envs
+    are independent, so the buffer an N-env rollout fills is the same whether N envs form one group or two (tested bit for bit),
+  * data parallel over env shards (one process per GPU): advantages are normalised with GLOBAL masked statistics (3-number all-reduce;
+    the reference's Horovod ranks normalise locally), the observation / value normalisers merge the batches of all ranks, gradients are
+    averaged in one flat all-reduce over RCCL.
+
+The policy / value networks are dense MLPs (cfg/amass_im.yaml:86-88: [1024, 1024, 512], relu; fixed sigma exp(-1.756), :76-81) through
+torch (rocBLAS): they are NOT part of the accelerated path.  rl_games itself is not rebuilt; the pieces of it the reference's methods call
+(value normaliser, masked means, policy KL, neglogp) are restated below from its published source [rl-games 1.1.4, from memory].
 """
 import math
 import time
@@ -21,58 +40,125 @@ import time
 import torch
 import torch.nn as nn
 
+from . import _lib
 from . import dist as vdist
-from .learning import OBS_IMITATION_DIM, ImitationObs, discount_values
+from .learning import OBS_IMITATION_DIM, ImitationObs, RunningNorm, discount_values
+
+LOG_2PI = math.log(2.0 * math.pi)
+NUM_DOF = 69
+CTX_DOF_POS = 168  # offset of `dof_pos` inside a 378-d context frame (body_pos 72 | body_rot 96 | dof_pos 69 | ..., humanoid_smpl_im.py:202)
 
 
-class MLP(nn.Module):
-    def __init__(self, inp, units, out):
+def _world(group):
+    return vdist.dist.get_world_size(group) if vdist.dist.is_available() and vdist.dist.is_initialized() else 1
+
+
+def _mlp(inp, units):
+    layers, d = [], inp
+    for u in units:
+        layers += [nn.Linear(d, u), nn.ReLU()]
+        d = u
+    return nn.Sequential(*layers)
+
+
+def neglogp(x, mu, sigma, logstd):
+    """rl_games ModelA2CContinuousLogStd.neglogp (called at models/im_models.py:31, 46)"""
+    return 0.5 * (((x - mu) / sigma) ** 2).sum(dim=-1) + 0.5 * LOG_2PI * x.shape[-1] + logstd.sum(dim=-1)
+
+
+def policy_kl(p0_mu, p0_sigma, p1_mu, p1_sigma):
+    """rl_games torch_ext.policy_kl(..., reduce=False) (im_agent.py:572): KL(N(p0) || N(p1)) per sample, with its 1e-5 guards"""
+    c1 = torch.log(p1_sigma / p0_sigma + 1e-5)
+    c2 = (p0_sigma ** 2 + (p1_mu - p0_mu) ** 2) / (2.0 * (p1_sigma ** 2 + 1e-5))
+    return (c1 + c2 - 0.5).sum(dim=-1)
+
+
+def masked_mean(x, mask):
+    """rl_games torch_ext.apply_masks (im_agent.py:537): sum of the alive entries over the NUMBER OF ELEMENTS of the mask (not its sum) -
+    the form the reference's own masked KL uses two lines further down (:573)."""
+    return (x * mask).sum() / mask.numel()
+
+
+class ValueMeanStd:
+    """The value normaliser `self.value_mean_std` (rl_games RunningMeanStd((1,)); im_agent.py:292, 301, 426-429): count starts at 1 with
+    mean 0 / var 1, epsilon 1e-5 inside the square root, a batch enters with torch's default (unbiased) variance, `unnorm` clamps its
+    input to +-5 before scaling back.  Data parallel: the moments of a batch are taken over the batches of all ranks (sum / sum of
+    squares / count in one all-reduce), so every rank keeps the same normaliser."""
+
+    def __init__(self, device, epsilon=1e-5):
+        self.running_mean = torch.zeros(1, dtype=torch.float64, device=device)
+        self.running_var = torch.ones(1, dtype=torch.float64, device=device)
+        self.count = torch.ones((), dtype=torch.float64, device=device)
+        self.epsilon = epsilon
+        self.training = False
+
+    def train(self, mode=True):
+        self.training = bool(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    @torch.no_grad()
+    def update(self, x, group=None):
+        x64 = x.detach().double().reshape(-1)
+        s = torch.stack([x64.sum(), (x64 * x64).sum(), torch.tensor(float(x64.numel()), dtype=torch.float64, device=x.device)])
+        if _world(group) > 1:
+            vdist.dist.all_reduce(s, group=group)
+        m = s[2]
+        mean = s[0] / m
+        var = torch.clamp(s[1] - m * mean * mean, min=0.0) / torch.clamp(m - 1.0, min=1.0)
+        delta = mean - self.running_mean
+        tot = self.count + m
+        self.running_mean = self.running_mean + delta * m / tot
+        self.running_var = (self.running_var * self.count + var * m + delta * delta * self.count * m / tot) / tot
+        self.count = tot
+
+    def __call__(self, x, unnorm=False, group=None):
+        if self.training:
+            self.update(x, group)
+        scale = torch.sqrt(self.running_var.float() + self.epsilon)
+        if unnorm:
+            return scale * torch.clamp(x, min=-5.0, max=5.0) + self.running_mean.float()
+        return torch.clamp((x - self.running_mean.float()) / scale, min=-5.0, max=5.0)
+
+
+class ImitatorNetwork(nn.Module):
+    """`ImitatorBuilder.Network` for cfg/amass_im.yaml (separate actor / critic MLPs over the 734-d in-network observation, RunningNorm
+    "ours", residual action, fixed sigma) with the parameter names of the reference's module, so that `load_reference_state_dict` takes a
+    reference checkpoint's `model` entry (`a2c_network.actor_mlp.0.weight` ...)."""
+
+    def __init__(self, num_actions=75, units=(1024, 1024, 512), sigma_init=-1.756, residual_action=True, device=None):
         super().__init__()
-        layers, d = [], inp
-        for u in units:
-            layers += [nn.Linear(d, u), nn.ReLU()]
-            d = u
-        layers.append(nn.Linear(d, out))
-        self.net = nn.Sequential(*layers)
+        self.actor_mlp, self.critic_mlp = _mlp(OBS_IMITATION_DIM, units), _mlp(OBS_IMITATION_DIM, units)
+        self.mu, self.value = nn.Linear(units[-1], num_actions), nn.Linear(units[-1], 1)
+        self.sigma = nn.Parameter(torch.full((num_actions,), float(sigma_init)), requires_grad=False)  # fixed_sigma, learn_sigma False
+        self.residual_action = residual_action
+        self.to(device)
+        self.running_obs = RunningNorm(OBS_IMITATION_DIM, device=device)
 
-    def forward(self, x):
-        return self.net(x)
+    def actor(self, x):
+        return self.mu(self.actor_mlp(x))
 
+    def critic(self, x):
+        return self.value(self.critic_mlp(x))
 
-class RunningMeanStd:
-    """rl_games' value normaliser / the reference's RunningNorm update rule (models/running_norm.py:22-31) on flat tensors; statistics
-    can be merged across ranks (sum, sum of squares, count) before the update."""
+    def load_reference_state_dict(self, sd, prefix="a2c_network."):
+        own = {k: v for k, v in sd.items() if k.startswith(prefix)}
+        self.load_state_dict({k[len(prefix):]: torch.as_tensor(v) for k, v in own.items() if "running_obs" not in k}, strict=True)
+        self.running_obs.load_state_dict({k.split("running_obs.")[1]: v for k, v in own.items() if "running_obs." in k})
 
-    def __init__(self, dim, device, clip=5.0):
-        self.n = torch.zeros((), dtype=torch.float64, device=device)
-        self.mean = torch.zeros(dim, device=device)
-        self.var = torch.zeros(dim, device=device)
-        self.std = torch.zeros(dim, device=device)
-        self.clip = clip
-
-    def update(self, x, mask=None, group=None):
-        """x [M, dim]; rows with mask == 0 are ignored.  One all-reduce of (count, sum, sum of squares) when distributed."""
-        x = x.double()
-        w = torch.ones(x.shape[0], 1, dtype=torch.float64, device=x.device) if mask is None else mask.double().reshape(-1, 1)
-        stats = torch.cat([w.sum().reshape(1), (x * w).sum(0), (x * x * w).sum(0)])
-        if vdist.dist.is_initialized() and vdist.dist.get_world_size(group) > 1:
-            vdist.dist.all_reduce(stats, group=group)
-        d = x.shape[1]
-        m = stats[0]
-        mean_x = stats[1:1 + d] / torch.clamp(m, min=1.0)
-        var_x = torch.clamp(stats[1 + d:] / torch.clamp(m, min=1.0) - mean_x * mean_x, min=0.0)
-        wgt = self.n / torch.clamp(m + self.n, min=1.0)
-        new_var = wgt * self.var.double() + (1 - wgt) * var_x + wgt * (1 - wgt) * (mean_x - self.mean.double()) ** 2
-        new_mean = wgt * self.mean.double() + (1 - wgt) * mean_x
-        self.var, self.mean = new_var.float(), new_mean.float()
-        self.std = self.var.sqrt()
-        self.n = self.n + m
-
-    def normalize(self, x):
-        return torch.clamp((x - self.mean) / (self.std + 1e-8), -self.clip, self.clip)
-
-    def denormalize(self, y):
-        return y * (self.std + 1e-8) + self.mean
+    def forward_train(self, feat_raw, target_dof_pad, prev_actions, group=None):
+        """ImitatorModel.Network.forward with is_train (im_models.py:27-41) on the minibatch's RAW in-network features: the running
+        statistics take them in (training mode, running_norm.py:33-34), then normalise them; residual mean; neglogp of the old actions."""
+        x = self.running_obs(feat_raw, group) if self.training else self.running_obs.normalize(feat_raw)
+        mu = self.actor(x)
+        if self.residual_action:
+            mu = mu + target_dof_pad
+        logstd = mu * 0.0 + self.sigma
+        sigma = torch.exp(logstd)
+        entropy = (0.5 + 0.5 * LOG_2PI + logstd).sum(dim=-1)  # Normal(mu, sigma).entropy().sum(-1)
+        return {"prev_neglogp": neglogp(prev_actions, mu, sigma, logstd), "values": self.critic(x), "entropy": entropy, "mus": mu, "sigmas": sigma}
 
 
 class ExperienceBuffer:
@@ -89,118 +175,263 @@ class ExperienceBuffer:
             "sigmas": torch.zeros((horizon, num_envs, act_dim), **f),
         }
 
-    def update_data(self, name, n, value):
-        self.tensor_dict[name][n].copy_(value.reshape(self.tensor_dict[name][n].shape))
+    def update_data(self, name, n, value, sl=slice(None)):
+        dst = self.tensor_dict[name][n, sl]
+        dst.copy_(value.reshape(dst.shape))
 
 
-def neglogp(x, mu, logstd):
-    """rl_games ModelA2CContinuousLogStd.neglogp"""
-    return 0.5 * (((x - mu) / torch.exp(logstd)) ** 2).sum(-1) + 0.5 * math.log(2.0 * math.pi) * x.shape[-1] + logstd.sum(-1)
+class _Group:
+    """one env batch of the rollout: a task, its env range in the buffer, its stream"""
+
+    def __init__(self, task, lo, stream, side):
+        self.task, self.lo, self.hi, self.stream, self.side = task, lo, lo + task.num_envs, stream, side  # side: the critic's stream
+        self.sl = slice(self.lo, self.hi)
 
 
 class PPOAgent:
     def __init__(self, task, horizon_length=32, gamma=0.99, tau=0.95, learning_rate=2e-5, e_clip=0.2, critic_coef=5.0, mini_epochs=6,
                  minibatch_envs=512, grad_norm=50.0, units=(1024, 1024, 512), sigma_init=-1.756, seed=0, group=None,
-                 normalize_value=True, normalize_advantage=True):
-        self.task, self.horizon_length, self.gamma, self.tau = task, horizon_length, gamma, tau
-        self.e_clip, self.critic_coef, self.mini_epochs, self.grad_norm = e_clip, critic_coef, mini_epochs, grad_norm
+                 normalize_value=True, normalize_advantage=True, entropy_coef=0.0, residual_action=True, reuse_next_values=True,
+                 truncate_grads=True, overlap_critic=True):
+        tasks = list(task) if isinstance(task, (list, tuple)) else [task]
+        self.tasks, self.task = tasks, tasks[0]
+        self.horizon_length, self.gamma, self.tau = horizon_length, gamma, tau
+        self.e_clip, self.critic_coef, self.entropy_coef, self.mini_epochs = e_clip, critic_coef, entropy_coef, mini_epochs
+        self.grad_norm, self.truncate_grads = grad_norm, truncate_grads
         self.normalize_value, self.normalize_advantage = normalize_value, normalize_advantage
+        self.reuse_next_values, self.overlap_critic = reuse_next_values, overlap_critic
         self.group = group
-        self.device = torch.device(task.device)
-        self.num_actors = task.num_envs
+        self.device = torch.device(self.task.device)
+        if any(str(t.device) != str(self.task.device) or t.context_padding != self.task.context_padding for t in tasks):
+            raise ValueError("the rollout groups of one agent live on one GPU and share the context layout")
+        self.num_actors = sum(t.num_envs for t in tasks)
+        self.num_actions = self.task.num_actions
         self.minibatch_envs = min(minibatch_envs, self.num_actors)
-        g = torch.Generator(device="cpu")
-        g.manual_seed(seed)  # the same initial weights on every rank
+        lo, self.groups = 0, []
+        for k, t in enumerate(tasks):
+            self.groups.append(_Group(t, lo, None if len(tasks) == 1 else torch.cuda.Stream(device=self.device),
+                                      torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None))
+            lo += t.num_envs
         with torch.random.fork_rng(devices=[]):
-            torch.manual_seed(seed)
-            self.actor = MLP(OBS_IMITATION_DIM, units, task.num_actions).to(self.device)
-            self.critic = MLP(OBS_IMITATION_DIM, units, 1).to(self.device)
-        self.logstd = torch.full((task.num_actions,), float(sigma_init), device=self.device)  # fixed_sigma, learn_sigma False
-        self.optimizer = torch.optim.Adam(list(self.actor.parameters()) + list(self.critic.parameters()), lr=learning_rate, eps=1e-8)
-        self.obs_norm = RunningMeanStd(OBS_IMITATION_DIM, self.device)
-        self.value_norm = RunningMeanStd(1, self.device)
-        self.obs_enc = ImitationObs(task.context_padding)
-        self.experience_buffer = ExperienceBuffer(horizon_length, self.num_actors, task.num_obs, task.num_actions, self.device)
+            torch.manual_seed(seed)  # the same initial weights on every rank
+            self.model = ImitatorNetwork(self.num_actions, units, sigma_init, residual_action, self.device)
+        self.model.eval()
+        self.last_lr = float(learning_rate)
+        self.optimizer = torch.optim.Adam(self.model.parameters(), self.last_lr, eps=1e-08, weight_decay=0.0)
+        self.value_mean_std = ValueMeanStd(self.device)
+        self.obs_enc = ImitationObs(self.task.context_padding)
+        self._lib = _lib.load()
+        self.experience_buffer = ExperienceBuffer(horizon_length, self.num_actors, self.task.num_obs, self.num_actions, self.device)
+        rank = vdist.dist.get_rank(group) if _world(group) > 1 else 0
         self.action_gen = torch.Generator(device=self.device)
-        self.action_gen.manual_seed(seed + 1000 * (vdist.dist.get_rank(group) if vdist.dist.is_initialized() else 0))
+        self.action_gen.manual_seed(seed + 1000 * rank)
+        self.idx_gen = torch.Generator(device="cpu")
+        self.idx_gen.manual_seed(seed)  # the same minibatch order on every rank (AMPDataset._idx_buf)
+        self._idx_buf = torch.randperm(self.num_actors, generator=self.idx_gen).to(self.device)
         self.dones = torch.zeros(self.num_actors, device=self.device)
         self.current_rewards = torch.zeros(self.num_actors, device=self.device)
         self.current_lengths = torch.zeros(self.num_actors, device=self.device)
         self.epoch_num = 0
         self.frame = 0
-        self._obs_norm_ready = self._value_norm_ready = False
+        self.dataset = None
+        self.noise_fn = None  # tests: noise_fn(n) -> [N, num_actions] standard-normal draws of step n
 
-    # ------------------------------------------------------------------ network side
-    def _features(self, obs, t):
-        """734-d in-network observation of step t (rollout flavour); the running statistics are applied inside the kernel."""
-        return self.obs_enc.rollout(obs, self.task.context_feat, t)
+    # compatibility with the round-2 attribute names
+    @property
+    def actor(self):
+        return nn.Sequential(self.model.actor_mlp, self.model.mu)
+
+    @property
+    def critic(self):
+        return nn.Sequential(self.model.critic_mlp, self.model.value)
+
+    def set_eval(self):
+        self.model.eval()
+        self.model.running_obs.eval()
+        self.value_mean_std.eval()
+
+    def set_train(self):
+        self.model.train()
+        self.model.running_obs.train()
+        self.value_mean_std.train()
+
+    # ------------------------------------------------------------------ network side of the rollout
+    def _features(self, task, obs, t):
+        """734-d in-network observation of step t (preprocess_input in eval mode: context frame context_padding + t, running statistics
+        applied inside the kernel)"""
+        return self.obs_enc.rollout(obs, task.context_feat, t)
 
     def _sync_obs_norm(self):
-        if self._obs_norm_ready:  # (host-side flags: no device read in the rollout loop)
-            self.obs_enc.set_running_stats(self.obs_norm.mean, self.obs_norm.std)
+        rn = self.model.running_obs
+        if rn._seen is None:
+            rn._seen = int(rn.n) > 0
+        if rn._seen:  # (a fresh model does not normalise, running_norm.py:36)
+            self.obs_enc.set_running_stats(rn.mean, rn.std)
+        else:
+            self.obs_enc.set_running_stats(None, None)
 
-    def get_action_values(self, obs, t):
-        feat = self._features(obs, t)
-        mu = self.actor(feat)
-        sigma = torch.exp(self.logstd).expand_as(mu)
-        action = mu + sigma * torch.randn(mu.shape, device=mu.device, generator=self.action_gen)
-        value = self.critic(feat)
-        if self.normalize_value and self._value_norm_ready:
-            value = self.value_norm.denormalize(value)
-        return {"actions": action, "mus": mu, "sigmas": sigma, "neglogpacs": neglogp(action, mu, self.logstd), "values": value}
-
-    def eval_critic(self, obs, t):
-        value = self.critic(self._features(obs, t))
-        if self.normalize_value and self._value_norm_ready:
-            value = self.value_norm.denormalize(value)
+    def _value(self, feat):
+        value = self.model.critic(feat)
+        if self.normalize_value:
+            value = self.value_mean_std(value, True)
         return value
+
+    def _policy_head(self, task, mu, noise, t):
+        """models/im_network_builder.py:226-228 + models/im_models.py:42-46 in one kernel; mu is updated in place"""
+        n = mu.shape[0]
+        action = torch.empty_like(mu)
+        sigma = torch.empty_like(mu)
+        nlp = torch.empty(n, dtype=torch.float32, device=mu.device)
+        ctx = task.context_feat
+        frame = (task.context_padding + int(t)) if self.model.residual_action else -1
+        if frame < 0:
+            raise NotImplementedError("residual_action = False is not built (the reference's default and both configs use True)")
+        _lib.check(self._lib.v2p_policy_head(n, _lib.ptr(mu), _lib.ptr(ctx), ctx.shape[1], frame, _lib.ptr(self.model.sigma), _lib.ptr(noise),
+                                             _lib.ptr(action), _lib.ptr(sigma), _lib.ptr(nlp), _lib.current_stream(mu.device)), "v2p_policy_head")
+        return action, sigma, nlp
+
+    def get_action_values(self, obs, t, task=None, feat=None, noise=None, value=None):
+        """im_agent.py:271-294 (`obs['t']` = t).  feat / value: what `_eval_critic` of the step before has already computed for this
+        very observation (reuse_next_values)."""
+        task = task or self.task
+        if feat is None:
+            feat = self._features(task, obs, t)
+        mu = self.model.actor(feat)
+        if noise is None:
+            noise = torch.randn(mu.shape, device=mu.device, generator=self.action_gen)
+        action, sigma, nlp = self._policy_head(task, mu, noise.contiguous(), t)
+        if value is None:
+            value = self._value(feat)
+        return {"actions": action, "mus": mu, "sigmas": sigma, "neglogpacs": nlp, "values": value}  # (value False: the caller has it)
+
+    def _eval_critic(self, obs, t, task=None):
+        """im_agent.py:296-303; also returns the features it was computed from"""
+        feat = self._features(task or self.task, obs, t)
+        return self._value(feat), feat
 
     # ------------------------------------------------------------------ rollout (im_agent.py:305-409), no host syncs in the loop
     @torch.no_grad()
-    def play_steps(self):
-        task, buf = self.task, self.experience_buffer
+    def play_steps(self, reset_fn=None):
+        """reset_fn(task, group_index): tests reset the envs at given clip times instead of `task.reset()`."""
+        buf = self.experience_buffer
+        self.set_eval()
         self._sync_obs_norm()
-        task.reset()  # per-epoch reset of all envs + context window (env_reset)
-        obs = task.obs_buf
+        T, A = self.horizon_length, self.num_actions
+        main = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
+        multi = len(self.groups) > 1
         self.dones.zero_()
-        prev_dones = torch.zeros_like(self.dones)
         self.current_rewards.zero_()
         self.current_lengths.zero_()
-        # device accumulators of what the reference collects through .nonzero() / AverageMeter on the host
-        acc = torch.zeros(8, dtype=torch.float64, device=self.device)  # finished: n, sum reward, sum length | step: n, sum reward | spare
-        sub_acc = torch.zeros(4, dtype=torch.float64, device=self.device)
-        for n in range(self.horizon_length):
-            buf.update_data("obses", n, obs)
-            res = self.get_action_values(obs, n)
-            for k in ("actions", "mus", "sigmas", "neglogpacs", "values"):
-                buf.update_data(k, n, res[k])
-            actions = res["actions"].contiguous()
-            task.step(actions)  # masks the rows of finished envs in place, like the reference
-            obs, rewards = task.obs_buf, task.rew_buf
-            self.dones = task.reset_buf.float()
-            buf.update_data("rewards", n, rewards)  # rewards_shaper scale_value 1
-            buf.update_data("next_obses", n, obs)
-            buf.update_data("dones", n, self.dones)
-            terminated = task.extras["terminate"].float().unsqueeze(-1)
-            next_vals = self.eval_critic(obs, n + 1) * (1.0 - terminated)  # end_value_type 'next'
-            buf.update_data("next_values", n, next_vals)
-            self.current_rewards += rewards
-            self.current_lengths += 1
-            step_dones = self.dones * (1.0 - prev_dones)  # envs that finished at this step
-            alive_before = 1.0 - prev_dones
-            acc[0] += step_dones.sum()
-            acc[1] += (self.current_rewards * step_dones).sum()
-            acc[2] += (self.current_lengths * step_dones).sum()
-            acc[3] += alive_before.sum()
-            acc[4] += (rewards * alive_before).sum()
-            sub_acc += (task.extras["sub_rewards"] * alive_before.unsqueeze(-1)).sum(0).double()
-            prev_dones = self.dones.clone()
-            # (the reference leaves the loop when every env is done - a host sync per step; finished envs are masked out of every
-            # statistic and of the loss by `alive`, so running the remaining steps changes no result)
-        still = 1.0 - self.dones
-        acc[0] += still.sum()
-        acc[1] += (self.current_rewards * still).sum()
-        acc[2] += (self.current_lengths * still).sum()
+        # the epoch's action noise in one draw, so that the env -> noise assignment does not depend on how the envs are grouped
+        noise_all = None if self.noise_fn else torch.randn((T, self.num_actors, A), device=self.device, generator=self.action_gen)
+        start = torch.cuda.Event() if multi else None
+        if multi:
+            start.record(main)
+        st = []
+        for gi, g in enumerate(self.groups):
+            s = dict(prev_dones=torch.zeros(g.task.num_envs, device=self.device),
+                     # device accumulators of what the reference collects through .nonzero() / AverageMeter on the host:
+                     # finished episodes: n, sum reward, sum length | steps of envs not done before: n, sum reward
+                     acc=torch.zeros(8, dtype=torch.float64, device=self.device), sub=None, feat=None, value=None)
+            st.append(s)
+        cuda = self.device.type == "cuda"
+        overlap = self.overlap_critic and self.reuse_next_values and cuda
+
+        def on(g):
+            return torch.cuda.stream(g.stream) if multi else _NullCtx()
+
+        def critic_of(g, s, feat, n, terminated):
+            """value of the observation BEFORE step n (features `feat`): `values` of step n and, masked by the terminations of the step
+            that produced the observation, `next_values` of step n - 1.  With overlap_critic on the group's SIDE stream: the critic pass is
+            needed by the buffer only, never by the next physics launch, so it runs while the actor pass and the physics of step n do."""
+            def work():
+                v = self._value(feat)
+                if n < T:
+                    buf.update_data("values", n, v, g.sl)
+                if n > 0:
+                    buf.update_data("next_values", n - 1, v * (1.0 - terminated), g.sl)  # end_value_type 'next'
+            if not overlap:
+                return work()
+            cur = torch.cuda.current_stream(self.device)
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            g.side.wait_event(ev)
+            for x in (feat, terminated):
+                if x is not None:
+                    x.record_stream(g.side)
+            with torch.cuda.stream(g.side):
+                work()
+
+        for gi, g in enumerate(self.groups):
+            with on(g):
+                if multi:
+                    g.stream.wait_event(start)
+                if overlap:
+                    g.side.wait_stream(torch.cuda.current_stream(self.device))
+                (reset_fn(g.task, gi) if reset_fn else g.task.reset())  # per-epoch reset of all envs + context window
+        for n in range(T):
+            for gi, g in enumerate(self.groups):
+                s, task, sl = st[gi], g.task, g.sl
+                with on(g):
+                    obs = task.obs_buf
+                    buf.update_data("obses", n, obs, sl)
+                    noise = self.noise_fn(n)[sl] if self.noise_fn else noise_all[n, sl]
+                    if self.reuse_next_values:
+                        if n == 0:
+                            s["feat"], s["term"] = self._features(task, obs, 0), None
+                        res = self.get_action_values(obs, n, task, s["feat"], noise, value=False)
+                    else:
+                        res = self.get_action_values(obs, n, task, None, noise)
+                        buf.update_data("values", n, res["values"], sl)
+                    for k in ("actions", "mus", "sigmas", "neglogpacs"):
+                        buf.update_data(k, n, res[k], sl)
+                    if self.reuse_next_values:
+                        # issued here, right in front of the physics launch it is to run beside (issued any earlier it would share the GPU
+                        # with the actor pass instead: two GEMM streams gain nothing from each other)
+                        critic_of(g, s, s["feat"], n, s["term"])
+                    task.step(res["actions"])  # masks the rows of finished envs in place, like the reference
+                    obs, rewards = task.obs_buf, task.rew_buf
+                    dones = task.reset_buf.float()
+                    self.dones[sl] = dones
+                    buf.update_data("rewards", n, rewards, sl)  # rewards_shaper scale_value 1
+                    buf.update_data("next_obses", n, obs, sl)
+                    buf.update_data("dones", n, dones, sl)
+                    terminated = task.extras["terminate"].float().unsqueeze(-1)
+                    if self.reuse_next_values:
+                        s["feat"], s["term"] = self._features(task, obs, n + 1), terminated
+                        if n == T - 1:
+                            critic_of(g, s, s["feat"], T, terminated)
+                    else:
+                        value_next, _ = self._eval_critic(obs, n + 1, task)
+                        buf.update_data("next_values", n, value_next * (1.0 - terminated), sl)
+                    self.current_rewards[sl] += rewards
+                    self.current_lengths[sl] += 1
+                    step_dones = dones * (1.0 - s["prev_dones"])  # envs that finished at this step
+                    alive_before = 1.0 - s["prev_dones"]
+                    acc = s["acc"]
+                    acc[0] += step_dones.sum()
+                    acc[1] += (self.current_rewards[sl] * step_dones).sum()
+                    acc[2] += (self.current_lengths[sl] * step_dones).sum()
+                    acc[3] += alive_before.sum()
+                    acc[4] += (rewards * alive_before).sum()
+                    sub = (task.extras["sub_rewards"] * alive_before.unsqueeze(-1)).sum(0).double()
+                    s["sub"] = sub if s["sub"] is None else s["sub"] + sub
+                    s["prev_dones"] = dones
+            # (the reference leaves the loop when every env is done - a host sync per step; see the module docstring)
+        for gi, g in enumerate(self.groups):
+            s, sl = st[gi], g.sl
+            with on(g):
+                still = 1.0 - self.dones[sl]
+                s["acc"][0] += still.sum()
+                s["acc"][1] += (self.current_rewards[sl] * still).sum()
+                s["acc"][2] += (self.current_lengths[sl] * still).sum()
+                if overlap:
+                    torch.cuda.current_stream(self.device).wait_stream(g.side)
+        if multi:
+            for g in self.groups:
+                main.wait_stream(g.stream)
+        acc = torch.stack([s["acc"] for s in st]).sum(0)
+        sub_acc = torch.stack([s["sub"] for s in st]).sum(0)
         td = buf.tensor_dict
         mb_advs = discount_values(td["dones"], td["values"], td["rewards"], td["next_values"], self.gamma, self.tau)
         mb_returns = mb_advs + td["values"]
@@ -208,80 +439,115 @@ class PPOAgent:
         batch["returns"] = mb_returns.transpose(0, 1)
         batch["alive"] = 1.0 - batch["dones"]  # the `dones` of step n as overwritten AFTER the step (im_agent.py:343, 403)
         batch["played_frames"] = self.num_actors * self.horizon_length
-        batch["context_feat"], batch["context_mask"] = task.context_feat, task.context_mask
+        if multi:
+            batch["context_feat"] = torch.cat([t.context_feat for t in self.tasks], dim=0)
+            batch["context_mask"] = torch.cat([t.context_mask for t in self.tasks], dim=0)
+        else:
+            batch["context_feat"], batch["context_mask"] = self.task.context_feat, self.task.context_mask
         batch["stats"] = (acc, sub_acc)
         return batch
 
-    # ------------------------------------------------------------------ update (im_agent.py:412-473 + a2c_common train_actor_critic)
+    # ------------------------------------------------------------------ update
     def _calc_advs(self, batch):
+        """im_agent.py:461-473; the statistics of the alive entries are global over the ranks"""
         adv = (batch["returns"] - batch["values"]).sum(-1)
         if self.normalize_advantage:
-            adv = vdist.normalize_advantages(adv, batch["alive"], self.group)  # global masked mean / std over all ranks
+            adv = vdist.normalize_advantages(adv, batch["alive"], self.group)
         return adv
 
+    @torch.no_grad()
+    def prepare_dataset(self, batch, feat_raw=None):
+        """im_agent.py:411-459: advantages from the un-normalised values; the value normaliser (training mode) takes the values in and
+        normalises them, then the returns.  Added: what the network's training-mode forward needs of the context, computed once per
+        epoch instead of once per minibatch - the raw 734-d features of every (env, step) (HIP kernel; `feat_raw` [N,T,734] given: the
+        caller's, e.g. a learner process that receives them) and the residual-action term."""
+        values, returns = batch["values"], batch["returns"]
+        advantages = self._calc_advs(batch)
+        if self.normalize_value:
+            values = self.value_mean_std(values.reshape(-1, 1), group=self.group).view(values.shape)
+            returns = self.value_mean_std(returns.reshape(-1, 1), group=self.group).view(returns.shape)
+        n, t = batch["alive"].shape
+        ctx, pad = batch["context_feat"], self.task.context_padding
+        if feat_raw is None:
+            feat_raw = ImitationObs(pad).training(batch["obses"].contiguous(), ctx).view(n, t, -1)  # preprocess_input, flatten=True
+        tgt = torch.zeros((n, t, self.num_actions), device=self.device)
+        tgt[:, :, :NUM_DOF] = ctx[:, pad:pad + t, CTX_DOF_POS:CTX_DOF_POS + NUM_DOF]
+        self.dataset = {"old_values": values, "old_logp_actions": batch["neglogpacs"], "advantages": advantages, "returns": returns,
+                        "actions": batch["actions"], "mu": batch["mus"], "sigma": batch["sigmas"], "alive": batch["alive"],
+                        "feat_raw": feat_raw, "target_dof_pad": tgt}
+        return self.dataset
+
+    def _get_item(self, i):
+        """AMPDataset._get_item (learning/amp_datasets.py:17-31): minibatch i = envs _idx_buf[i m : (i + 1) m]; reshuffled at the end"""
+        start, end = i * self.minibatch_envs, (i + 1) * self.minibatch_envs
+        idx = self._idx_buf[start:end]
+        item = {k: v[idx] for k, v in self.dataset.items()}
+        if end >= self.num_actors:
+            self._idx_buf = torch.randperm(self.num_actors, generator=self.idx_gen).to(self.device)
+        return item
+
+    def calc_gradients(self, input_dict):
+        """im_agent.py:475-587 on one minibatch of envs ([m, T, ...] tensors, flattened like :478-481)."""
+        self.set_train()
+        d = {k: v.reshape((-1, v.shape[-1]) if v.dim() > 2 else (-1,)) for k, v in input_dict.items()}
+        alive, advantage = d["alive"], d["advantages"]
+        res = self.model.forward_train(d["feat_raw"], d["target_dof_pad"], d["actions"], self.group)
+        # _actor_loss / _critic_loss (common_agent.py:491-520; clip_value False), bound_loss with bounds_loss_coef None = 0
+        ratio = torch.exp(d["old_logp_actions"] - res["prev_neglogp"])
+        a_loss = torch.max(-advantage * ratio, -advantage * torch.clamp(ratio, 1.0 - self.e_clip, 1.0 + self.e_clip))
+        c_loss = (d["returns"] - res["values"]) ** 2
+        mask = alive.unsqueeze(1)
+        a_l, c_l, ent = masked_mean(a_loss.unsqueeze(1), mask), masked_mean(c_loss, mask), masked_mean(res["entropy"].unsqueeze(1), mask)
+        loss = a_l + self.critic_coef * c_l - self.entropy_coef * ent
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        for p in params:
+            p.grad = None
+        loss.backward()
+        world = _world(self.group)
+        if world > 1:  # data parallel over env shards: one flat all-reduce of the gradients over RCCL, averaged (Horovod's DistributedOptimizer)
+            flat = torch.cat([p.grad.reshape(-1) for p in params])
+            vdist.dist.all_reduce(flat, group=self.group)
+            flat /= world
+            o = 0
+            for p in params:
+                p.grad.copy_(flat[o:o + p.numel()].view_as(p))
+                o += p.numel()
+        if self.truncate_grads:
+            nn.utils.clip_grad_norm_(params, self.grad_norm)
+        self.optimizer.step()
+        with torch.no_grad():
+            kl = (policy_kl(res["mus"].detach(), res["sigmas"].detach(), d["mu"], d["sigma"]) * alive).sum() / alive.numel()
+            clip_frac = (torch.abs(ratio.detach() - 1.0) > self.e_clip).float().mean()
+        self.train_result = {"actor_loss": a_l.detach(), "critic_loss": c_l.detach(), "entropy": ent.detach(), "kl": kl, "actor_clip_frac": clip_frac}
+        return self.train_result
+
     def train_epoch(self):
+        """learning/common_agent.py:146-216"""
         sync = torch.cuda.synchronize if self.device.type == "cuda" else (lambda: None)
         sync()
         t0 = time.perf_counter()
         batch = self.play_steps()
         sync()
         t1 = time.perf_counter()
-        adv = self._calc_advs(batch)
-        alive = batch["alive"]
-        n, t = alive.shape
-        # in-network features of the whole batch (training flavour of the obs kernel) and running statistics (RunningNorm.update)
-        raw_enc = ImitationObs(self.task.context_padding)
-        feats_raw = raw_enc.training(batch["obses"].contiguous(), batch["context_feat"])
-        self.obs_norm.update(feats_raw, alive.reshape(-1), self.group)
-        self._obs_norm_ready = True
-        self._sync_obs_norm()
-        feats = self.obs_norm.normalize(feats_raw).view(n, t, -1)
-        values, returns = batch["values"], batch["returns"]
-        if self.normalize_value:
-            self.value_norm.update(returns.reshape(-1, 1), alive.reshape(-1), self.group)
-            self._value_norm_ready = True
-            values, returns = self.value_norm.normalize(values), self.value_norm.normalize(returns)
-        old_nlp, actions = batch["neglogpacs"], batch["actions"]
-        world = vdist.dist.get_world_size(self.group) if vdist.dist.is_initialized() else 1
-        params = list(self.actor.parameters()) + list(self.critic.parameters())
-        info = {"a_loss": [], "c_loss": [], "kl": []}
+        self.set_train()
+        frames = batch.pop("played_frames")
+        self.prepare_dataset(batch)
+        info = {"actor_loss": [], "critic_loss": [], "kl": [], "actor_clip_frac": []}
         for _ in range(self.mini_epochs):
-            perm = torch.randperm(n, device=self.device, generator=self.action_gen)
-            for i in range(0, n - self.minibatch_envs + 1, self.minibatch_envs):
-                idx = perm[i:i + self.minibatch_envs]
-                f, a_ = feats[idx].reshape(-1, feats.shape[-1]), actions[idx].reshape(-1, actions.shape[-1])
-                m = alive[idx].reshape(-1)
-                mu = self.actor(f)
-                nlp = neglogp(a_, mu, self.logstd)
-                ratio = torch.exp(old_nlp[idx].reshape(-1) - nlp)
-                ad = adv[idx].reshape(-1)
-                a_loss = torch.max(-ad * ratio, -ad * torch.clamp(ratio, 1.0 - self.e_clip, 1.0 + self.e_clip))
-                v = self.critic(f)
-                c_loss = (v - returns[idx].reshape(-1, 1)) ** 2
-                denom = torch.clamp(m.sum(), min=1.0)
-                a_l, c_l = (a_loss * m).sum() / denom, (c_loss.squeeze(-1) * m).sum() / denom
-                loss = a_l + self.critic_coef * c_l
-                for p in params:
-                    p.grad = None
-                loss.backward()
-                if world > 1:  # data-parallel over env shards: one flat all-reduce of the gradients over RCCL, averaged
-                    flat = torch.cat([p.grad.reshape(-1) for p in params])
-                    vdist.dist.all_reduce(flat, group=self.group)
-                    flat /= world
-                    o = 0
-                    for p in params:
-                        p.grad.copy_(flat[o:o + p.numel()].view_as(p))
-                        o += p.numel()
-                nn.utils.clip_grad_norm_(params, self.grad_norm)
-                self.optimizer.step()
-                info["a_loss"].append(a_l.detach())
-                info["c_loss"].append(c_l.detach())
-                info["kl"].append((0.5 * ((mu.detach() - batch["mus"][idx].reshape(-1, mu.shape[-1])) ** 2 / torch.exp(2 * self.logstd)).sum(-1) * m).sum() / denom)
+            for i in range(self.num_actors // self.minibatch_envs):
+                r = self.calc_gradients(self._get_item(i))
+                for k in info:
+                    info[k].append(r[k])
         sync()
         t2 = time.perf_counter()
         acc, sub_acc = batch["stats"]
-        acc_h, sub_h = acc.tolist(), sub_acc.tolist()  # the ONE read-back of the epoch's statistics
-        frames = batch["played_frames"]
+        alive = batch["alive"]
+        tail = torch.stack([torch.stack(info[k]).mean().double() for k in ("actor_loss", "critic_loss", "kl", "actor_clip_frac")] + [alive.double().mean()])
+        host = torch.cat([acc, sub_acc, tail]).tolist()  # the ONE read-back of the epoch's statistics
+        acc_h, sub_h, tail_h = host[:8], host[8:8 + sub_acc.numel()], host[8 + sub_acc.numel():]
+        for t in self.tasks:
+            if hasattr(t, "check"):
+                t.check()  # a substep job that timed out surfaces here, once per epoch (the streams are idle: no extra wait)
         self.epoch_num += 1
         self.frame += frames
         play_time, update_time = t1 - t0, t2 - t1
@@ -289,12 +555,18 @@ class PPOAgent:
                 "fps_step": frames / play_time, "fps_total": frames / (t2 - t0),
                 "mean_rewards": acc_h[1] / max(acc_h[0], 1.0), "mean_lengths": acc_h[2] / max(acc_h[0], 1.0),
                 "step_rewards": acc_h[4] / max(acc_h[3], 1.0), "step_sub_rewards": [s / max(acc_h[3], 1.0) for s in sub_h],
-                "alive_ratio": float(alive.sum().item() / alive.numel()),
-                "a_loss": float(torch.stack(info["a_loss"]).mean()), "c_loss": float(torch.stack(info["c_loss"]).mean()),
-                "kl": float(torch.stack(info["kl"]).mean())}
+                "alive_ratio": tail_h[4], "a_loss": tail_h[0], "c_loss": tail_h[1], "kl": tail_h[2], "clip_frac": tail_h[3]}
 
     def format_epoch_line(self, r):
         """the reference's per-epoch line (im_agent.py:211-214)"""
         return ("%d\tT_play %.2f\tT_update %.2f\tstep_rewards %.4f %s\teps_len %.2f\talive %.2f\tfps step %d\tfps total %d"
                 % (self.epoch_num, r["play_time"], r["update_time"], r["step_rewards"], "[" + ",".join("%.4f" % s for s in r["step_sub_rewards"]) + "]",
                    r["mean_lengths"], r["alive_ratio"], r["fps_step"], r["fps_total"]))
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
