@@ -453,7 +453,7 @@ def main():
                                       (", %d ROLLOUT GROUPS of %d envs on %d streams (reported separately from the headline)" % (G, ng, G) if G > 1 else "") +
                                       (", TERMINATED ENVS FROZEN (not reference behaviour)" if args.freeze_terminated else "") + (", STUB TASK (launch-logic test, not a measurement)" if stub else "")),
                        "num_envs_per_gpu": n, "global_envs": world * n, "parallelism": "env-sharded x%d, no data-path collective" % world,
-                       "world_size_seen": world_seen, "backend": None if dist is None else ("gloo" if stub else "nccl(rccl)"),
+                       "world_size_seen": world_seen, "world_size_matches_gpus": world_seen == args.gpus, "backend": None if dist is None else ("gloo" if stub else "nccl(rccl)"),
                        "per_rank_env_steps_per_s": per_rank, "alive_fraction_at_end": alive, "substep_jobs": bool(args.substep_jobs)},
             "roofline": roof,
         }
