@@ -75,6 +75,7 @@ __device__ __forceinline__ V3 residual_wrench(const float* root_rot, float a0, f
 #pragma clang fp reassociate(on) reciprocal(on) contract(fast)  // (a file-scope fp pragma stays in force past the namespace: switch back)
 #endif
 
+typedef volatile __attribute__((address_space(3))) float lds_vfloat;  // a volatile float in LDS (ds_read / ds_write, 32-bit address + immediate offset)
 constexpr int LPE = 32;  // lanes per environment
 
 // wave-wide "any lane": a compare of the ballot in scalar registers (HIP's __any materialises the predicate as a 0/1 VGPR first:
@@ -214,6 +215,12 @@ __device__ __forceinline__ void grp_argmax(float& v, int& k) {
 #ifndef V2P_LL_WPS
 #define V2P_LL_WPS 3   // waves per SIMD the register budget is set for (168 VGPRs; 2 = 256 VGPRs with everything in registers)
 #endif
+#ifndef V2P_LL_WPS_BALL
+#define V2P_LL_WPS_BALL 2     // ... of the racket + ball instantiations
+#endif
+#ifndef V2P_LL_WPS_LIMITS
+#define V2P_LL_WPS_LIMITS 2   // ... of the joint-limit instantiations without a ball
+#endif
 constexpr int LL_WPB = V2P_LL_WPB;
 // V2P_LL_PARK2: phase-scoped parking of values that a phase does not touch (link velocities during pass 2 / contact generation / the
 // Lambda recursion, Lambda of the root during contact generation, the contact records during the Lambda recursion): lowers the
@@ -298,7 +305,7 @@ struct ContactStore<true> {
 // reaction (-impulse, a pure torque) joins what the link hands up to its parent.  The inverse mass of the rows is the joint-space
 // inverse inertia K = Di + ((T - 1)^T G (T - 1))_ww = Lambda_b,ww - H1 - H1^T + Lambda_parent,ww in the notation of the recursion below.
 template <bool CONTACT, bool MULTI, bool TGS, bool DIAG, bool BALL, bool JOBS, bool LIMITS>
-__global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_WPS) void physics_ll_kernel(PhysArgs a) {
+__global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (LIMITS ? V2P_LL_WPS_LIMITS : V2P_LL_WPS))) void physics_ll_kernel(PhysArgs a) {
     constexpr bool WALK = V2P_LL_WALK != 0;  // the sweep as one walk over the tree (see the sweep)
     const int64_t N = a.n;
     const int lane = threadIdx.x & 63;
@@ -385,7 +392,11 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
     // scratch - private memory that ends up as HBM write traffic; 9 dwords x 64 lanes of LDS per wave cost nothing.
     extern __shared__ float park_all[];
     float* const park = park_all + (threadIdx.x >> 6) * LDS_FLOATS_PER_WAVE + lane;  // slot k of this lane: park[k * 64]
-    volatile float* const bl = park_all + (threadIdx.x >> 6) * LDS_FLOATS_PER_WAVE + PARK_SLOTS * 64 + half * BL_SLOTS;  // this env's ball block
+    // this env's ball block.  The pointer carries the LDS address space in its TYPE: the accesses are volatile (the ball lane writes what
+    // link lanes read within the wave), and address-space inference leaves volatile accesses alone - as a plain `volatile float*` every
+    // bl[k] was a FLAT load / store through its own 64-bit address, ~50 loop-invariant pointers that were kept (spilled: 400 B of
+    // scratch per lane) across the substep loop
+    lds_vfloat* const bl = (lds_vfloat*)(park_all + (threadIdx.x >> 6) * LDS_FLOATS_PER_WAVE + PARK_SLOTS * 64 + half * BL_SLOTS);
     auto park_put3 = [&](int slot, V3 v) { park[slot * 64] = v.x; park[(slot + 1) * 64] = v.y; park[(slot + 2) * 64] = v.z; };
     auto park_get3 = [&](int slot) -> V3 { return V3{park[slot * 64], park[(slot + 1) * 64], park[(slot + 2) * 64]}; };
     // (PARK2) the link velocities leave the registers for the phases that do not touch them; the W0 / XD0 slots are free outside the sweep
@@ -638,6 +649,7 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                 if (sub % BP.sub_per_sim == 0) {
                     // the reference's bounce test on the ball height at the start of every simulate() call (apply_external_force_to_ball, :731-737)
                     // (system-scope accesses: with substep jobs the calls of one step run in different workgroups)
+                    const int64_t e = env_here();
                     if (BP.has_bounce && live_env) {
                         if (sub == 0) flag_st(&BP.has_bounce_now[e], 0);
                         if (bp.z <= BP.bounce_height && !flag_ld(&BP.has_bounce[e])) {
@@ -674,7 +686,7 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                 const M3 Rw = q2mat(wq);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    volatile float* rk = bl + BL_RK + 16 * j;
+                    lds_vfloat* rk = bl + BL_RK + 16 * j;
                     bool on = false;
                     if (CONTACT && j < BP.ncyl) {
                         const V3 cw = wx + mul(Rw, V3{BP.cyl[j][0], BP.cyl[j][1], BP.cyl[j][2]}), aw = mul(Rw, V3{BP.cyl[j][3], BP.cyl[j][4], BP.cyl[j][5]});
@@ -746,7 +758,7 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                     const unsigned long long wb = __ballot(gap == gmin && gap < 3.0e38f);
                     const unsigned wmine = half ? (unsigned)(wb >> 32) : (unsigned)wb;
                     if (wmine && lb == __ffs(wmine) - 1) {
-                        volatile float* rk = bl + BL_RK + 32;
+                        lds_vfloat* rk = bl + BL_RK + 32;
                         rk[RK_A] = 1.f;
                         rk[RK_GAP] = gap;
                         rk[RK_RL] = rlw.x; rk[RK_RL + 1] = rlw.y; rk[RK_RL + 2] = rlw.z;
@@ -1196,7 +1208,7 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                     const float ih = PHYS_RCP(h);
 #pragma unroll
                     for (int j = 0; j < 3; ++j) {
-                        volatile float* rk = bl + BL_RK + 16 * j;
+                        lds_vfloat* rk = bl + BL_RK + 16 * j;
                         if (rk[RK_A] != 0.f && ball_rec_mine(j)) {
                             const V3 n{rk[RK_N], rk[RK_N + 1], rk[RK_N + 2]}, rl{rk[RK_RL], rk[RK_RL + 1], rk[RK_RL + 2]};
                             const float gap = rk[RK_GAP];
@@ -1514,7 +1526,7 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                                 V3 bv{bl[BL_VEL], bl[BL_VEL + 1], bl[BL_VEL + 2]}, bw{bl[BL_ANG], bl[BL_ANG + 1], bl[BL_ANG + 2]};
 #pragma unroll 1
                                 for (int j = 0; j < 3; ++j) {
-                                    volatile float* rk = bl + BL_RK + 16 * j;
+                                    lds_vfloat* rk = bl + BL_RK + 16 * j;
                                     if (rk[RK_A] == 0.f || !ball_rec_mine(j)) continue;
                                     const V3 n{rk[RK_N], rk[RK_N + 1], rk[RK_N + 2]}, rl{rk[RK_RL], rk[RK_RL + 1], rk[RK_RL + 2]};
                                     V3 t1v, t2v;
@@ -1717,7 +1729,7 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                                     V3 bv{bl[BL_VEL], bl[BL_VEL + 1], bl[BL_VEL + 2]}, bw{bl[BL_ANG], bl[BL_ANG + 1], bl[BL_ANG + 2]};
 #pragma unroll 1
                                     for (int j = 0; j < 3; ++j) {
-                                        volatile float* rk = bl + BL_RK + 16 * j;
+                                        lds_vfloat* rk = bl + BL_RK + 16 * j;
                                         if (rk[RK_A] == 0.f || !ball_rec_mine(j)) continue;
                                         const V3 n{rk[RK_N], rk[RK_N + 1], rk[RK_N + 2]}, rl{rk[RK_RL], rk[RK_RL + 1], rk[RK_RL + 2]};
                                         V3 t1, t2;
@@ -1907,11 +1919,11 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
             // force on the ball in this substep from the racket (sum over the two cylinders) and from the hull point, world axes
             V3 frk{0.f, 0.f, 0.f}, fbd{0.f, 0.f, 0.f};
             const int hl = (int)bl[BL_HLINK] - 1;
-            if (ball_lane || (valid && (lb == BP.racket_link || lb == hl))) {
+            if ((ball_lane || (valid && (lb == BP.racket_link || lb == hl)))) {
                 const float ih = PHYS_RCP(h);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    volatile float* rk = bl + BL_RK + 16 * j;
+                    lds_vfloat* rk = bl + BL_RK + 16 * j;
                     if (rk[RK_A] != 0.f) {
                         const V3 n{rk[RK_N], rk[RK_N + 1], rk[RK_N + 2]};
                         V3 t1, t2;
@@ -1936,6 +1948,9 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
                 bl[BL_POS] = bp.x; bl[BL_POS + 1] = bp.y; bl[BL_POS + 2] = bp.z;
                 bl[BL_QUAT] = bq.x; bl[BL_QUAT + 1] = bq.y; bl[BL_QUAT + 2] = bq.z; bl[BL_QUAT + 3] = bq.w;
                 bl[BL_ANG] = bw.x; bl[BL_ANG + 1] = bw.y; bl[BL_ANG + 2] = bw.z;
+                // (output addresses from the opaque env index: formed from `e` they are loop invariants, hoisted in front of the substep
+                // loop and kept - spilled - across all of it: 70 dwords of scratch per lane in the racket + ball kernels)
+                const int64_t e = env_here();
                 if (live_env && sub % BP.sub_per_sim == BP.sub_per_sim - 1) {
                     const int ks = sub / BP.sub_per_sim, nsim = nsub / BP.sub_per_sim;
                     float* o = BP.per_sim + (e * nsim + ks) * 13;
@@ -2157,7 +2172,7 @@ __global__ __launch_bounds__(64 * LL_WPB, (BALL || DIAG || LIMITS) ? 2 : V2P_LL_
             }
         }
     }
-    if constexpr (JOBS && !BALL && !LIMITS && !TGS && !DIAG) {
+    if constexpr (JOBS && !DIAG) {
         // ---- post-physics fused in (v2p_env_step): the same functions, compiled with the same semantics, as env_post_kernel; lane = body
         // holds exactly the values the exposed tensors were just given.  The post-physics kernel cost a launch of its own right behind
         // the tail of this one (the heaviest env pairs finish last, on an almost empty GPU); here every pair does it as it finishes.
@@ -2328,39 +2343,10 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s, float* actions, int* fuse
         }
         return dim3((unsigned)a.job_mono + (blocks - (unsigned)a.job_mono) * (unsigned)env->p.nsub);
     };
-    if (env->p.joint_limits && env->p.enable_contact && !tgs) {  // joint-limit rows: their own instantiations (PGS, with contacts, +- ball)
-        int rc0;
-        const dim3 jgrid = job_grid(rc0);
-        if (rc0 != V2P_OK) return rc0;
-        if (env->ball) {
-            if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, false, false, true, true, true>), jgrid, block, lds, s, a);
-            else hipLaunchKernelGGL((physics_ll_kernel<true, false, false, false, true, true, true>), jgrid, block, lds, s, a);
-        } else {
-            if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, false, false, false, true, true>), jgrid, block, lds, s, a);
-            else hipLaunchKernelGGL((physics_ll_kernel<true, false, false, false, false, true, true>), jgrid, block, lds, s, a);
-        }
-    } else if (env->p.joint_limits) {
-        set_error("physics: joint limits run with contacts on and the PGS solver");
-        return V2P_ERR_UNSUPPORTED;
-    } else if (env->ball && env->p.enable_contact && !tgs) {  // racket + ball: its own instantiation (PGS, with contacts)
-        int rc0;
-        const dim3 jgrid = job_grid(rc0);
-        if (rc0 != V2P_OK) return rc0;
-        if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, false, false, true, true, false>), jgrid, block, lds, s, a);
-        else hipLaunchKernelGGL((physics_ll_kernel<true, false, false, false, true, true, false>), jgrid, block, lds, s, a);
-    } else if (env->ball) {
-        set_error("physics: racket + ball runs with contacts on and the PGS solver");
-        return V2P_ERR_UNSUPPORTED;
-    } else if (diag && env->p.enable_contact && !tgs && !multi) {  // the instrumented build exists for the headline configuration only
-        hipLaunchKernelGGL((physics_ll_kernel<true, false, false, true, false, false, false>), grid, block, lds, s, a);
-    } else if (env->p.enable_contact && tgs) {
-        if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, true, false, false, false, false>), grid, block, lds, s, a);
-        else hipLaunchKernelGGL((physics_ll_kernel<true, false, true, false, false, false, false>), grid, block, lds, s, a);
-    } else if (env->p.enable_contact) {
-        int rc0;
-        const dim3 jgrid = job_grid(rc0);
-        if (rc0 != V2P_OK) return rc0;
-        if (fused_post && actions && env->mlib) {  // v2p_env_step: post-physics runs in the epilogue of every env's last job
+    // every production instantiation is cut into substep jobs and runs post-physics in the epilogue of an env's last job (v2p_env_step);
+    // the instrumented build (DIAG) exists for the headline configuration only and keeps whole control steps per workgroup
+    auto with_post = [&]() {
+        if (fused_post && actions && env->mlib) {
             a.post.b = env->buf;
             a.post.t = env->mlib->t;
             a.post.motion_id = env->motion_id;
@@ -2368,11 +2354,33 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s, float* actions, int* fuse
             a.post.on = 1;
             *fused_post = 1;
         }
-        if (multi) hipLaunchKernelGGL((physics_ll_kernel<true, true, false, false, false, true, false>), jgrid, block, lds, s, a);
-        else hipLaunchKernelGGL((physics_ll_kernel<true, false, false, false, false, true, false>), jgrid, block, lds, s, a);
+    };
+    if (env->p.joint_limits && !(env->p.enable_contact && !tgs)) {
+        set_error("physics: joint limits run with contacts on and the PGS solver");
+        return V2P_ERR_UNSUPPORTED;
+    }
+    if (env->ball && !(env->p.enable_contact && !tgs)) {
+        set_error("physics: racket + ball runs with contacts on and the PGS solver");
+        return V2P_ERR_UNSUPPORTED;
+    }
+    if (diag && env->p.enable_contact && !tgs && !multi && !env->ball && !env->p.joint_limits) {
+        hipLaunchKernelGGL((physics_ll_kernel<true, false, false, true, false, false, false>), grid, block, lds, s, a);
     } else {
-        if (multi) hipLaunchKernelGGL((physics_ll_kernel<false, true, false, false, false, false, false>), grid, block, lds, s, a);
-        else hipLaunchKernelGGL((physics_ll_kernel<false, false, false, false, false, false, false>), grid, block, lds, s, a);
+        int rc0;
+        const dim3 jgrid = job_grid(rc0);
+        if (rc0 != V2P_OK) return rc0;
+        with_post();
+        const bool lim = env->p.joint_limits != 0, ball = env->ball != nullptr, con = env->p.enable_contact != 0;
+#define V2P_LL_LAUNCH(C, T, B, L) do { \
+            if (multi) hipLaunchKernelGGL((physics_ll_kernel<C, true, T, false, B, true, L>), jgrid, block, lds, s, a); \
+            else hipLaunchKernelGGL((physics_ll_kernel<C, false, T, false, B, true, L>), jgrid, block, lds, s, a); } while (0)
+        if (lim && ball) V2P_LL_LAUNCH(true, false, true, true);
+        else if (lim) V2P_LL_LAUNCH(true, false, false, true);
+        else if (ball) V2P_LL_LAUNCH(true, false, true, false);
+        else if (con && tgs) V2P_LL_LAUNCH(true, true, false, false);
+        else if (con) V2P_LL_LAUNCH(true, false, false, false);
+        else V2P_LL_LAUNCH(false, false, false, false);
+#undef V2P_LL_LAUNCH
     }
     if (paired) {  // the tables this launch has filled are what the next one reads
         env->pair_buf = 1 - buf;
