@@ -203,6 +203,13 @@ typedef struct {
     int32_t joint_limits;       /* 1: every DOF whose range (v2p_model_desc.limit_lower/upper) is narrower than a full turn carries a
                                  * limit row in the contact solver (the racket arm of the player MJCFs; the amass MJCF has none).
                                  * Link-per-lane schedule, PGS, contacts on.  0 (default): ranges are ignored. */
+    /* ---- ABI 9 */
+    float limit_margin;         /* radians; < 0 = default (0.05).  A limit row exists in a substep only while its DOF is within reach of the
+                                 * limit: C < limit_margin + h * max(0, rate of approach after the unconstrained update v*), C = distance to
+                                 * the nearer limit - the speculative activation every other row of the model has (contact_offset for hull
+                                 * vertices, the closing distance of a substep for the ball), PhysX's `contactDistance` of a joint limit.
+                                 * A joint far from its limits costs nothing; one that is pushed across by an impulse of the same substep
+                                 * is caught in the next (C < 0 is always active) and corrected with erp.  1e9 = rows always on (ABI 8). */
 } v2p_sim_cfg;
 
 /* Caller-owned DEVICE buffers the engine reads/writes; these are the tensors the reference

@@ -72,6 +72,7 @@ typedef struct {
     int enable_contact;
     int solver_type;       /* 0 = PGS (default), 1 = TGS (see the substep) */
     int joint_limits;      /* 1: DOFs whose range is narrower than a full turn get a limit row (see the substep) */
+    double limit_margin;   /* 0.05 rad: the row exists only while C < limit_margin + h max(0, approach rate of v*) */
 } v2p_oparams;
 
 /* ---- racket + ball (vid2player/env/tasks/humanoid_smpl_im_mvae.py:367-442, 711-783; data/assets/tennis_ball.urdf,
@@ -630,7 +631,11 @@ static int substep_impl(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s
          * carries ONE row against the nearer of its two limits, C = min(q - lo, hi - q), on the joint rate of that DOF (body axes; equal
          * to the rate of the exp-map component to first order), sign +1 (lower) / -1 (upper); bias like a contact's normal row
          * (C/h separated - only an approach that would cross the limit within the substep is stopped -, erp C/h violated); impulse
-         * >= 0.  Order: the limit rows of joint b right before the hull points of body b. */
+         * >= 0.  Order: the limit rows of joint b right before the hull points of body b.
+         * Activation (speculative, like every other row of this model: contact_offset for hull vertices, the closing distance of a
+         * substep for the ball; PhysX: the `contactDistance` of a joint limit): the row exists in this substep only if
+         * C < limit_margin + h max(0, approach rate), the rate being the joint rate AFTER the unconstrained update (v*: the implicit
+         * PD can change a joint rate by tens of rad/s within a substep).  A violated limit (C < 0) is always active. */
         crow_t rows[NB * MAXC_BODY + 4 + 3 * NJ];
         int nc = 0, ci = 0;
         /* ball x humanoid: the hull (convex hull of the link's contact vertices) nearest to the ball carries one point, found at the
@@ -683,6 +688,10 @@ static int substep_impl(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s
                     const double lo = m->limit_lo[j], hi = m->limit_hi[j];
                     if (hi - lo >= 6.28) continue;
                     const double clo = q[j] - lo, chi = hi - q[j];
+                    {
+                        const double sg = clo <= chi ? 1.0 : -1.0, gp = clo <= chi ? clo : chi;
+                        if (!(gp < p->limit_margin + h * fmax(0.0, -sg * v[6 + j]))) continue;
+                    }
                     crow_t *r = &rows[nc++];
                     memset(r, 0, sizeof(*r));
                     r->kind = 3; r->body = b; r->vert = i;

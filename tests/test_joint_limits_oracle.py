@@ -91,3 +91,31 @@ def test_limits_and_contacts_share_the_sweep(racket_model):
     _, dp, dv, rb = o.get_state()
     assert touched >= 4 and np.isfinite(rb).all()
     assert dp[jw] < np.deg2rad(10.0) + 5e-3
+
+
+def test_speculative_activation_agrees_with_rows_that_are_always_on(racket_model):
+    """limit_margin: a row exists only while its DOF is within 0.05 rad of the limit or would reach it at the approach rate of v*.  Driven
+    into the limits (and spun into them) the result is the one of rows that always exist (limit_margin = 1e9, the model before ABI 9):
+    a row that is absent is a row that would not have acted."""
+    m = racket_model
+    jw, je = 3 * (m.body_index("R_Wrist") - 1), 3 * (m.body_index("R_Elbow") - 1)
+    tar = np.zeros(69)
+    tar[jw:jw + 3] = [1.0, 1.2, -2.0]
+    tar[je] = 2.5
+    dv = np.zeros(69)
+    dv[jw + 1] = 15.0
+
+    def run(margin):
+        o = po.PhysOracle(m, po.default_params(joint_limits=1, limit_margin=margin))
+        root = np.zeros(13)
+        root[2], root[6] = 3.0, 1.0
+        o.set_state(root, np.zeros(69), dv)
+        out = []
+        for _ in range(40):
+            o.step(pd_target=tar)
+            out.append(o.get_state()[1].copy())
+        return np.array(out)
+
+    a, b = run(0.05), run(1e9)
+    assert np.abs(a - b).max() < 1e-6, np.abs(a - b).max()
+    assert np.abs(a[-1, jw:jw + 3] - np.deg2rad([10.0, 45.0, -90.0])).max() < 2e-3

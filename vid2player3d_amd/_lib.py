@@ -42,7 +42,7 @@ class SimCfg(C.Structure):
                 ("context_padding", C.c_int32), ("term_heights", C.c_float * 24), ("body_pos_weights", C.c_float * 24),
                 ("reward_specs", C.c_float * 8), ("freeze_terminated_envs", C.c_int32), ("schedule", C.c_int32), ("pair_envs_by_load", C.c_int32),
                 ("solver_type", C.c_int32), ("substep_jobs", C.c_int32), ("job_mono_permille", C.c_int32), ("pair_mix_permille", C.c_int32), ("debug_contacts", C.c_int32),
-                ("joint_limits", C.c_int32)]
+                ("joint_limits", C.c_int32), ("limit_margin", C.c_float)]
 
 
 class EnvBuffers(C.Structure):

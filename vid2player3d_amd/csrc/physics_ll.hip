@@ -216,10 +216,10 @@ __device__ __forceinline__ void grp_argmax(float& v, int& k) {
 #define V2P_LL_WPS 3   // waves per SIMD the register budget is set for (168 VGPRs; 2 = 256 VGPRs with everything in registers)
 #endif
 #ifndef V2P_LL_WPS_BALL
-#define V2P_LL_WPS_BALL 2     // ... of the racket + ball instantiations
+#define V2P_LL_WPS_BALL 3     // ... of the racket + ball instantiations
 #endif
 #ifndef V2P_LL_WPS_LIMITS
-#define V2P_LL_WPS_LIMITS 2   // ... of the joint-limit instantiations without a ball
+#define V2P_LL_WPS_LIMITS 3   // ... of the joint-limit instantiations without a ball
 #endif
 constexpr int LL_WPB = V2P_LL_WPB;
 // V2P_LL_PARK2: phase-scoped parking of values that a phase does not touch (link velocities during pass 2 / contact generation / the
@@ -574,67 +574,8 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                 zv = cross(pw, wpr);
             }
         }
-        // ---- per link, all lanes at once: joint torque, body inertia at its origin (world axes), bias force
-        // mass properties are needed once per substep: reload them (L1/K$ hits) instead of pinning 10 registers for the
-        // whole kernel; the opaque index keeps the loads from being hoisted back out of the loop
-        const float mass = S->mass[bo];
-        const V3 com{S->com[bo][0], S->com[bo][1], S->com[bo][2]};
-        const Sym3 Ib{S->inertia[bo][0], S->inertia[bo][1], S->inertia[bo][2], S->inertia[bo][3], S->inertia[bo][4], S->inertia[bo][5]};
-        V3 tau{0.f, 0.f, 0.f};
-        float lsgn[3] = {0.f, 0.f, 0.f}, lbias[3] = {0.f, 0.f, 0.f}, llam[3] = {0.f, 0.f, 0.f};  // LIMITS: this joint's rows (sign 0 = none)
-        bool limact = false;
-        Sym3 Kd{1.f, 0.f, 0.f, 1.f, 0.f, 1.f};  // LIMITS: joint-space inverse inertia of this joint, body axes
-        Sym3 A;
-        M3 B;
-        Sym3 C{mass, 0.f, 0.f, mass, 0.f, mass};
-        V3 pn, pf;
-        {
-            const M3 R = q2mat(q);
-            const float kp = S->kp[bo], kd = S->kd[bo];
-            const V3 qe = b != 0 ? quat_to_expmap_stable(jq) : V3{0.f, 0.f, 0.f};
-            if (b != 0) tau = mul(R, kp * (park_get3(PARK_TAR) - qe) - (kd + h * kp) * wt);
-            if (LIMITS) {
-                limact = false;
-                const float ih = PHYS_RCP(h);
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const float lo = S->limit_lo[bo][i], hi = S->limit_hi[bo][i], qi = i == 0 ? qe.x : (i == 1 ? qe.y : qe.z);
-                    const bool on = P.joint_limits && valid && b != 0 && hi - lo < 6.28f;
-                    const float clo = qi - lo, chi = hi - qi;
-                    const float gap = clo <= chi ? clo : chi;
-                    lsgn[i] = on ? (clo <= chi ? 1.f : -1.f) : 0.f;
-                    lbias[i] = gap >= 0.f ? gap * ih : fmaxf(P.erp * gap * ih, -P.max_depen);
-                    llam[i] = 0.f;
-                    limact = limact || on;
-                }
-            }
-            V3 dc = mul(R, com);
-            V3 k0 = mul(Ib, V3{R.m[0], R.m[1], R.m[2]});
-            V3 k1 = mul(Ib, V3{R.m[3], R.m[4], R.m[5]});
-            V3 k2 = mul(Ib, V3{R.m[6], R.m[7], R.m[8]});
-            V3 r0 = row(R, 0), r1 = row(R, 1), r2 = row(R, 2);
-            Sym3 Ic{dot(r0, k0), dot(r0, k1), dot(r0, k2), dot(r1, k1), dot(r1, k2), dot(r2, k2)};
-            float dd = dot(dc, dc);
-            A = Sym3{Ic.xx + mass * (dd - dc.x * dc.x), Ic.xy - mass * dc.x * dc.y, Ic.xz - mass * dc.x * dc.z,
-                     Ic.yy + mass * (dd - dc.y * dc.y), Ic.yz - mass * dc.y * dc.z, Ic.zz + mass * (dd - dc.z * dc.z)};
-            B.m[0] = 0.f;            B.m[1] = -mass * dc.z;  B.m[2] = mass * dc.y;
-            B.m[3] = mass * dc.z;    B.m[4] = 0.f;           B.m[5] = -mass * dc.x;
-            B.m[6] = -mass * dc.y;   B.m[7] = mass * dc.x;   B.m[8] = 0.f;
-            V3 wwd = cross(w, cross(w, dc));
-            pf = mass * (wwd - V3{0.f, 0.f, P.gravity_z});
-            pn = cross(w, mul(Ic, w)) + cross(dc, pf);
-            if (b == 0 && wrench_on) {
-                const float* cw = a.ctrl + env_here() * CTRL_SLOTS;
-                const V3 extF{ldin(&cw[CT_FORCE + 0]), ldin(&cw[CT_FORCE + 1]), ldin(&cw[CT_FORCE + 2])};
-                const V3 extT{ldin(&cw[CT_TORQUE + 0]), ldin(&cw[CT_TORQUE + 1]), ldin(&cw[CT_TORQUE + 2])};
-                pn = pn - extT - cross(dc, extF);  // force acts at the root COM
-                pf = pf - extF;
-            }
-        }
-
-        // pose of the link: next used by contact generation, then by the integration
-        park[PARK_Q * 64] = q.x; park[(PARK_Q + 1) * 64] = q.y; park[(PARK_Q + 2) * 64] = q.z; park[(PARK_Q + 3) * 64] = q.w;
-        park_put3(PARK_X, x);
+        // (racket + ball: the ball lane and the ball x hull narrow phase run HERE, right after the kinematics, where a lane holds little
+        // more than its pose and velocity: further down, next to the link's inertia blocks, their temporaries did not fit)
         if (BALL) {
             // pose and (start-of-substep) velocity of the racket's link, handed to the ball lane of the same env
             const int src = base + BP.racket_link;
@@ -768,6 +709,67 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                 }
             }
         }
+        // ---- per link, all lanes at once: joint torque, body inertia at its origin (world axes), bias force
+        // mass properties are needed once per substep: reload them (L1/K$ hits) instead of pinning 10 registers for the
+        // whole kernel; the opaque index keeps the loads from being hoisted back out of the loop
+        const float mass = S->mass[bo];
+        const V3 com{S->com[bo][0], S->com[bo][1], S->com[bo][2]};
+        const Sym3 Ib{S->inertia[bo][0], S->inertia[bo][1], S->inertia[bo][2], S->inertia[bo][3], S->inertia[bo][4], S->inertia[bo][5]};
+        V3 tau{0.f, 0.f, 0.f};
+        float lsgn[3] = {0.f, 0.f, 0.f}, lbias[3] = {0.f, 0.f, 0.f}, llam[3] = {0.f, 0.f, 0.f};  // LIMITS: this joint's rows (sign 0 = none)
+        bool limact = false;
+        Sym3 Kd{1.f, 0.f, 0.f, 1.f, 0.f, 1.f};  // LIMITS: joint-space inverse inertia of this joint, body axes
+        Sym3 A;
+        M3 B;
+        Sym3 C{mass, 0.f, 0.f, mass, 0.f, mass};
+        V3 pn, pf;
+        {
+            const M3 R = q2mat(q);
+            const float kp = S->kp[bo], kd = S->kd[bo];
+            const V3 qe = b != 0 ? quat_to_expmap_stable(jq) : V3{0.f, 0.f, 0.f};
+            if (b != 0) tau = mul(R, kp * (park_get3(PARK_TAR) - qe) - (kd + h * kp) * wt);
+            if (LIMITS) {
+                limact = false;
+                const float ih = PHYS_RCP(h);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const float lo = S->limit_lo[bo][i], hi = S->limit_hi[bo][i], qi = i == 0 ? qe.x : (i == 1 ? qe.y : qe.z);
+                    const bool on = P.joint_limits && valid && b != 0 && hi - lo < 6.28f;
+                    const float clo = qi - lo, chi = hi - qi;
+                    const float gap = clo <= chi ? clo : chi;
+                    lsgn[i] = on ? (clo <= chi ? 1.f : -1.f) : 0.f;
+                    lbias[i] = gap >= 0.f ? gap * ih : fmaxf(P.erp * gap * ih, -P.max_depen);
+                    llam[i] = 0.f;
+                    limact = limact || on;
+                }
+            }
+            V3 dc = mul(R, com);
+            V3 k0 = mul(Ib, V3{R.m[0], R.m[1], R.m[2]});
+            V3 k1 = mul(Ib, V3{R.m[3], R.m[4], R.m[5]});
+            V3 k2 = mul(Ib, V3{R.m[6], R.m[7], R.m[8]});
+            V3 r0 = row(R, 0), r1 = row(R, 1), r2 = row(R, 2);
+            Sym3 Ic{dot(r0, k0), dot(r0, k1), dot(r0, k2), dot(r1, k1), dot(r1, k2), dot(r2, k2)};
+            float dd = dot(dc, dc);
+            A = Sym3{Ic.xx + mass * (dd - dc.x * dc.x), Ic.xy - mass * dc.x * dc.y, Ic.xz - mass * dc.x * dc.z,
+                     Ic.yy + mass * (dd - dc.y * dc.y), Ic.yz - mass * dc.y * dc.z, Ic.zz + mass * (dd - dc.z * dc.z)};
+            B.m[0] = 0.f;            B.m[1] = -mass * dc.z;  B.m[2] = mass * dc.y;
+            B.m[3] = mass * dc.z;    B.m[4] = 0.f;           B.m[5] = -mass * dc.x;
+            B.m[6] = -mass * dc.y;   B.m[7] = mass * dc.x;   B.m[8] = 0.f;
+            V3 wwd = cross(w, cross(w, dc));
+            pf = mass * (wwd - V3{0.f, 0.f, P.gravity_z});
+            pn = cross(w, mul(Ic, w)) + cross(dc, pf);
+            if (b == 0 && wrench_on) {
+                const float* cw = a.ctrl + env_here() * CTRL_SLOTS;
+                const V3 extF{ldin(&cw[CT_FORCE + 0]), ldin(&cw[CT_FORCE + 1]), ldin(&cw[CT_FORCE + 2])};
+                const V3 extT{ldin(&cw[CT_TORQUE + 0]), ldin(&cw[CT_TORQUE + 1]), ldin(&cw[CT_TORQUE + 2])};
+                pn = pn - extT - cross(dc, extF);  // force acts at the root COM
+                pf = pf - extF;
+            }
+        }
+
+        // pose of the link: next used by contact generation, then by the integration
+        park[PARK_Q * 64] = q.x; park[(PARK_Q + 1) * 64] = q.y; park[(PARK_Q + 2) * 64] = q.z; park[(PARK_Q + 3) * 64] = q.w;
+        park_put3(PARK_X, x);
         LLPH(1);
         park_vel(w, xd);
         // ================================================================ pass 2: articulated inertia, leaves -> root by level
@@ -1101,6 +1103,25 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
             const bool ballground = BALL && ball_lane && bl[BL_GA] != 0.f;
             const unsigned long long tb = __ballot(valid && (cnt > 0 || ballhit));
             const unsigned m0 = (unsigned)tb, m1 = (unsigned)(tb >> 32);
+            if (LIMITS && any64(limact)) {
+                // speculative activation of the limit rows (the model is stated in oracle/phys/v2p_phys_oracle.c): a row exists in this substep
+                // only while its DOF is within limit_margin of the limit or would reach it at the approach rate of v* (the joint rate after
+                // the unconstrained update: link velocity minus the parent's, body axes).  Joints far from their limits are no stops of the
+                // walk and Lambda is not carried down to them.
+                const V3 wv = PARK2 ? park_get3(PARK_W0) : w;
+                const V3 pwv = pp(wv, true);
+                const V3 om = mulT(q2mat(q), wv - pwv);
+                const float mrate = P.limit_margin * PHYS_RCP(h);
+                bool anyrow = false;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const float omi = i == 0 ? om.x : (i == 1 ? om.y : om.z);
+                    const bool on = lsgn[i] != 0.f && lbias[i] < mrate + fmaxf(0.f, -lsgn[i] * omi);  // (violated: lbias < 0)
+                    if (!on) lsgn[i] = 0.f;
+                    anyrow = anyrow || on;
+                }
+                limact = anyrow;
+            }
             const unsigned long long lmb = LIMITS ? __ballot(valid && limact) : 0ull;
             const unsigned lm0 = (unsigned)lmb, lm1 = (unsigned)(lmb >> 32);
             if (DIAG && a.wave_times) { const int tt = __popc(half ? m1 : m0); tsum += tt; tmaxs = tt > tmaxs ? tt : tmaxs; }

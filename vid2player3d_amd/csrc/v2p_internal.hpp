@@ -95,6 +95,7 @@ struct EnvParams {
     int freeze_terminated;  // envs whose reset flag is set are not simulated (their state stays as it is)
     int solver_type;        // 0 PGS, 1 TGS (frozen Jacobians)
     int joint_limits;       // 1: limit rows for DOFs with a range narrower than a full turn
+    float limit_margin;     // ... that exist only while C < limit_margin + h max(0, approach rate of v*)
     int context_length, context_padding;
     float dt;              // control step
     float term_heights[NB];

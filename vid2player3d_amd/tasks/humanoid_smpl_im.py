@@ -403,6 +403,7 @@ class HumanoidSMPLIM:
         # joint ranges of the MJCF enforced as limit rows (Isaac Gym always enforces them; only the racket arm of the player MJCFs has
         # DOFs narrower than a full turn, the amass MJCF has none)
         c.joint_limits = int(env.get("joint_limits", False))
+        c.limit_margin = float(env.get("limit_margin", -1.0))  # radians within which a limit row exists (-1: the engine's default, 0.05)
         c.debug_contacts = int(env.get("debug_contacts", 0))  # 0 off, 1 last substep's contact vertices kept, 2 every substep's
         hold = env.get("residual_force_hold", "first_sim")
         c.residual_hold_sims = 1 if hold == "first_sim" else self.control_freq_inv
