@@ -101,6 +101,10 @@ typedef struct {
     const int *forced_ids; /* [NB*4] in: use these hull vertices (body*64+vertex, -1 = none) instead of the selection rule */
     int *own_ids;          /* [NB*4] out: what the selection rule picks in this state (whether or not it was forced) */
     double *margins;       /* [NB] out: how close the selection rule came to deciding otherwise, in metres (1e30 = no decision) */
+    double *clamp_margin;  /* [1] in/out (min): how close any row update of the sweep came to the other side of its clamp, as the change of
+                            * the row's relative velocity (m/s, rad/s for a limit row) that would have switched it: |unclamped impulse -
+                            * switching value| * w_ii.  A float32 evaluation of the same sweep can take the other branch when this is
+                            * of the order of its rounding; the parity tests attribute their outliers with it. */
 } v2p_osub_io;
 
 typedef struct {
@@ -828,6 +832,10 @@ static int substep_impl(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s
                     double rel = bias[row];
                     for (int col = 0; col < NDT; ++col) rel += Jr[row * NDT + col] * v[col];
                     double nl = lam[row] - rel / wii[row];
+                    if (io && io->clamp_margin) {
+                        const double sw = a == 0 ? fabs(nl) : fabs(fabs(nl) - rows[c].mu * lam[3 * c]);
+                        if (sw * wii[row] < *io->clamp_margin) *io->clamp_margin = sw * wii[row];
+                    }
                     if (a == 0) { if (nl < 0) nl = 0; }
                     else { double lim = rows[c].mu * lam[3 * c]; if (nl > lim) nl = lim; if (nl < -lim) nl = -lim; }
                     double dl = nl - lam[row];
@@ -998,10 +1006,12 @@ int v2p_oracle_substep(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s,
  * own_ids [nsub][NB*4], margins [nsub][NB] (nullable): what the rule selects in the state of each substep and how narrowly. */
 int v2p_oracle_step_io(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s, const double *pd_target, const double *ext_force,
                        const double *ext_torque, int nsub, int hold, double *contact_force, double *dof_force, int *contact_ids,
-                       const int *forced_ids, int *own_ids, double *margins) {
+                       const int *forced_ids, int *own_ids, double *margins, double *clamp_margin /*[1] nullable: min over the substeps*/) {
+    if (clamp_margin) *clamp_margin = 1e30;
     for (int i = 0; i < nsub; ++i) {
         int on = i < hold;
-        v2p_osub_io io = {forced_ids ? forced_ids + (size_t)i * NB * 4 : 0, own_ids ? own_ids + (size_t)i * NB * 4 : 0, margins ? margins + (size_t)i * NB : 0};
+        v2p_osub_io io = {forced_ids ? forced_ids + (size_t)i * NB * 4 : 0, own_ids ? own_ids + (size_t)i * NB * 4 : 0, margins ? margins + (size_t)i * NB : 0,
+                          clamp_margin};
         int rc = v2p_oracle_substep_io(m, p, s, pd_target, on ? ext_force : 0, on ? ext_torque : 0, contact_force, dof_force, contact_ids, &io);
         if (rc) return rc;
     }
@@ -1010,7 +1020,7 @@ int v2p_oracle_step_io(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s,
 
 int v2p_oracle_step(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s, const double *pd_target, const double *ext_force,
                     const double *ext_torque, int nsub, int hold, double *contact_force, double *dof_force, int *contact_ids) {
-    return v2p_oracle_step_io(m, p, s, pd_target, ext_force, ext_torque, nsub, hold, contact_force, dof_force, contact_ids, 0, 0, 0);
+    return v2p_oracle_step_io(m, p, s, pd_target, ext_force, ext_torque, nsub, hold, contact_force, dof_force, contact_ids, 0, 0, 0, 0);
 }
 
 /* A batch of independent humanoids, OpenMP over envs (the cpu_baseline leg of bench.py and the larger parity tests): env e uses
@@ -1021,7 +1031,7 @@ int v2p_oracle_step_batch(const v2p_omodel *const *models, const int *model_of, 
                           int nsub, int hold, double *contact_force /*[n][NB*3]*/, double *dof_force /*[n][69]*/, int *contact_ids /*[n][NB*4]*/,
                           const int *forced_ids /*[n][nsub][NB*4]*/, int *own_ids, double *margins /*[n][nsub][NB]*/,
                           double *root13 /*[n][13]*/, double *dof_pos /*[n][69]*/, double *dof_vel /*[n][69]*/, double *rb_state /*[n][NB*13]*/,
-                          int num_threads) {
+                          int num_threads, double *clamp_margin /*[n] nullable*/) {
     int failed = 0;
 #ifdef _OPENMP
     if (num_threads > 0) omp_set_num_threads(num_threads);
@@ -1034,7 +1044,7 @@ int v2p_oracle_step_batch(const v2p_omodel *const *models, const int *model_of, 
                                     ext_torque ? ext_torque + E * 3 : 0, nsub, hold, contact_force ? contact_force + E * NB * 3 : 0,
                                     dof_force ? dof_force + E * 3 * NJ : 0, contact_ids ? contact_ids + E * NB * 4 : 0,
                                     forced_ids ? forced_ids + E * nsub * NB * 4 : 0, own_ids ? own_ids + E * nsub * NB * 4 : 0,
-                                    margins ? margins + E * nsub * NB : 0);
+                                    margins ? margins + E * nsub * NB : 0, clamp_margin ? clamp_margin + E : 0);
         if (rc) { ++failed; continue; }
         if (root13 || dof_pos || dof_vel || rb_state)
             v2p_oracle_get_state(m, &states[e], root13 ? root13 + E * 13 : 0, dof_pos ? dof_pos + E * 3 * NJ : 0, dof_vel ? dof_vel + E * 3 * NJ : 0,

@@ -157,7 +157,7 @@ class PhysOracle:
         own = np.full((nsub, NB, 4), -1, dtype=np.int32) if want_selection else None
         mg = np.zeros((nsub, NB)) if want_selection else None
         rc = self.lib.v2p_oracle_step_io(C.byref(self.model), C.byref(self.params), C.byref(self.state), _dptr(tar), _dptr(f), _dptr(t),
-                                         int(nsub), int(hold), _dptr(cf), _dptr(df), _iptr(ids), _iptr(forced), _iptr(own), _dptr(mg))
+                                         int(nsub), int(hold), _dptr(cf), _dptr(df), _iptr(ids), _iptr(forced), _iptr(own), _dptr(mg), None)
         if rc:
             raise RuntimeError("oracle substep failed (mass matrix not positive definite)")
         if want_selection:
@@ -245,10 +245,12 @@ class BatchOracle:
         if want_selection:
             out["own"] = np.full((n, nsub, NB, 4), -1, dtype=np.int32)
             out["margin"] = np.zeros((n, nsub, NB))
+        # how close any row update came to the other side of its clamp, as a change of the row's relative velocity (min over the step)
+        out["clamp"] = np.full(n, 1e30)
         failed = self.lib.v2p_oracle_step_batch(self._mptr, _iptr(self.model_of), C.byref(self.params), self.states, n, _dptr(tar), _dptr(f), _dptr(t),
                                                 int(nsub), int(hold), _dptr(out["cf"]), _dptr(out["df"]), _iptr(out["ids"]), _iptr(forced),
                                                 _iptr(out.get("own")), _dptr(out.get("margin")), _dptr(out["root"]), _dptr(out["dpos"]),
-                                                _dptr(out["dvel"]), _dptr(out["rb"]), self.threads)
+                                                _dptr(out["dvel"]), _dptr(out["rb"]), self.threads, _dptr(out["clamp"]))
         if failed:
             raise RuntimeError("oracle step failed in %d envs (mass matrix not positive definite)" % failed)
         return out

@@ -60,3 +60,21 @@ def close(a, b, tol, what=""):
         print("[close] %-40s err %.3e  limit %.3e  used %.3f" % (what, err, lim, err / lim))
         return
     assert err <= lim, "%s: max abs err %.3e > %.1e" % (what, err, lim)
+
+
+def rows_close(a, b, atol, rtol, what):
+    """Per-element mixed bound |a - b| <= atol + rtol |b| (axis 0 = env).  Prints the 50 / 99 / 100th percentiles of the error and of the
+    share of the bound it uses (pytest -s) and returns the boolean mask of the ENVS that break the bound somewhere."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert np.isfinite(a).all(), what + ": non-finite values"
+    if a.size == 0:
+        return np.zeros(a.shape[0], dtype=bool)
+    err = np.abs(a - b)
+    use = err / (atol + rtol * np.abs(b))
+    bad = (use > 1.0).reshape(a.shape[0], -1).any(axis=1)
+    pe, pu = np.percentile(err, [50, 99, 100]), np.percentile(use, [50, 99, 100])
+    print("[rows] %-34s |err| p50 %.1e p99 %.1e max %.1e | share of (%.0e + %.0e|ref|) p50 %.3f p99 %.3f max %.2f | envs over: %d of %d"
+          % (what, pe[0], pe[1], pe[2], atol, rtol, pu[0], pu[1], pu[2], int(bad.sum()), a.shape[0]))
+    return bad
