@@ -208,7 +208,15 @@ def cpu_baseline(budget_s=12.0, max_steps=HORIZON, sigma=0.17):
         t_phys += tc - tb
         t_task += (tb - ta) + (td - tc)
     dt = t_phys + t_task
-    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
+    ref_ops = None
+    try:  # the reference's OWN task code timed in the build container (tools/ref_cpu_baseline.py; the reference tree does not travel)
+        r = json.load(open(os.path.join(REPO, "profiles", "r03_ref_cpu_task_ops.json")))
+        ref_ops = {"env_steps_per_s": r["env_steps_per_s_task_ops_only"], "kind": "reference (its HumanoidSMPLIM reset / pre_physics_step / post_physics_step on "
+                   "CPU tensors, physics replaced by a state copy)", "cores": r["threads"], "host": "build container (%s), NOT this box" % r["host"],
+                   "envs": r["envs"], "ms_per_step": r["ms_per_step"], "source": "from_profiles: profiles/r03_ref_cpu_task_ops.json"}
+    except Exception:
+        pass
+    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port", "reference_task_ops": ref_ops,
             "physics_env_steps_per_s": n * steps / t_phys, "physics_env_steps_per_s_per_core": n * steps / t_phys / threads,
             "task_ops_env_steps_per_s": n * steps / t_task, "task_ops_threads": 1,
             "sample": "%d envs x %d control steps (4 substeps each, contacts on): C float64 dense oracle, one batched OpenMP call per step on %d threads "
