@@ -329,6 +329,10 @@ typedef struct {                  /* caller-owned DEVICE buffers */
     float* bounce_pos;            /* [N,3] */
     uint8_t* has_racket_contact;      /* [N] */
     uint8_t* has_racket_contact_now;  /* [N] */
+    /* ---- ABI 9 */
+    float* contact_force_sum;     /* [N,24,3] nullable: `_contact_forces_sum` (humanoid_smpl_im_mvae.py:186, 690, 781) - the net contact force of
+                                   * every link (the racket's link carries the reaction of the ball) after each simulate() call, summed over the
+                                   * calls of the control step; overwritten by every step */
 } v2p_ball_buffers;
 int v2p_env_attach_ball(v2p_env* e, const v2p_ball_cfg* cfg, const v2p_ball_buffers* buffers);
 
@@ -342,6 +346,10 @@ int v2p_env_profile_end(v2p_env* e, double* physics_ms_total, int64_t* launches)
 /* synchronises the stream and reports errors detected on the device since the last check (a substep job that waited too long for
  * its predecessor: V2P_ERR_HIP).  Cheap enough for once per epoch; not needed for correctness of normal runs. */
 int v2p_env_check(v2p_env* e, void* stream);
+/* the same without waiting (ABI 9): enqueues a copy of the error word behind the work already on `stream` and reports what the PREVIOUS
+ * call's copy has brought back, if it has arrived.  One call per epoch (HumanoidSMPLIM.reset of all envs makes it) surfaces a timed-out
+ * job one epoch late at no cost to the rollout. */
+int v2p_env_check_async(v2p_env* e, void* stream);
 
 const char* v2p_last_error(void);
 int v2p_abi_version(void);

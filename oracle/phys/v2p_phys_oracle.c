@@ -936,8 +936,10 @@ void v2p_oracle_ball_aero(const v2p_oball *ball, double spin_scale, double force
 int v2p_oracle_step_ball(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s, const double *pd_target, const double *ext_force,
                          const double *ext_torque, int nsub, int hold, int sub_per_sim, double *contact_force, double *dof_force, int *contact_ids,
                          const v2p_oball_params *bp, v2p_oball *ball, double spin_scale, double *ball_per_sim, int *racket_hit_per_sim,
-                         double *ball_contact) {
+                         double *ball_contact, double *contact_force_sum /*[NB*3] nullable: net contact forces summed over the simulate() calls
+                                                                          * (`_contact_forces_sum`, humanoid_smpl_im_mvae.py:781; needs contact_force)*/) {
     double f[3] = {0, 0, 0}, bc[9];
+    if (contact_force_sum) memset(contact_force_sum, 0, sizeof(double) * NB * 3);
     for (int i = 0; i < nsub; ++i) {
         if (i % sub_per_sim == 0) v2p_oracle_ball_aero(ball, spin_scale, f);
         int on = i < hold;
@@ -951,6 +953,7 @@ int v2p_oracle_step_ball(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *
                 memcpy(o + 7, ball->vel, sizeof(double) * 3); memcpy(o + 10, ball->angvel, sizeof(double) * 3);
             }
             if (racket_hit_per_sim) racket_hit_per_sim[k] = (bc[0] != 0.0 || bc[1] != 0.0 || bc[2] != 0.0);
+            if (contact_force_sum && contact_force) for (int j = 0; j < NB * 3; ++j) contact_force_sum[j] += contact_force[j];
         }
     }
     if (ball_contact) memcpy(ball_contact, bc, sizeof(bc));

@@ -193,13 +193,14 @@ class PhysOracle:
         [nsim,13], racket-hit flag per simulate() [nsim], force on the ball from racket / ground in the last substep [2,3])."""
         cf, df, ids = np.zeros((NB, 3)), np.zeros(69), np.full(NB * 4, -1, dtype=np.int32)
         nsim = nsub // sub_per_sim
-        per_sim, hit, bc = np.zeros((nsim, 13)), np.zeros(nsim, dtype=np.int32), np.zeros(9)
+        per_sim, hit, bc, cfs = np.zeros((nsim, 13)), np.zeros(nsim, dtype=np.int32), np.zeros(9), np.zeros((NB, 3))
         tar = None if pd_target is None else np.ascontiguousarray(pd_target, dtype=np.float64)
         f = None if ext_force is None else np.ascontiguousarray(ext_force, dtype=np.float64)
         t = None if ext_torque is None else np.ascontiguousarray(ext_torque, dtype=np.float64)
         rc = self.lib.v2p_oracle_step_ball(C.byref(self.model), C.byref(self.params), C.byref(self.state), _dptr(tar), _dptr(f), _dptr(t), int(nsub), int(hold),
                                            int(sub_per_sim), _dptr(cf), _dptr(df), _iptr(ids), C.byref(self.ball_params), C.byref(self.ball),
-                                           C.c_double(self.spin_scale), _dptr(per_sim), _iptr(hit), _dptr(bc))
+                                           C.c_double(self.spin_scale), _dptr(per_sim), _iptr(hit), _dptr(bc), _dptr(cfs))
+        self.contact_force_sum = cfs  # net contact forces of the links summed over the simulate() calls of the step
         if rc:
             raise RuntimeError("oracle ball step failed (%d)" % rc)
         self.ball_body_force = bc[6:9].copy()  # force on the ball from the humanoid's links, last substep

@@ -17,6 +17,7 @@ def make_rb_task(n, lib, **env):
 
     env.setdefault("debug_contacts", 1)
     env.setdefault("body_shape_mismatch", "ignore")
+    env.setdefault("contact_forces_sum", True)
     cfg = default_cfg(n, motion_lib=lib, sample_first_motions=True, **env)
     return HumanoidSMPLIMRacketBall(cfg, device_type="cuda", device_id=0)
 
@@ -82,9 +83,24 @@ def _launch(task, rng, mode):
 def test_ball_step_matches_oracle(mlib, mode, lift, limits, player):
     """limits: with the joint ranges of the player MJCF's racket arm enforced (v2p_sim_cfg.joint_limits) - the wrist's limit rows, its
     hull points and the ball x racket rows then all belong to the same link.  player: the asset (nadal = left-handed: racket on L_Wrist)."""
+    _ball_step_vs_oracle(mlib, mode, lift, limits, player)
+
+
+@pytest.mark.parametrize("mode", ["hit", "body"])
+def test_ball_step_with_one_body_shape_per_clip(mlib, mode):
+    """racket + ball on per-clip body shapes (three differently scaled bodies, each with the racket folded into its wrist): every env
+    against the oracle of ITS shape"""
+    from vid2player3d_amd.model import load_baked_model
+
+    base = load_baked_model()
+    _ball_step_vs_oracle(mlib, mode, 0.0, True, "djokovic", shapes=[base.scaled(0.9), base, base.scaled(1.12)])
+
+
+def _ball_step_vs_oracle(mlib, mode, lift, limits, player, shapes=None):
     n = 32
     rng = np.random.default_rng({"flight": 1, "ground": 2, "hit": 3, "body": 4}[mode] + int(10 * lift))
-    task = make_rb_task(n, mlib, joint_limits=limits, player=player)
+    extra = {} if shapes is None else {"body_model": shapes, "motion_shape_ids": np.arange(8) % len(shapes)}
+    task = make_rb_task(n, mlib, joint_limits=limits, player=player, **extra)
     rl = task.racket_geometry["racket_link"]
     assert rl == (17 if player == "nadal" else 22)
     task.reset_with_times(None, T(rng.uniform(0.1, 1.0, size=n)))
@@ -101,6 +117,8 @@ def test_ball_step_matches_oracle(mlib, mode, lift, limits, player):
     bm = task.body_model
     oracles = []
     for e in range(n):
+        if shapes is not None:
+            bm = task.body_shapes[task._env_shape_ids[e]]
         o = PhysOracle(bm, default_params(joint_limits=int(limits)), kp=bm.kp.astype(np.float32), kd=bm.kd.astype(np.float32))
         o.set_state(root[e], dpos[e], dvel[e])
         o.attach_ball(task.racket_geometry)
@@ -120,12 +138,12 @@ def test_ball_step_matches_oracle(mlib, mode, lift, limits, player):
         task._physics_step()
         torch.cuda.synchronize()
         _, pd, _, force, torque = O.pre_physics(act, N(task.reset_buf), dpos_before, rb0[:, 0, 3:7], bm.kp.astype(np.float32))
-        per_sim, hit, bc, rbs, ids, cf, bbf = [], [], [], [], [], [], []
+        per_sim, hit, bc, rbs, ids, cf, bbf, cfs = [], [], [], [], [], [], [], []
         for e in range(n):
             oracles[e].set_ball(ball_before[e])
             c, _, i, ps, h, b = oracles[e].step_ball(pd_target=pd[e], ext_force=force[e], ext_torque=torque[e], nsub=4, hold=2, sub_per_sim=2)
-            per_sim.append(ps); hit.append(h); bc.append(b); rbs.append(oracles[e].get_state()[3]); ids.append(i); cf.append(c); bbf.append(oracles[e].ball_body_force)
-        per_sim, hit, bc, rbs, ids, cf, bbf = map(np.stack, (per_sim, hit, bc, rbs, ids, cf, bbf))
+            per_sim.append(ps); hit.append(h); bc.append(b); rbs.append(oracles[e].get_state()[3]); ids.append(i); cf.append(c); bbf.append(oracles[e].ball_body_force); cfs.append(oracles[e].contact_force_sum)
+        per_sim, hit, bc, rbs, ids, cf, bbf, cfs = map(np.stack, (per_sim, hit, bc, rbs, ids, cf, bbf, cfs))
         assert np.array_equal(N(task.debug_contacts()), ids), "hull contact vertices differ"
         got_ps = N(task._ball_states_per_sim)
         close(got_ps[..., 0:3], per_sim[..., 0:3], 2e-5, "%s ball pos (step %d)" % (mode, step))
@@ -145,6 +163,9 @@ def test_ball_step_matches_oracle(mlib, mode, lift, limits, player):
         close(rb[..., 0:3], rbs[..., 0:3], 2e-5, "rb pos")
         close(rb[..., 7:13], rbs[..., 7:13], 1e-3, "rb vel")
         close(N(task._contact_forces), cf, 2e-2, "net contact forces (the racket's link carries the reaction of the ball)")
+        close(N(task._contact_forces_sum), cfs, 2e-2, "_contact_forces_sum: net contact forces summed over the two simulate() calls")
+        if lift == 0.0:  # standing on the ground: the feet carry the weight in both simulate() calls
+            assert np.abs(cfs - cf).max() > 1.0, "the first simulate() call contributes"
         # the racket rigid body = the wrist frame moved by the weld offset
         Rw = Rotation.from_quat(rbs[:, rl, 3:7]).as_matrix()
         off = np.einsum("nij,j->ni", Rw, task.racket_geometry["racket_offset"])

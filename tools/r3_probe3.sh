@@ -1,7 +1,4 @@
 set -u
 O=gpurun_out; mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_physics.py tests/test_gpu_racket_ball.py -q -s 2>&1 > $O/t_rows_full.log
-grep "^\[rows\]\|^\[outliers\]\|passed\|failed\|Error\|assert" $O/t_rows_full.log > $O/t_rows.log
-tail -5 $O/t_rows_full.log | cut -c1-300; rm -f $O/t_rows_full.log
-grep -c "outliers" $O/t_rows.log
-timeout 600 python tools/limit_cost.py > $O/limit_cost.txt 2>&1; cat $O/limit_cost.txt
+timeout 900 python -m pytest tests/test_gpu_racket_ball.py tests/test_gpu_vec_task.py tests/test_gpu_ppo.py -q -x 2>&1 | grep -v "^E    .*array\|^E   .*where" | tail -30 | cut -c1-400
+for v in "--racket-ball" "--racket-ball --per-clip-shapes"; do echo "[$v] $(timeout 300 python bench.py --no-cpu-baseline $v 2>&1 | tail -1 | cut -c1-200)"; done

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libv2p_rollout.so")
 SOURCES = ["capi.hip", "motion_state.hip", "task_ops.hip", "physics.hip", "physics_ll.hip"]
-HEADERS = ["v2p_internal.hpp", "v2p_math.hpp", "v2p_math.inc", "phys_math.hpp", "phys_common.hpp", "motion_sample.hpp", "motion_sample.inc", "post_ops.inc", os.path.join("..", "..", "include", "v2p_rollout.h")]
+HEADERS = ["v2p_internal.hpp", "v2p_dev.hpp", "v2p_math.inc", "phys_math.hpp", "phys_common.hpp", "motion_sample.inc", "hull_gjk.hpp", "post_ops.inc", os.path.join("..", "..", "include", "v2p_rollout.h")]
 ARCH = "gfx950"
 
 

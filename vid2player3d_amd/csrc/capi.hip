@@ -445,6 +445,7 @@ void v2p_env_destroy(v2p_env* e) {
     if (e->job_progress) (void)hipFree(e->job_progress);
     if (e->job_hand) (void)hipFree(e->job_hand);
     delete e->ball;
+    if (e->err_host) { (void)hipHostFree(e->err_host); (void)hipEventDestroy(e->err_event); }
     profile_free(e);
     if (e->shapes_dev) (void)hipFree(e->shapes_dev);
     if (e->shape_aug_dev) (void)hipFree(e->shape_aug_dev);
@@ -536,6 +537,7 @@ int v2p_env_attach_ball(v2p_env* e, const v2p_ball_cfg* c, const v2p_ball_buffer
     d.body_contact = b->ball_body_contact;
     d.has_bounce = b->has_bounce; d.has_bounce_now = b->has_bounce_now; d.bounce_pos = b->bounce_pos;
     d.has_hit = b->has_racket_contact; d.has_hit_now = b->has_racket_contact_now;
+    d.contact_sum = b->contact_force_sum;
     if (e->pair_mix_default) e->pair_mix_permille = 0;
     return V2P_OK;
 }
@@ -552,6 +554,34 @@ int v2p_env_check(v2p_env* e, void* stream) {
         (void)hipMemset(word, 0, sizeof(flag));
         set_error("v2p_env_check: a substep job timed out waiting for its predecessor (workgroups were not dispatched in index order?)");
         return V2P_ERR_HIP;
+    }
+    return rc;
+}
+
+int v2p_env_check_async(v2p_env* e, void* stream) {
+    if (!e) { set_error("v2p_env_check_async: bad argument"); return V2P_ERR_INVALID; }
+    if (!e->job_progress) return V2P_OK;
+    DeviceGuard g(e->device);
+    int rc = V2P_OK;
+    if (!e->err_host) {
+        rc = check_hip(hipHostMalloc((void**)&e->err_host, sizeof(int32_t), hipHostMallocDefault), "hipHostMalloc(error word)");
+        if (rc == V2P_OK) rc = check_hip(hipEventCreateWithFlags(&e->err_event, hipEventDisableTiming), "hipEventCreate(error word)");
+        if (rc != V2P_OK) return rc;
+        *e->err_host = 0;
+    } else if (e->err_pending && hipEventQuery(e->err_event) == hipSuccess) {
+        e->err_pending = 0;
+        if (*e->err_host) {
+            *e->err_host = 0;
+            (void)hipMemsetAsync(e->job_progress + v2p::job_wave_slots(e->n), 0, sizeof(int32_t), (hipStream_t)stream);
+            set_error("v2p_env_check_async: a substep job timed out waiting for its predecessor in an earlier step (its results are invalid)");
+            return V2P_ERR_HIP;
+        }
+    }
+    if (!e->err_pending) {  // fetch the word as it stands behind everything enqueued so far; looked at by the next call
+        rc = check_hip(hipMemcpyAsync(e->err_host, e->job_progress + v2p::job_wave_slots(e->n), sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream),
+                       "hipMemcpyAsync(job error word)");
+        if (rc == V2P_OK) rc = check_hip(hipEventRecord(e->err_event, (hipStream_t)stream), "hipEventRecord(error word)");
+        if (rc == V2P_OK) e->err_pending = 1;
     }
     return rc;
 }

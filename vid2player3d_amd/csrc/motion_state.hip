@@ -1,7 +1,7 @@
 // Stand-alone reference-motion sampler kernel: MotionLib.get_motion_state
 // (embodied_pose/utils/motion_lib.py:164-266).  HBM-bound gather: per query 2 x 1356 B of
 // table rows in, 1324 B out; one thread per (query, body).
-#include "motion_sample.hpp"
+#include "v2p_dev.hpp"
 
 namespace v2p {
 

@@ -33,6 +33,7 @@ struct BallDev {
     float* body_contact;   // [N,3] or NULL: force on the ball from the humanoid's links, last substep
     uint8_t *has_bounce, *has_bounce_now, *has_hit, *has_hit_now;  // the reference's flags (all or none)
     float* bounce_pos;     // [N,3]
+    float* contact_sum;    // [N,24,3] or NULL: net contact forces of the links summed over the simulate() calls of the control step
 };
 
 // post-physics fused into the physics launch (v2p_env_step, link-per-lane schedule): what env_post_kernel takes

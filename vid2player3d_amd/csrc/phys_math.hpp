@@ -1,6 +1,6 @@
 // Small dense-matrix helpers shared by the physics kernels (registers only: every index is a compile-time constant).
 #pragma once
-#include "v2p_math.hpp"
+#include "v2p_dev.hpp"
 
 namespace v2p {
 

@@ -29,7 +29,7 @@
 #include <stdlib.h>
 
 #include "v2p_internal.hpp"
-#include "v2p_math.hpp"
+#include "v2p_dev.hpp"
 #include "phys_common.hpp"
 
 namespace v2p {

@@ -1993,12 +1993,16 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                     if (BP.body_contact) { float* ob = BP.body_contact + e * 3; ob[0] = fbd.x; ob[1] = fbd.y; ob[2] = fbd.z; }
                 }
             }
-            if (last && valid && live_env && !frozen) {  // the reaction on the touched link enters its net contact force below
+            if ((last || (BP.contact_sum && sub % BP.sub_per_sim == BP.sub_per_sim - 1)) && valid && live_env && !frozen) {
+                // the reaction on the touched link enters its net contact force below
                 const V3 fr = mask(lb == BP.racket_link, frk) + mask(lb == hl, fbd);
                 park[PARK_W0 * 64] = fr.x; park[(PARK_W0 + 1) * 64] = fr.y; park[(PARK_W0 + 2) * 64] = fr.z;
             }
         }
-        if (last && valid && live_env && !frozen) {
+        // (racket + ball, opt-in: `_contact_forces_sum`, the net contact forces summed over the simulate() calls of a control step,
+        // humanoid_smpl_im_mvae.py:781 - what refresh_net_contact_force_tensor shows after EVERY call is needed then, not only after the last)
+        const bool sum_now = BALL && BP.contact_sum && sub % BP.sub_per_sim == BP.sub_per_sim - 1;
+        if ((last || sum_now) && valid && live_env && !frozen) {
             // net contact force per body = sum of impulses / h  (refresh_net_contact_force_tensor)
             V3 cforce{0.f, 0.f, 0.f};
             if (CONTACT) {
@@ -2008,8 +2012,17 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                     if (c < cnt) { const V3 lc = CS.lam(c); cforce.z += lc.x * ih; cforce.x += lc.y * ih; cforce.y += lc.z * ih; }
                 if (BALL) cforce = cforce - park_get3(PARK_W0);
             }
-            float* oc = a.x_contact + (env_here() * NB + b) * 3;
-            oc[0] = cforce.x; oc[1] = cforce.y; oc[2] = cforce.z;
+            if (last) {
+                float* oc = a.x_contact + (env_here() * NB + b) * 3;
+                oc[0] = cforce.x; oc[1] = cforce.y; oc[2] = cforce.z;
+            }
+            if (sum_now) {  // (system-scope accesses: the calls of one step may run in different workgroups)
+                float* os = BP.contact_sum + (env_here() * NB + b) * 3;
+                const bool first = sub < BP.sub_per_sim;
+                cstore(os, (first ? 0.f : cload(os)) + cforce.x);
+                cstore(os + 1, (first ? 0.f : cload(os + 1)) + cforce.y);
+                cstore(os + 2, (first ? 0.f : cload(os + 2)) + cforce.z);
+            }
         }
     }
 

@@ -5,7 +5,7 @@
 // reduction over the 24 bodies of an env where the reference takes means.
 #include <math.h>
 
-#include "motion_sample.hpp"
+#include "v2p_dev.hpp"
 #include "phys_common.hpp"
 
 namespace v2p {

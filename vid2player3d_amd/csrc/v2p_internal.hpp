@@ -151,6 +151,9 @@ struct v2p_env {
     int pair_mix_default;     // pair_mix_permille was left to the engine (-1)
     int job_mono_permille;    // share of the env pairs (the heaviest) whose substeps stay in one workgroup
     v2p::BallDev* ball;       // racket + ball attached (v2p_env_attach_ball), else NULL
+    int32_t* err_host;        // pinned copy of the substep jobs' error word (v2p_env_check_async), lazily allocated
+    hipEvent_t err_event;
+    int err_pending;
     hipEvent_t* prof_ev;      // 2 events per measured physics launch (v2p_env_profile_begin), else NULL
     int64_t prof_cap, prof_n;
     int pair_have;            // the last physics launch left (key, pos, start) that have not been scattered into perm yet

@@ -10,6 +10,7 @@ the task logic stays the imitation task's (`HumanoidSMPLIM`).  Exposed like the 
     _racket_rb_state  [N,13]     rigid body 24
     _ball_states_per_sim [N,2,13], _racket_ball_contact_per_sim [N,2]   what the reference sees after each of the 2 simulate() calls
     _has_bounce / _has_bounce_now / _bounce_pos, _has_racket_ball_contact(_now)   the flags of :731-737 and :773-779, same rules
+    _contact_forces_sum [N,24,3]  net contact forces summed over the simulate() calls of a control step (:781)
 """
 import ctypes as C
 
@@ -30,14 +31,22 @@ class HumanoidSMPLIMRacketBall(HumanoidSMPLIM):
         env = cfg["env"] = dict(cfg["env"])
         base = env.get("body_model") or load_baked_model(default_humanoid_mass=env.get("default_humanoid_mass", 90.0), kp_scale=env.get("kp_scale", 1.0),
                                                          kd_scale=env.get("kd_scale", env.get("kp_scale", 1.0)))
-        if isinstance(base, (list, tuple)):
-            raise NotImplementedError("racket + ball with per-clip body shapes is not built")
+        if env.get("has_racket_collision", False):
+            # (humanoid_smpl_im_mvae.py:42, 397-401: racket shapes with collision filter 0 = the racket collides with the links of its own
+            # humanoid; default False in every config)
+            raise NotImplementedError("has_racket_collision=True (racket x link contacts) is not built; the reference default is False")
         # the player asset: djokovic / federer (right hand) or nadal (left hand); cfg_v2p righthand = False selects the left-handed one
         # like the reference (humanoid_smpl_im_mvae.py:73-78).  The exposed rigid-body order is the canonical one either way (racket =
         # rigid body 24: the reference permutes the left-handed asset's tensor into it, :67, 197-201).
         v2p = dict(cfg.get("v2p") or {})
         player = env.get("player", "djokovic" if v2p.get("righthand", True) else "nadal")
-        model, self.racket_geometry = racket.with_racket(base, player=player)
+        if isinstance(base, (list, tuple)):
+            # one body shape per clip: the racket is the same object in every hand - welded at the same offset of the wrist frame - so
+            # every shape gets it folded in, and the ball's cylinders (given in the wrist frame) are shared
+            folded = [racket.with_racket(b, player=player) for b in base]
+            model, self.racket_geometry = [m for m, _ in folded], folded[0][1]
+        else:
+            model, self.racket_geometry = racket.with_racket(base, player=player)
         env["body_model"] = model
         # the player MJCF's racket-arm ranges (R_Wrist +-10 / +-45 / +-90 deg, R_Elbow_x <= 90 deg) are enforced like Isaac Gym does
         env.setdefault("joint_limits", True)
@@ -54,6 +63,9 @@ class HumanoidSMPLIMRacketBall(HumanoidSMPLIM):
         self._racket_ball_contact_per_sim = torch.zeros((n, nsim), dtype=torch.int32, device=dev)
         self._ball_contact_forces = torch.zeros((n, 2, 3), **f)
         self._ball_body_contact_force = torch.zeros((n, 3), **f)  # on the ball from the humanoid's links (ball x hull contacts)
+        # `_contact_forces_sum` (:186, 690, 781): net contact forces of the links after each simulate() call, summed over the control step
+        # (opt-in, cfg env contact_forces_sum: nothing in the reference reads it, and keeping it costs the launch 2 %)
+        self._contact_forces_sum = torch.zeros((n, 24, 3), **f) if env.get("contact_forces_sum", False) else None
         self._has_bounce = torch.zeros(n, dtype=torch.bool, device=dev)
         self._has_bounce_now = torch.zeros(n, dtype=torch.bool, device=dev)
         self._bounce_pos = torch.zeros((n, 3), **f)
@@ -81,7 +93,8 @@ class HumanoidSMPLIMRacketBall(HumanoidSMPLIM):
                              ball_per_sim=self._ball_states_per_sim.data_ptr(), racket_hit_per_sim=self._racket_ball_contact_per_sim.data_ptr(),
                              ball_contact=self._ball_contact_forces.data_ptr(), ball_body_contact=self._ball_body_contact_force.data_ptr(),
                              has_bounce=self._has_bounce.data_ptr(), has_bounce_now=self._has_bounce_now.data_ptr(), bounce_pos=self._bounce_pos.data_ptr(),
-                             has_racket_contact=self._has_racket_ball_contact.data_ptr(), has_racket_contact_now=self._has_racket_ball_contact_now.data_ptr())
+                             has_racket_contact=self._has_racket_ball_contact.data_ptr(), has_racket_contact_now=self._has_racket_ball_contact_now.data_ptr(),
+                             contact_force_sum=None if self._contact_forces_sum is None else self._contact_forces_sum.data_ptr())
         _lib.check(self._lib.v2p_env_attach_ball(self._h_env, C.byref(c), C.byref(b)), "v2p_env_attach_ball")
         self.ball_material = mat
 

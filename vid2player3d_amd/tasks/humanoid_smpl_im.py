@@ -515,6 +515,8 @@ class HumanoidSMPLIM:
     def reset(self, env_ids=None):
         """HumanoidSMPL.reset (humanoid_smpl.py:136-159) with reference-state init."""
         if env_ids is None:
+            # once per epoch: a substep job that timed out in an earlier step (its results are then invalid) raises here, without a wait
+            _lib.check(self._lib.v2p_env_check_async(self._h_env, self._stream()), "v2p_env_check_async")
             n = self.num_envs
             ids_t, motion_ids = None, self._reset_ref_motion_ids
         else:
