@@ -343,13 +343,16 @@ int v2p_env_attach_ball(v2p_env* e, const v2p_ball_cfg* cfg, const v2p_ball_buff
 int v2p_env_profile_begin(v2p_env* e, int64_t max_launches);
 int v2p_env_profile_end(v2p_env* e, double* physics_ms_total, int64_t* launches);
 
-/* synchronises the stream and reports errors detected on the device since the last check (a substep job that waited too long for
- * its predecessor: V2P_ERR_HIP).  Cheap enough for once per epoch; not needed for correctness of normal runs. */
+/* Substep jobs: a job whose predecessor (the previous substep of its env pair, another workgroup of the launch) does not show up within
+ * ~20 ms stops waiting and recomputes the pair's earlier substeps itself - results and progress do not depend on the order in which the
+ * hardware dispatches workgroups, only time is lost.  Every such recovery is counted on the device (it should never happen: jobs are
+ * numbered the way workgroups are dispatched).  v2p_env_check synchronises `stream` and fetches the counter; v2p_env_check_async (ABI 9)
+ * enqueues the fetch behind the work already on `stream` and picks up what the previous call's fetch brought back, without waiting (one
+ * call per epoch: HumanoidSMPLIM.reset of all envs makes it); v2p_env_job_recoveries returns the count as last fetched (total since
+ * the batch was created). */
 int v2p_env_check(v2p_env* e, void* stream);
-/* the same without waiting (ABI 9): enqueues a copy of the error word behind the work already on `stream` and reports what the PREVIOUS
- * call's copy has brought back, if it has arrived.  One call per epoch (HumanoidSMPLIM.reset of all envs makes it) surfaces a timed-out
- * job one epoch late at no cost to the rollout. */
 int v2p_env_check_async(v2p_env* e, void* stream);
+int v2p_env_job_recoveries(v2p_env* e, int64_t* count);
 
 const char* v2p_last_error(void);
 int v2p_abi_version(void);

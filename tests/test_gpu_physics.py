@@ -338,6 +338,42 @@ def test_substep_jobs_are_invisible(mlib, n):
             assert np.array_equal(x, y), "step %d, tensor %d: %d of %d values differ (max %.3e)" % (k, j, int((x != y).sum()), x.size, float(np.abs(x.astype(np.float64) - y).max()))
 
 
+def test_a_job_that_gives_up_waiting_recomputes_and_changes_nothing(mlib, monkeypatch):
+    """Forward progress of the substep jobs must not rest on the dispatch order.  With the time-out set to zero polls every job whose
+    predecessor has not finished at its first look gives up at once and recomputes the pair's earlier substeps itself, while the
+    predecessor still runs (and later rewrites the same values): results stay bit-identical to whole control steps per workgroup, with
+    and without the ball (whose per-call flags and accumulators must not be touched by a replay)."""
+    import warnings
+
+    n = 4096
+    outs = []
+    for jobs, spins in ((False, None), (True, "0")):
+        if spins is not None:
+            monkeypatch.setenv("V2P_JOB_TIMEOUT_SPINS", spins)
+        task = make_task(n, mlib, substep_jobs=jobs)
+        g = torch.Generator(device=DEV)
+        g.manual_seed(29)
+        task.reset_with_times(None, torch.rand(n, device=DEV, generator=g) * 0.8)
+        snaps = []
+        for k in range(8):
+            a = torch.cat([task._target_dof_pos + 0.4 * torch.randn((n, 69), device=DEV, generator=g), 0.3 * torch.randn((n, 6), device=DEV, generator=g)], dim=1).contiguous()
+            task.step(a)
+            snaps.append([N(task._rigid_body_state).copy(), N(task._dof_state).copy(), N(task._contact_forces).copy(), N(task.rew_buf).copy(), N(task.reset_buf).copy(),
+                          N(task.obs_buf).copy()])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            task.check()
+        if jobs:
+            assert task.job_recoveries() > 100, "the fixture must exercise the recovery path (%d)" % task.job_recoveries()
+        else:
+            assert task.job_recoveries() == 0
+        outs.append(snaps)
+        task.close()
+    for k, (sa, sb) in enumerate(zip(*outs)):
+        for j, (x, y) in enumerate(zip(sa, sb)):
+            assert np.array_equal(x, y), "step %d, tensor %d: %d of %d values differ (max %.3e)" % (k, j, int((x != y).sum()), x.size, float(np.abs(x.astype(np.float64) - y).max()))
+
+
 def test_substep_jobs_with_twelve_substeps_per_control_step(mlib):
     """sim.substeps 6 x controlFrequencyInv 2 = 12 substeps per control step (vid2player's controller configs,
     vid2player/cfg/*.yaml `substeps: 6`): the progress word of a pair counts launch x (nsub + 1) + substep, so the hand-overs of one

@@ -204,12 +204,18 @@ def test_bounce_and_hit_flags(mlib):
     task.close()
 
 
-@pytest.mark.parametrize("n", [3, 2048])
-def test_substep_jobs_are_invisible_with_ball(mlib, n):
+@pytest.mark.parametrize("n,timeout_spins", [(3, None), (2048, None), (2048, "0")])
+def test_substep_jobs_are_invisible_with_ball(mlib, n, timeout_spins, monkeypatch):
     """Racket + ball + joint limits through substep jobs (the ball's state and its aerodynamic force are handed over with the
-    humanoid's; the flags are kept through system-scope accesses): bit-identical to one workgroup per env pair, step after step."""
+    humanoid's; the flags are kept through system-scope accesses): bit-identical to one workgroup per env pair, step after step.
+    timeout_spins "0": every job whose predecessor is not done at its first look recomputes the earlier substeps itself (the recovery
+    path: the replayed substeps must leave the per-call flags and the force accumulator alone)."""
+    import warnings
+
     outs = []
     for jobs in (False, True):
+        if jobs and timeout_spins is not None:
+            monkeypatch.setenv("V2P_JOB_TIMEOUT_SPINS", timeout_spins)
         task = make_rb_task(n, mlib, substep_jobs=jobs, debug_contacts=0)
         g = torch.Generator(device=DEV)
         g.manual_seed(23)
@@ -227,8 +233,12 @@ def test_substep_jobs_are_invisible_with_ball(mlib, n):
             snaps.append([N(task._rigid_body_state).copy(), N(task._ball_root_states).copy(), N(task._ball_states_per_sim).copy(), N(task._contact_forces).copy(),
                           N(task._ball_contact_forces).copy(), N(task._ball_body_contact_force).copy(), N(task._racket_ball_contact_per_sim).copy(),
                           N(task._has_bounce).copy(), N(task._has_bounce_now).copy(), N(task._bounce_pos).copy(), N(task._has_racket_ball_contact).copy(),
-                          N(task.rew_buf).copy(), N(task.reset_buf).copy()])
-        task.check()
+                          N(task.rew_buf).copy(), N(task.reset_buf).copy(), N(task._contact_forces_sum).copy(), N(task._has_racket_ball_contact_now).copy()])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            task.check()
+        if jobs and timeout_spins is not None:
+            assert task.job_recoveries() > 100, task.job_recoveries()
         outs.append(snaps)
         task.close()
     if n > 100:

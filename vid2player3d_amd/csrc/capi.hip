@@ -386,7 +386,9 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
         rc = check_hip(hipMalloc((void**)&e->job_progress, sizeof(int32_t) * words), "hipMalloc(job_progress)");
         if (rc == V2P_OK) rc = check_hip(hipMemset(e->job_progress, 0, sizeof(int32_t) * words), "hipMemset(job_progress)");
         // the state as the jobs hand it over: 50 16-byte chunks per env (see physics_ll.hip)
-        if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->job_hand, sizeof(float) * HAND_FLOATS * N), "hipMalloc(job_hand)");
+        if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->job_hand, sizeof(float) * HAND_FLOATS * N * (size_t)(p.nsub > 1 ? p.nsub - 1 : 1)), "hipMalloc(job_hand)");
+        // ~20 ms: far beyond the longest chain of substeps of a launch.  (V2P_JOB_TIMEOUT_SPINS: tests force the recovery path with 0)
+        e->job_timeout_spins = getenv("V2P_JOB_TIMEOUT_SPINS") ? atol(getenv("V2P_JOB_TIMEOUT_SPINS")) : 50000l;
     }
     if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->pair_key, sizeof(int32_t) * N), "hipMalloc(pair_key)");
     if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->pair_pos, sizeof(int32_t) * N), "hipMalloc(pair_pos)");
@@ -547,14 +549,9 @@ int v2p_env_check(v2p_env* e, void* stream) {
     DeviceGuard g(e->device);
     int rc = check_hip(hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize");
     if (rc != V2P_OK || !e->job_progress) return rc;
-    int32_t flag = 0;
-    int32_t* word = e->job_progress + v2p::job_wave_slots(e->n);
-    rc = check_hip(hipMemcpy(&flag, word, sizeof(flag), hipMemcpyDeviceToHost), "hipMemcpy(job error word)");
-    if (rc == V2P_OK && flag) {
-        (void)hipMemset(word, 0, sizeof(flag));
-        set_error("v2p_env_check: a substep job timed out waiting for its predecessor (workgroups were not dispatched in index order?)");
-        return V2P_ERR_HIP;
-    }
+    int32_t count = 0;
+    rc = check_hip(hipMemcpy(&count, e->job_progress + v2p::job_wave_slots(e->n), sizeof(count), hipMemcpyDeviceToHost), "hipMemcpy(job recovery counter)");
+    if (rc == V2P_OK) e->job_recoveries = count;
     return rc;
 }
 
@@ -564,26 +561,27 @@ int v2p_env_check_async(v2p_env* e, void* stream) {
     DeviceGuard g(e->device);
     int rc = V2P_OK;
     if (!e->err_host) {
-        rc = check_hip(hipHostMalloc((void**)&e->err_host, sizeof(int32_t), hipHostMallocDefault), "hipHostMalloc(error word)");
-        if (rc == V2P_OK) rc = check_hip(hipEventCreateWithFlags(&e->err_event, hipEventDisableTiming), "hipEventCreate(error word)");
+        rc = check_hip(hipHostMalloc((void**)&e->err_host, sizeof(int32_t), hipHostMallocDefault), "hipHostMalloc(job recovery counter)");
+        if (rc == V2P_OK) rc = check_hip(hipEventCreateWithFlags(&e->err_event, hipEventDisableTiming), "hipEventCreate(job recovery counter)");
         if (rc != V2P_OK) return rc;
         *e->err_host = 0;
     } else if (e->err_pending && hipEventQuery(e->err_event) == hipSuccess) {
         e->err_pending = 0;
-        if (*e->err_host) {
-            *e->err_host = 0;
-            (void)hipMemsetAsync(e->job_progress + v2p::job_wave_slots(e->n), 0, sizeof(int32_t), (hipStream_t)stream);
-            set_error("v2p_env_check_async: a substep job timed out waiting for its predecessor in an earlier step (its results are invalid)");
-            return V2P_ERR_HIP;
-        }
+        e->job_recoveries = *e->err_host;
     }
-    if (!e->err_pending) {  // fetch the word as it stands behind everything enqueued so far; looked at by the next call
+    if (!e->err_pending) {  // fetch the counter as it stands behind everything enqueued so far; looked at by the next call
         rc = check_hip(hipMemcpyAsync(e->err_host, e->job_progress + v2p::job_wave_slots(e->n), sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream),
-                       "hipMemcpyAsync(job error word)");
-        if (rc == V2P_OK) rc = check_hip(hipEventRecord(e->err_event, (hipStream_t)stream), "hipEventRecord(error word)");
+                       "hipMemcpyAsync(job recovery counter)");
+        if (rc == V2P_OK) rc = check_hip(hipEventRecord(e->err_event, (hipStream_t)stream), "hipEventRecord(job recovery counter)");
         if (rc == V2P_OK) e->err_pending = 1;
     }
     return rc;
+}
+
+int v2p_env_job_recoveries(v2p_env* e, int64_t* count) {
+    if (!e || !count) { set_error("v2p_env_job_recoveries: bad argument"); return V2P_ERR_INVALID; }
+    *count = e->job_recoveries;
+    return V2P_OK;
 }
 
 static void profile_free(v2p_env* e) {

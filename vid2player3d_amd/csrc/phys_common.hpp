@@ -89,7 +89,8 @@ struct PhysArgs {
     // substep jobs (physics_ll.hip JOBS): workgroups per substep, progress word per wave slot (+1 error word), epoch of this launch
     int32_t job_blocks, job_epoch, job_mono;
     int32_t* job_progress;
-    float* job_hand;  // [N][HAND_FLOATS] state hand-off between the substep jobs of an env pair
+    float* job_hand;  // [nsub - 1][N][HAND_FLOATS] state hand-off between the substep jobs of an env pair: slot s = the state after substep s
+    long job_timeout_spins;  // polls (of ~0.4 us) after which a job stops waiting for its predecessor and recomputes the earlier substeps
     PostArgs post;
 };
 

@@ -297,8 +297,11 @@ struct ContactStore<true> {
 // JOBS: one launch = substeps x waves JOBS.  Job (s, p) runs substep s of wave p's env pair and hands the state over to job (s+1, p)
 // through global memory (system-scope stores / loads + a progress word per pair).  With whole control steps as jobs, 8192 envs are
 // 4096 indivisible jobs of 0.14-0.65 ms on 2048-3072 wave slots and the launch is as long as its worst slot (82 % utilisation,
-// profiles/r02*_wave_times.txt); quarter-size jobs pack 4x finer.  Jobs are dispatched in index order (substep-major, heavy pairs
-// first), so a job only ever waits for one that was dispatched before it.
+// profiles/r02*_wave_times.txt); quarter-size jobs pack 4x finer.  Jobs are numbered (and, as observed, dispatched) substep-major,
+// heavy pairs first, so a job normally waits for one that started before it; a job whose predecessor does not show up within the
+// time-out RECOMPUTES the pair's earlier substeps itself (see the wait), so neither progress nor results depend on the dispatch order.
+// (Numbering the jobs by tickets drawn from an atomic counter as the workgroups start - progress by construction - measured -13 %:
+// 13 k atomics on one address per launch.)
 // LIMITS: joint-limit rows (v2p_sim_cfg.joint_limits; the model is stated in oracle/phys/v2p_phys_oracle.c).  A DOF whose range is
 // narrower than a full turn carries one row against its nearer limit; the rows of joint b form their own block update right before
 // the contact block of link b.  A limit impulse is a joint-space impulse: it enters the propagation as the link's `un`, and its
@@ -317,35 +320,43 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
     // JOBS: the first job_mono workgroups run ALL substeps of the job_mono heaviest env pairs (their chain of substeps is the critical
     // path of the launch: it starts at once and never waits); the other pairs are cut into one job per substep, substep-major
     const int nblk = JOBS ? a.job_blocks : (int)gridDim.x;                 // env pairs (wave slots) of the launch
-    const bool mono = !JOBS || (int)blockIdx.x < a.job_mono;
+    const int jid = (int)blockIdx.x;  // jobs are numbered substep-major, heavy pairs first
+    const bool mono = !JOBS || jid < a.job_mono;
     const int jcut = JOBS && nblk > a.job_mono ? nblk - a.job_mono : 1;     // pairs that are cut into substep jobs
-    const int jrel = JOBS ? (int)blockIdx.x - a.job_mono : 0;
+    const int jrel = JOBS ? jid - a.job_mono : 0;
     const int sjob = mono ? 0 : jrel / jcut;                               // the substep this job runs
-    const int bid = mono ? (int)blockIdx.x : a.job_mono + jrel % jcut;
+    const int bid = mono ? jid : a.job_mono + jrel % jcut;
     const int64_t slot = ((int64_t)bid * LL_WPB + (threadIdx.x >> 6)) * 2 + half;
     const bool live_env = slot < N;
     const bool first_job = mono || sjob == 0, last_job = mono || sjob == a.p.nsub - 1;
-    const bool handed = !mono && sjob > 0;  // the inputs of this job were written by another workgroup of this launch
+    // the inputs of this job were written by another workgroup of this launch - unless that one did not show up in time (below)
+    bool handed = !mono && sjob > 0;
     int* const progress = JOBS ? a.job_progress + (bid * LL_WPB + (threadIdx.x >> 6)) : nullptr;
     if constexpr (JOBS) if (handed) {
-        // wait for the previous substep of this env pair (dispatched before this job: it is running or done)
+        // wait for the previous substep of this env pair
         // progress word of a pair = launch number x (nsub + 1) + substeps handed over: the last hand-over of launch E stores
         // E (nsub + 1) + nsub - 1, below every value a job of launch E + 1 waits for, whatever nsub is (vid2player's controller
         // configs run substeps 6 x controlFrequencyInv 2 = 12 per control step)
         const int want = a.job_epoch * (a.p.nsub + 1) + sjob;
+        int ok = 1;
         if (lane == 0) {
-            int* const errword = a.job_progress + a.job_blocks * LL_WPB;
             long spins = 0;
             while (__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
-                __builtin_amdgcn_s_sleep(16);
-                ++spins;
-                // ~0.25 s without progress, or another job has already given up: report (v2p_env_check) instead of hanging the GPU
-                if (spins > 500000l || ((spins & 1023) == 0 && __hip_atomic_load(errword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)) {
-                    __hip_atomic_store(errword, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (spins >= a.job_timeout_spins) {
+                    // The predecessor is late beyond reason (jobs are dispatched in index order as far as observed, but nothing promises
+                    // it).  This job then runs the pair's EARLIER substeps itself, from the inputs of the step, before its own: every job
+                    // of a pair computes the same bits whoever runs it, the hand-over slots are per substep, and the replayed substeps
+                    // publish nothing - so the late predecessor, when it does run, rewrites identical values and nothing else changes.
+                    // Progress and results are independent of the dispatch order; only time is lost (counted: v2p_env_job_recoveries).
+                    ok = 0;
+                    __hip_atomic_fetch_add(a.job_progress + a.job_blocks * LL_WPB, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     break;
                 }
+                __builtin_amdgcn_s_sleep(16);
+                ++spins;
             }
         }
+        handed = __builtin_amdgcn_readfirstlane(ok) != 0;
         __builtin_amdgcn_wave_barrier();
     }
     int64_t e = live_env ? slot : N - 1;
@@ -430,7 +441,7 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
         else if (kmax >= 40) __builtin_amdgcn_s_setprio(1);
     }
 #endif
-    const int sub0 = mono ? 0 : sjob, sub1 = mono ? nsub : (nsub ? sjob + 1 : 0);  // substeps of this job
+    const int sub0 = handed ? sjob : 0, sub1 = mono ? nsub : (nsub ? sjob + 1 : 0);  // substeps of this job (a job that gave up waiting replays 0 .. sjob - 1)
     auto ldin = [&](const float* p) -> float { return handed ? cload(p) : *p; };
 
     // ---- state: the root lane carries the root pose/velocity, every other lane its joint
@@ -438,7 +449,8 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
     V3 x{0.f, 0.f, 0.f}, w{0.f, 0.f, 0.f}, xd{0.f, 0.f, 0.f}, wt{0.f, 0.f, 0.f}, tar{0.f, 0.f, 0.f};
     // (JOBS: the job of an env's first substep reads the engine's state, the others what the job before them handed over: 16-byte chunks,
     // chunk 2b, 2b+1 = joint b (quaternion | rate), chunks 0, 1, 48, 49 = the root (quat | pos, vx | vy, vz, wx, wy | wz))
-    float* const hand = JOBS ? a.job_hand + e * HAND_FLOATS : nullptr;
+    // (one hand-over slot per substep: slot s holds the state after substep s)
+    float* const hand = JOBS && handed ? a.job_hand + ((int64_t)(sjob - 1) * N + e) * HAND_FLOATS : nullptr;
     bool got = false;
     if constexpr (JOBS) if (handed) {
         f4 c0, c1;
@@ -469,24 +481,32 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
             jq = Q4{st[SIDX(jb + 0)], st[SIDX(jb + 1)], st[SIDX(jb + 2)], st[SIDX(jb + 3)]};
             wt = V3{st[SIDX(vb + 0)], st[SIDX(vb + 1)], st[SIDX(vb + 2)]};
         }
-        if (!a.actions || handed) tar = V3{ldin(&a.ctrl[CIDX(cb + 0)]), ldin(&a.ctrl[CIDX(cb + 1)]), ldin(&a.ctrl[CIDX(cb + 2)])};
+        if (!a.actions) tar = V3{ldin(&a.ctrl[CIDX(cb + 0)]), ldin(&a.ctrl[CIDX(cb + 1)]), ldin(&a.ctrl[CIDX(cb + 2)])};
     }
-    auto stctl = [&](float* p, float v) { if (!mono) cstore(p, v); else *p = v; };  // ctrl is read by the later jobs of the pair
-    if (a.actions && valid && live_env && first_job) {
+    // the residual root wrench of the fused step: lanes 0 (force) and 25 (torque) of the env keep it in the PARK_TAR slots of their LDS columns
+    // (neither has a joint target)
+    float* const wrench_park = park_all + (threadIdx.x >> 6) * LDS_FLOATS_PER_WAVE + base;
+    if (a.actions && valid && live_env) {
         // ---- pre-physics fused in (same functions, same rounding as env_pre_kernel below): lane b owns the three action components of
-        // its joint, the root lane the residual wrench; dead envs are masked in place on the caller's tensor
+        // its joint, the root lane the residual wrench; dead envs are masked in place on the caller's tensor.  EVERY job of the env derives
+        // the PD targets and the wrench itself - from the caller's actions and the exposed state of the start of the step, which nothing
+        // overwrites before the env's last job has read them - instead of having the first job hand them over through `ctrl`: 75 dword
+        // write-through stores per env, each its own fabric write (PMC: WRITE_SIZE)
         const bool dead = a.reset[e] == 1;
         if (b != 0) {
             float* ap = a.actions + e * NACT + 3 * (b - 1);
             float ax = ap[0], ay = ap[1], az = ap[2];
-            if (dead) { ax = ay = az = 0.f; ap[0] = 0.f; ap[1] = 0.f; ap[2] = 0.f; }
+            if (dead) {
+                ax = ay = az = 0.f;
+                if (first_job) { ap[0] = 0.f; ap[1] = 0.f; ap[2] = 0.f; }
+            }
             const float* qd = a.x_dof + (e * NDOF + 3 * (b - 1)) * 2;
             const float lim = P.pd_tar_lim;
             tar = V3{strict::pd_clamp(ax, qd[0], lim), strict::pd_clamp(ay, qd[2], lim), strict::pd_clamp(az, qd[4], lim)};
-            float* pt = a.pd_target + e * NDOF + 3 * (b - 1);
-            pt[0] = tar.x; pt[1] = tar.y; pt[2] = tar.z;
-            const int cb = CT_PD + 3 * (b - 1);
-            stctl(&a.ctrl[CIDX(cb + 0)], tar.x); stctl(&a.ctrl[CIDX(cb + 1)], tar.y); stctl(&a.ctrl[CIDX(cb + 2)], tar.z);
+            if (first_job) {
+                float* pt = a.pd_target + e * NDOF + 3 * (b - 1);
+                pt[0] = tar.x; pt[1] = tar.y; pt[2] = tar.z;
+            }
         } else {
             float* ap = a.actions + e * NACT + NDOF;
             float af[6];
@@ -494,17 +514,19 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
             for (int k = 0; k < 6; ++k) af[k] = ap[k];
             if (dead) {
 #pragma unroll
-                for (int k = 0; k < 6; ++k) { af[k] = 0.f; ap[k] = 0.f; }
+                for (int k = 0; k < 6; ++k) { af[k] = 0.f; if (first_job) ap[k] = 0.f; }
             }
-            const float* rq4 = a.x_rb + e * NB * 13 + 3;
-            const strict::V3 F = strict::residual_wrench(rq4, af[0], af[1], af[2], P.res_force_scale);
-            const strict::V3 Tq = strict::residual_wrench(rq4, af[3], af[4], af[5], P.res_torque_scale);
-            stctl(&a.ctrl[CIDX(CT_FORCE + 0)], F.x); stctl(&a.ctrl[CIDX(CT_FORCE + 1)], F.y); stctl(&a.ctrl[CIDX(CT_FORCE + 2)], F.z);
-            stctl(&a.ctrl[CIDX(CT_TORQUE + 0)], Tq.x); stctl(&a.ctrl[CIDX(CT_TORQUE + 1)], Tq.y); stctl(&a.ctrl[CIDX(CT_TORQUE + 2)], Tq.z);
+            if (sub0 < P.hold_sub) {  // (a job past the substeps that hold the wrench has no use for it)
+                const float* rq4 = a.x_rb + e * NB * 13 + 3;
+                const strict::V3 F = strict::residual_wrench(rq4, af[0], af[1], af[2], P.res_force_scale);
+                const strict::V3 Tq = strict::residual_wrench(rq4, af[3], af[4], af[5], P.res_torque_scale);
+                wrench_park[PARK_TAR * 64] = F.x; wrench_park[(PARK_TAR + 1) * 64] = F.y; wrench_park[(PARK_TAR + 2) * 64] = F.z;
+                wrench_park[25 + PARK_TAR * 64] = Tq.x; wrench_park[25 + (PARK_TAR + 1) * 64] = Tq.y; wrench_park[25 + (PARK_TAR + 2) * 64] = Tq.z;
+            }
         }
     }
 
-    park_put3(PARK_TAR, tar);  // constant for the whole launch
+    if (valid && b != 0) park_put3(PARK_TAR, tar);  // constant for the whole launch (the columns of lanes 0 and 25 hold the wrench there)
     const BallDev& BP = a.ball;
     const bool ball_lane = BALL && lb == NB;  // the first idle lane of the env carries the ball
     if (ball_lane) {
@@ -538,7 +560,7 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
     const long long tl0 = a.wave_times ? wall_clock64() : 0, tc0 = a.wave_times ? clock64() : 0;
     auto timeline = [&]() {
         if (!DIAG && a.wave_times && lane == 0) {
-            long long* tl = a.wave_times + (int64_t)blockIdx.x * 4;
+            long long* tl = a.wave_times + (int64_t)jid * 4;
             tl[0] = tl0; tl[1] = wall_clock64(); tl[2] = (long long)bid + ((long long)sjob << 24) + ((long long)(mono ? 1 : 0) << 28) + ((long long)ksum << 32);
             tl[3] = clock64() - tc0;  // shader cycles of the job: with the wall clock, the clock the job ran at
         }
@@ -550,6 +572,8 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
     for (int sub = sub0; sub < sub1; ++sub) {
         const bool wrench_on = sub < P.hold_sub;
         const bool last = sub == nsub - 1;
+        // a substep that is being recomputed by a job that gave up waiting for its predecessor: it publishes nothing (the predecessor does)
+        const bool replay = JOBS && !mono && sub < sjob;
         LLPH(0);
         // per-link model constants are (re)loaded where they are used (L1/K$ hits) instead of pinning ~20 registers for the whole
         // kernel; the opaque index keeps the compiler from hoisting the loads back out of the substep loop
@@ -591,7 +615,7 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                     // the reference's bounce test on the ball height at the start of every simulate() call (apply_external_force_to_ball, :731-737)
                     // (system-scope accesses: with substep jobs the calls of one step run in different workgroups)
                     const int64_t e = env_here();
-                    if (BP.has_bounce && live_env) {
+                    if (BP.has_bounce && live_env && !replay) {
                         if (sub == 0) flag_st(&BP.has_bounce_now[e], 0);
                         if (bp.z <= BP.bounce_height && !flag_ld(&BP.has_bounce[e])) {
                             flag_st(&BP.has_bounce[e], 1);
@@ -759,9 +783,15 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
             pf = mass * (wwd - V3{0.f, 0.f, P.gravity_z});
             pn = cross(w, mul(Ic, w)) + cross(dc, pf);
             if (b == 0 && wrench_on) {
-                const float* cw = a.ctrl + env_here() * CTRL_SLOTS;
-                const V3 extF{ldin(&cw[CT_FORCE + 0]), ldin(&cw[CT_FORCE + 1]), ldin(&cw[CT_FORCE + 2])};
-                const V3 extT{ldin(&cw[CT_TORQUE + 0]), ldin(&cw[CT_TORQUE + 1]), ldin(&cw[CT_TORQUE + 2])};
+                V3 extF, extT;
+                if (a.actions) {
+                    extF = V3{wrench_park[PARK_TAR * 64], wrench_park[(PARK_TAR + 1) * 64], wrench_park[(PARK_TAR + 2) * 64]};
+                    extT = V3{wrench_park[25 + PARK_TAR * 64], wrench_park[25 + (PARK_TAR + 1) * 64], wrench_park[25 + (PARK_TAR + 2) * 64]};
+                } else {
+                    const float* cw = a.ctrl + env_here() * CTRL_SLOTS;
+                    extF = V3{ldin(&cw[CT_FORCE + 0]), ldin(&cw[CT_FORCE + 1]), ldin(&cw[CT_FORCE + 2])};
+                    extT = V3{ldin(&cw[CT_TORQUE + 0]), ldin(&cw[CT_TORQUE + 1]), ldin(&cw[CT_TORQUE + 2])};
+                }
                 pn = pn - extT - cross(dc, extF);  // force acts at the root COM
                 pf = pf - extF;
             }
@@ -1972,7 +2002,7 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                 // (output addresses from the opaque env index: formed from `e` they are loop invariants, hoisted in front of the substep
                 // loop and kept - spilled - across all of it: 70 dwords of scratch per lane in the racket + ball kernels)
                 const int64_t e = env_here();
-                if (live_env && sub % BP.sub_per_sim == BP.sub_per_sim - 1) {
+                if (live_env && !replay && sub % BP.sub_per_sim == BP.sub_per_sim - 1) {
                     const int ks = sub / BP.sub_per_sim, nsim = nsub / BP.sub_per_sim;
                     float* o = BP.per_sim + (e * nsim + ks) * 13;
                     o[0] = bp.x; o[1] = bp.y; o[2] = bp.z; o[3] = bq.x; o[4] = bq.y; o[5] = bq.z; o[6] = bq.w;
@@ -1993,7 +2023,7 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                     if (BP.body_contact) { float* ob = BP.body_contact + e * 3; ob[0] = fbd.x; ob[1] = fbd.y; ob[2] = fbd.z; }
                 }
             }
-            if ((last || (BP.contact_sum && sub % BP.sub_per_sim == BP.sub_per_sim - 1)) && valid && live_env && !frozen) {
+            if ((last || (BP.contact_sum && !replay && sub % BP.sub_per_sim == BP.sub_per_sim - 1)) && valid && live_env && !frozen) {
                 // the reaction on the touched link enters its net contact force below
                 const V3 fr = mask(lb == BP.racket_link, frk) + mask(lb == hl, fbd);
                 park[PARK_W0 * 64] = fr.x; park[(PARK_W0 + 1) * 64] = fr.y; park[(PARK_W0 + 2) * 64] = fr.z;
@@ -2001,7 +2031,7 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
         }
         // (racket + ball, opt-in: `_contact_forces_sum`, the net contact forces summed over the simulate() calls of a control step,
         // humanoid_smpl_im_mvae.py:781 - what refresh_net_contact_force_tensor shows after EVERY call is needed then, not only after the last)
-        const bool sum_now = BALL && BP.contact_sum && sub % BP.sub_per_sim == BP.sub_per_sim - 1;
+        const bool sum_now = BALL && BP.contact_sum && !replay && sub % BP.sub_per_sim == BP.sub_per_sim - 1;
         if ((last || sum_now) && valid && live_env && !frozen) {
             // net contact force per body = sum of impulses / h  (refresh_net_contact_force_tensor)
             V3 cforce{0.f, 0.f, 0.f};
@@ -2117,7 +2147,7 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
             const bool root = b == 0;
             const float A0 = root ? q.x : jq.x, A1 = root ? q.y : jq.y, A2 = root ? q.z : jq.z, A3 = root ? q.w : jq.w;
             const float B0 = root ? x.x : wt.x, B1 = root ? x.y : wt.y, B2 = root ? x.z : wt.z, B3 = root ? xd.x : 0.f;
-            float* const ho = a.job_hand + e * HAND_FLOATS;
+            float* const ho = a.job_hand + ((int64_t)sjob * N + e) * HAND_FLOATS;
             const bool second = lb & 1;
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
@@ -2132,7 +2162,7 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
             }
         }
         if (BALL && ball_lane && live_env) {
-            float* const ho = a.job_hand + e * HAND_FLOATS;
+            float* const ho = a.job_hand + ((int64_t)sjob * N + e) * HAND_FLOATS;
             cstore4(ho + 4 * 50, bl[0], bl[1], bl[2], bl[3]);
             cstore4(ho + 4 * 51, bl[4], bl[5], bl[6], bl[7]);
             cstore4(ho + 4 * 52, bl[8], bl[9], bl[10], bl[11]);
@@ -2361,6 +2391,7 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s, float* actions, int* fuse
     a.job_blocks = (int)blocks;
     a.job_progress = env->job_progress;
     a.job_hand = env->job_hand;
+    a.job_timeout_spins = env->job_timeout_spins;
     a.job_mono = (int)blocks;
     auto job_grid = [&](int& rc) -> dim3 {
         rc = V2P_OK;

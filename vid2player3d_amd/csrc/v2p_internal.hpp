@@ -145,7 +145,9 @@ struct v2p_env {
     int substeps_per_sim;     // substeps of one simulate() call
     int substep_jobs;         // v2p_sim_cfg.substep_jobs: the physics launch is cut into (substep, env pair) jobs
     int32_t* job_progress;    // [waves + 1] progress word per wave slot, last = error flag
-    float* job_hand;          // [N][HAND_FLOATS] the state as one substep job hands it to the next (16-byte chunks)
+    float* job_hand;          // [nsub - 1][N][HAND_FLOATS] the state as one substep job hands it to the next (16-byte chunks), a slot per substep
+    long job_timeout_spins;   // see PhysArgs
+    int64_t job_recoveries;   // jobs that gave up waiting and recomputed, as last fetched (v2p_env_check / _check_async)
     int job_epoch;
     int pair_mix_permille;    // share of the envs (the heaviest) that are paired with the lightest ones instead of with each other
     int pair_mix_default;     // pair_mix_permille was left to the engine (-1)

@@ -515,8 +515,9 @@ class HumanoidSMPLIM:
     def reset(self, env_ids=None):
         """HumanoidSMPL.reset (humanoid_smpl.py:136-159) with reference-state init."""
         if env_ids is None:
-            # once per epoch: a substep job that timed out in an earlier step (its results are then invalid) raises here, without a wait
+            # once per epoch, without a wait: substep jobs that had to be recomputed (never, normally) are noticed and warned about
             _lib.check(self._lib.v2p_env_check_async(self._h_env, self._stream()), "v2p_env_check_async")
+            self._warn_job_recoveries()
             n = self.num_envs
             ids_t, motion_ids = None, self._reset_ref_motion_ids
         else:
@@ -647,8 +648,24 @@ class HumanoidSMPLIM:
         return out
 
     def check(self):
-        """Synchronise and raise if the device reported an error since the last check (v2p_env_check)."""
+        """Synchronise (v2p_env_check: raises on a HIP error) and fetch the substep jobs' recovery counter."""
         _lib.check(self._lib.v2p_env_check(self._h_env, self._stream()), "v2p_env_check")
+        self._warn_job_recoveries()
+
+    def job_recoveries(self):
+        """Substep jobs that gave up waiting for their predecessor and recomputed the earlier substeps themselves (as last fetched by
+        check() or by the per-epoch reset()).  Results are unaffected; a count that grows means the launch loses time."""
+        n = C.c_int64(0)
+        _lib.check(self._lib.v2p_env_job_recoveries(self._h_env, C.byref(n)), "v2p_env_job_recoveries")
+        return int(n.value)
+
+    def _warn_job_recoveries(self):
+        n = self.job_recoveries()
+        if n > getattr(self, "_job_recoveries_seen", 0):
+            import warnings
+            warnings.warn("%d substep jobs of the physics launches were recomputed after waiting in vain for their predecessor (workgroups not "
+                          "dispatched in index order?): results are unaffected, the launches lose time; cfg env substep_jobs=False avoids it" % n)
+            self._job_recoveries_seen = n
 
     def profile_begin(self, max_launches):
         """HIP events around every physics-kernel launch from now on (engine side, on the launch stream)."""
