@@ -12,7 +12,7 @@ tail -30 $O/pytest_full.log > $O/pytest_gpu.log
 grep -h "^\[selection\]\|^\[schedules\]" $O/pytest_full.log > $O/selection.log; rm -f $O/pytest_full.log
 timeout 300 python __graft_entry__.py --smoke > $O/smoke.log 2>&1
 timeout 600 python bench.py > $O/bench.log 2>&1
-for v in "--num-envs 1024 --no-contact" "--djokovic" "--racket-ball" "--racket-ball --joint-limits 0" "--racket-ball --ball-body-contacts 0" "--racket-ball --substep-jobs 0" "--per-clip-shapes" "--solver tgs" "--freeze-terminated" "--action-noise 0.03" "--num-envs 32768 --steps 96 --warmup 32" "--substep-jobs 0"; do
+for v in "--num-envs 1024 --no-contact" "--djokovic" "--racket-ball" "--racket-ball --joint-limits 0" "--racket-ball --ball-body-contacts 0" "--racket-ball --substep-jobs 0" "--racket-ball --per-clip-shapes" "--per-clip-shapes" "--solver tgs" "--groups 2" "--freeze-terminated" "--action-noise 0.03" "--num-envs 32768 --steps 96 --warmup 32" "--substep-jobs 0"; do
   echo "[$v] $(timeout 300 python bench.py --no-cpu-baseline $v 2>&1 | tail -1)"
 done > $O/bench_variants.log 2>&1
 timeout 600 python bench.py --ppo --ppo-epochs 3 > $O/bench_ppo.log 2>&1

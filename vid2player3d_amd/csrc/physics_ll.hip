@@ -70,6 +70,12 @@ __device__ __forceinline__ V3 residual_wrench(const float* root_rot, float a0, f
     const Q4 hq = ref_heading_quat(ref_calc_heading(ref_remove_base_rot(Q4{root_rot[0], root_rot[1], root_rot[2], root_rot[3]})));
     return ref_quat_rotate(hq, V3{a0 * scale, a1 * scale, a2 * scale});
 }
+// force and torque at once: one heading quaternion (the same functions of the same arguments: the same bits as two calls)
+__device__ __forceinline__ void residual_wrench2(const float* root_rot, const float* a6, float fscale, float tscale, V3& F, V3& T) {
+    const Q4 hq = ref_heading_quat(ref_calc_heading(ref_remove_base_rot(Q4{root_rot[0], root_rot[1], root_rot[2], root_rot[3]})));
+    F = ref_quat_rotate(hq, V3{a6[0] * fscale, a6[1] * fscale, a6[2] * fscale});
+    T = ref_quat_rotate(hq, V3{a6[3] * tscale, a6[4] * tscale, a6[5] * tscale});
+}
 }  // namespace strict
 #if !defined(V2P_LL_STRICT_MATH)
 #pragma clang fp reassociate(on) reciprocal(on) contract(fast)  // (a file-scope fp pragma stays in force past the namespace: switch back)
@@ -462,6 +468,15 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
             x = V3{c1.x, c1.y, c1.z};
             xd = V3{c1.w, c2.x, c2.y};
             w = V3{c2.z, c2.w, c3.x};
+            if (a.actions && valid && sjob < a.p.hold_sub) {
+                // the residual wrench of the fused step travels with the root's chunks while a later job still needs it (it is held for the
+                // first hold_sub substeps only): force behind w.z, torque in chunk 54
+                f4 c4, c5;
+                cload4x2(hand + 4 * 54, hand + 4 * 54, c4, c5);
+                float* const wp = park_all + (threadIdx.x >> 6) * LDS_FLOATS_PER_WAVE + base;
+                wp[PARK_TAR * 64] = c3.y; wp[(PARK_TAR + 1) * 64] = c3.z; wp[(PARK_TAR + 2) * 64] = c3.w;
+                wp[25 + PARK_TAR * 64] = c4.x; wp[25 + (PARK_TAR + 1) * 64] = c4.y; wp[25 + (PARK_TAR + 2) * 64] = c4.z;
+            }
         } else {
             jq = Q4{c0.x, c0.y, c0.z, c0.w};
             wt = V3{c1.x, c1.y, c1.z};
@@ -516,10 +531,10 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
 #pragma unroll
                 for (int k = 0; k < 6; ++k) { af[k] = 0.f; if (first_job) ap[k] = 0.f; }
             }
-            if (sub0 < P.hold_sub) {  // (a job past the substeps that hold the wrench has no use for it)
+            if (sub0 < P.hold_sub && !handed) {  // (a job past the substeps that hold the wrench has no use for it; a later job is handed it)
                 const float* rq4 = a.x_rb + e * NB * 13 + 3;
-                const strict::V3 F = strict::residual_wrench(rq4, af[0], af[1], af[2], P.res_force_scale);
-                const strict::V3 Tq = strict::residual_wrench(rq4, af[3], af[4], af[5], P.res_torque_scale);
+                strict::V3 F, Tq;
+                strict::residual_wrench2(rq4, af, P.res_force_scale, P.res_torque_scale, F, Tq);
                 wrench_park[PARK_TAR * 64] = F.x; wrench_park[(PARK_TAR + 1) * 64] = F.y; wrench_park[(PARK_TAR + 2) * 64] = F.z;
                 wrench_park[25 + PARK_TAR * 64] = Tq.x; wrench_park[25 + (PARK_TAR + 1) * 64] = Tq.y; wrench_park[25 + (PARK_TAR + 2) * 64] = Tq.z;
             }
@@ -2158,7 +2173,13 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
             }
             if (root && valid && live_env) {
                 cstore4(ho + 4 * 48, xd.y, xd.z, w.x, w.y);
-                cstore4(ho + 4 * 49, w.z, 0.f, 0.f, 0.f);
+                if (a.actions && sjob + 1 < a.p.hold_sub) {  // the next job still applies the residual wrench: it travels along
+                    const float* wp = park_all + (threadIdx.x >> 6) * LDS_FLOATS_PER_WAVE + base;
+                    cstore4(ho + 4 * 49, w.z, wp[PARK_TAR * 64], wp[(PARK_TAR + 1) * 64], wp[(PARK_TAR + 2) * 64]);
+                    cstore4(ho + 4 * 54, wp[25 + PARK_TAR * 64], wp[25 + (PARK_TAR + 1) * 64], wp[25 + (PARK_TAR + 2) * 64], 0.f);
+                } else {
+                    cstore4(ho + 4 * 49, w.z, 0.f, 0.f, 0.f);
+                }
             }
         }
         if (BALL && ball_lane && live_env) {

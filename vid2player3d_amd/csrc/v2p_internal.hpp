@@ -172,7 +172,7 @@ inline int64_t job_wave_slots(int64_t n) { return (n + 2 * V2P_LL_WPB - 1) / (2 
 
 // state SoA slots
 constexpr int ST_ROOT_POS = 0, ST_ROOT_QUAT = 3, ST_JQUAT = 7, ST_VEL = 7 + 4 * NJ, STATE_SLOTS = 7 + 4 * NJ + 6 + 3 * NJ;  // 174
-constexpr int HAND_FLOATS = 216;  // 54 chunks of 4 floats: chunk 2b, 2b+1 = joint b (quaternion | rate), 0, 1, 48, 49 = root, 50 .. 53 = the ball (state 13 | aerodynamic force 3)
+constexpr int HAND_FLOATS = 224;  // 56 chunks of 4 floats: chunk 2b, 2b+1 = joint b (quaternion | rate), 0, 1, 48, 49 = root (49 also: residual force), 50 .. 53 = the ball (state 13 | aerodynamic force 3), 54 = residual torque
 constexpr int CT_PD = 0, CT_FORCE = NDOF, CT_TORQUE = NDOF + 3, CTRL_SLOTS = NDOF + 6;
 // physics outputs (SoA): rigid-body state 24x13, dof_pos 69, contact force 72, dof force 69
 constexpr int OUT_RB = 0, OUT_DOF_POS = NB * 13, OUT_CONTACT = OUT_DOF_POS + NDOF, OUT_DOF_FORCE = OUT_CONTACT + NB * 3,
