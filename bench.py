@@ -257,7 +257,7 @@ def run_ppo(args, task, dist, world, rank):
 
     tasks = task if isinstance(task, list) else [task]
     task = tasks[0]
-    agent = PPOAgent(tasks if len(tasks) > 1 else task, seed=7, reuse_next_values=not args.ppo_reference_critic_passes, overlap_critic=not args.ppo_no_overlap)
+    agent = PPOAgent(tasks if len(tasks) > 1 else task, seed=7, reuse_next_values=not args.ppo_reference_critic_passes, overlap_critic=not args.ppo_no_overlap, mixed_precision=args.ppo_mixed_precision)
     agent.train_epoch()  # warm-up epoch (allocator, rocBLAS heuristics, running statistics)
     rows = []
     for _ in range(args.ppo_epochs):
@@ -276,11 +276,12 @@ def run_ppo(args, task, dist, world, rank):
         from vid2player3d_amd import build
         out = {"metric": "env-steps/sec at num_envs=8192, SMPL humanoid imitation", "value": world * frames / total, "unit": "env-steps/s", "n_gpus": world,
                "steps": args.ppo_epochs * HORIZON, "warmup": HORIZON, "ms_per_step": 1e3 * total / (args.ppo_epochs * HORIZON), "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "scaling": "weak", "vs_baseline": None, "dtype": "f16 autocast (update) / f32" if args.ppo_mixed_precision else "f32", "data": "synthetic",
                "config": {"workload": "FULL PPO LOOP (BASELINE config 5 shape, reported separately from the rollout metric): amass_im num_envs=%d per GPU, "
                                       "horizon 32, actor/critic MLP [1024,1024,512] on the 734-d observation (residual action), 6 mini-epochs x minibatches of 512 envs; "
-                                      "%d rollout group(s) per GPU, critic %s; value = fps total"
-                                      % (args.num_envs, len(tasks), "twice per step like the reference" if args.ppo_reference_critic_passes else "once per step (next_values reused as values)" + ("" if args.ppo_no_overlap else ", on a side stream beside the physics launch")),
+                                      "%d rollout group(s) per GPU, critic %s%s; value = fps total"
+                                      % (args.num_envs, len(tasks), "twice per step like the reference" if args.ppo_reference_critic_passes else "once per step (next_values reused as values)" + ("" if args.ppo_no_overlap else ", on a side stream beside the physics launch"),
+                                         ", UPDATE IN MIXED PRECISION (fp16 autocast: the reference's non-default cfg option)" if args.ppo_mixed_precision else ""),
                           "num_envs_per_gpu": args.num_envs, "global_envs": world * args.num_envs,
                           "parallelism": "env-sharded x%d; advantage statistics, running norms and gradients all-reduced over RCCL at the update" % world,
                           "fps_step": world * frames / play, "fps_total": world * frames / total,
@@ -319,6 +320,7 @@ def main():
     ap.add_argument("--ppo-epochs", type=int, default=4, help="timed PPO epochs (after one untimed warm-up epoch)")
     ap.add_argument("--groups", type=int, default=1, help="rollout groups per GPU: the rank's envs as G env batches on G HIP streams (reported separately from the headline; "
                     "with --ppo the physics of one group overlaps the policy inference of the other)")
+    ap.add_argument("--ppo-mixed-precision", action="store_true", help="--ppo: the reference's cfg option mixed_precision (amass_im.yaml: False): fp16 autocast + loss scaling in the update; a labelled variant, never the headline")
     ap.add_argument("--ppo-no-overlap", action="store_true", help="--ppo: the critic pass on the rollout's own stream instead of a side stream beside the physics (A/B)")
     ap.add_argument("--ppo-reference-critic-passes", action="store_true", help="--ppo: evaluate the critic twice per step like the reference (A/B of reuse_next_values)")
     ap.add_argument("--stub-task", action="store_true", help=argparse.SUPPRESS)  # launch-logic test without GPUs (gloo, CPU); never a measurement

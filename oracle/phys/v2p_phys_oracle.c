@@ -117,6 +117,8 @@ typedef struct {
 int v2p_oracle_substep_io(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s, const double *pd_target, const double *ext_force,
                           const double *ext_torque, double *contact_force, double *dof_force, int *contact_ids, const v2p_osub_io *io);
 
+static __thread int g_hull_rows; /* ball x hull points of the last substep (diagnostics of the parity tests) */
+
 /* ------------------------------------------------------------------ small helpers */
 static void cross(const double a[3], const double b[3], double o[3]) {
     double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
@@ -640,16 +642,18 @@ static int substep_impl(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s
          * substep for the ball; PhysX: the `contactDistance` of a joint limit): the row exists in this substep only if
          * C < limit_margin + h max(0, approach rate), the rate being the joint rate AFTER the unconstrained update (v*: the implicit
          * PD can change a joint rate by tens of rad/s within a substep).  A violated limit (C < 0) is always active. */
-        crow_t rows[NB * MAXC_BODY + 4 + 3 * NJ];
+        crow_t rows[NB * MAXC_BODY + 6 + 3 * NJ];
         int nc = 0, ci = 0;
-        /* ball x humanoid: the hull (convex hull of the link's contact vertices) nearest to the ball carries one point, found at the
-         * start of the substep; activation and bias exactly like a racket point.  A ball centre INSIDE a hull (more than a radius deep:
+        /* ball x humanoid: every hull (convex hull of a link's contact vertices) the ball can reach within the substep carries one point
+         * (PhysX: one per overlapping pair; the MAXH nearest are kept), found at the start of the substep; activation and bias exactly
+         * like a racket point; the rows of a link's point are solved right after that link's ground points.  A ball centre INSIDE a hull (more than a radius deep:
          * not reachable through the speculative rows unless it is placed there) is pushed out along the direction from the centre of
          * the hull's body-frame bounding box. */
-        int hull_link = -1;
-        crow_t hull_row;
+        g_hull_rows = 0;
+#define MAXH 3 /* hull points kept per ball: the nearest links (the engine's LDS block holds three next to the cylinders' two) */
+        int nhull = 0, hull_link[MAXH];
+        crow_t hull_row[MAXH];
         if (ball && bp->body_contacts && p->enable_contact) {
-            double best = 1e300;
             for (int b = 0; b < NB; ++b) {
                 if (b == bp->racket_link) continue;
                 const int v0 = m->hull_offsets[b], nv = m->hull_offsets[b + 1] - v0;
@@ -675,13 +679,21 @@ static int substep_impl(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s
                 double vrel = 0;
                 for (int i = 0; i < 3; ++i) vrel += (ball->vel[i] - k.xd[b][i] - wr[i]) * nw[i];
                 const double gapb = dist - bp->radius;
-                if (gapb < p->contact_offset + h * fmax(0.0, -vrel) && gapb < best) {
-                    best = gapb; hull_link = b;
-                    memset(&hull_row, 0, sizeof(hull_row));
-                    hull_row.kind = 4; hull_row.body = b; hull_row.vert = 0;
-                    memcpy(hull_row.pos, pt, sizeof(pt)); memcpy(hull_row.n, nw, sizeof(nw));
-                    tangent_basis(nw, hull_row.t1, hull_row.t2);
-                    hull_row.gap = gapb; hull_row.mu = bp->fric_body; hull_row.rest = bp->rest_body;
+                if (gapb < p->contact_offset + h * fmax(0.0, -vrel)) {
+                    /* one point per overlapping link (PhysX: one per overlapping pair), the MAXH nearest kept, nearest first; ties: lower link */
+                    int at = nhull;
+                    while (at > 0 && gapb < hull_row[at - 1].gap) --at;
+                    if (at < MAXH) {
+                        for (int q = (nhull < MAXH ? nhull : MAXH - 1); q > at; --q) { hull_row[q] = hull_row[q - 1]; hull_link[q] = hull_link[q - 1]; }
+                        crow_t *hr = &hull_row[at];
+                        memset(hr, 0, sizeof(*hr));
+                        hr->kind = 4; hr->body = b; hr->vert = 0;
+                        memcpy(hr->pos, pt, sizeof(pt)); memcpy(hr->n, nw, sizeof(nw));
+                        tangent_basis(nw, hr->t1, hr->t2);
+                        hr->gap = gapb; hr->mu = bp->fric_body; hr->rest = bp->rest_body;
+                        hull_link[at] = b;
+                        if (nhull < MAXH) ++nhull;
+                    }
                 }
             }
         }
@@ -709,7 +721,7 @@ static int substep_impl(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s
                 r->n[0] = 0; r->n[1] = 0; r->n[2] = 1; r->t1[0] = 1; r->t1[1] = 0; r->t1[2] = 0; r->t2[0] = 0; r->t2[1] = 1; r->t2[2] = 0;
                 r->gap = cs.pos[ci][2]; r->mu = p->mu; r->rest = 0.0;
             }
-            if (b == hull_link) rows[nc++] = hull_row;
+            for (int q = 0; q < nhull; ++q) if (hull_link[q] == b) { rows[nc++] = hull_row[q]; ++g_hull_rows; }
             if (ball && b == bp->racket_link)
                 for (int j = 0; j < bp->ncyl; ++j) {
                     double cw[3], aw[3], pt[3], n[3];
@@ -747,7 +759,7 @@ static int substep_impl(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s
         double *wii = Tr + (size_t)(nrow > 0 ? nrow : 1) * NDT;
         double *lam = wii + (nrow > 0 ? nrow : 1);
         double *bias = lam + (nrow > 0 ? nrow : 1);
-        double gap[NB * MAXC_BODY + 4 + 3 * NJ];
+        double gap[NB * MAXC_BODY + 6 + 3 * NJ];
         int slot_in_body[NB];
         memset(slot_in_body, 0, sizeof(slot_in_body));
         for (int c = 0; c < nc; ++c) {
@@ -936,15 +948,18 @@ void v2p_oracle_ball_aero(const v2p_oball *ball, double spin_scale, double force
 int v2p_oracle_step_ball(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s, const double *pd_target, const double *ext_force,
                          const double *ext_torque, int nsub, int hold, int sub_per_sim, double *contact_force, double *dof_force, int *contact_ids,
                          const v2p_oball_params *bp, v2p_oball *ball, double spin_scale, double *ball_per_sim, int *racket_hit_per_sim,
-                         double *ball_contact, double *contact_force_sum /*[NB*3] nullable: net contact forces summed over the simulate() calls
+                         double *ball_contact, int *max_hull_points /*[1] nullable: most ball x hull points active in one substep*/,
+                         double *contact_force_sum /*[NB*3] nullable: net contact forces summed over the simulate() calls
                                                                           * (`_contact_forces_sum`, humanoid_smpl_im_mvae.py:781; needs contact_force)*/) {
     double f[3] = {0, 0, 0}, bc[9];
     if (contact_force_sum) memset(contact_force_sum, 0, sizeof(double) * NB * 3);
+    if (max_hull_points) *max_hull_points = 0;
     for (int i = 0; i < nsub; ++i) {
         if (i % sub_per_sim == 0) v2p_oracle_ball_aero(ball, spin_scale, f);
         int on = i < hold;
         int rc = substep_impl(m, p, s, pd_target, on ? ext_force : 0, on ? ext_torque : 0, contact_force, dof_force, contact_ids, 0, bp, ball, f, bc);
         if (rc) return rc;
+        if (max_hull_points && g_hull_rows > *max_hull_points) *max_hull_points = g_hull_rows;
         if (i % sub_per_sim == sub_per_sim - 1) {
             int k = i / sub_per_sim;
             if (ball_per_sim) {

@@ -197,9 +197,11 @@ class PhysOracle:
         tar = None if pd_target is None else np.ascontiguousarray(pd_target, dtype=np.float64)
         f = None if ext_force is None else np.ascontiguousarray(ext_force, dtype=np.float64)
         t = None if ext_torque is None else np.ascontiguousarray(ext_torque, dtype=np.float64)
+        nh = C.c_int(0)
         rc = self.lib.v2p_oracle_step_ball(C.byref(self.model), C.byref(self.params), C.byref(self.state), _dptr(tar), _dptr(f), _dptr(t), int(nsub), int(hold),
                                            int(sub_per_sim), _dptr(cf), _dptr(df), _iptr(ids), C.byref(self.ball_params), C.byref(self.ball),
-                                           C.c_double(self.spin_scale), _dptr(per_sim), _iptr(hit), _dptr(bc), _dptr(cfs))
+                                           C.c_double(self.spin_scale), _dptr(per_sim), _iptr(hit), _dptr(bc), C.byref(nh), _dptr(cfs))
+        self.max_hull_points = int(nh.value)  # most ball x hull points active in one substep of the step
         self.contact_force_sum = cfs  # net contact forces of the links summed over the simulate() calls of the step
         if rc:
             raise RuntimeError("oracle ball step failed (%d)" % rc)

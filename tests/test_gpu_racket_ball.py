@@ -44,6 +44,19 @@ def _launch(task, rng, mode):
         ball[:, 2] = rng.uniform(0.03, 0.25, n)
         ball[:, 7:10] = np.stack([rng.normal(0, 6, n), rng.normal(0, 6, n), rng.uniform(-12, 1, n)], 1)
         ball[:, 10:13] = rng.normal(0, 60, (n, 3))
+    elif mode == "joint":
+        # aimed at a JOINT of each env (knee, elbow, neck ...): the hulls of the two links that meet there are both within reach of a
+        # fast ball, so two hull points are active at once (one per overlapping link)
+        for e in range(n):
+            b = int(rng.choice([2, 6, 10, 12, 16, 3, 7]))
+            target = rb[e, b, 0:3]
+            d = rng.normal(size=3)
+            d[2] = abs(d[2])
+            d /= np.linalg.norm(d)
+            speed = rng.uniform(15, 35)
+            ball[e, 0:3] = target + rng.uniform(0.15, 0.3) * d
+            ball[e, 7:10] = -speed * d + rb[e, b, 7:10]
+            ball[e, 10:13] = rng.normal(0, 80, 3)
     elif mode == "body":
         # aimed at the hull of a link of each env (not the racket's), from a random direction
         bm = task.body_model
@@ -79,7 +92,7 @@ def _launch(task, rng, mode):
 
 @pytest.mark.parametrize("mode,lift,limits,player", [("flight", 0.0, False, "djokovic"), ("ground", 0.0, False, "djokovic"), ("hit", 0.4, False, "djokovic"),
                                                      ("hit", 0.0, False, "djokovic"), ("hit", 0.0, True, "djokovic"), ("body", 0.4, False, "djokovic"),
-                                                     ("body", 0.0, True, "federer"), ("hit", 0.0, True, "nadal")])
+                                                     ("body", 0.0, True, "federer"), ("hit", 0.0, True, "nadal"), ("joint", 0.4, False, "djokovic")])
 def test_ball_step_matches_oracle(mlib, mode, lift, limits, player):
     """limits: with the joint ranges of the player MJCF's racket arm enforced (v2p_sim_cfg.joint_limits) - the wrist's limit rows, its
     hull points and the ball x racket rows then all belong to the same link.  player: the asset (nadal = left-handed: racket on L_Wrist)."""
@@ -98,7 +111,7 @@ def test_ball_step_with_one_body_shape_per_clip(mlib, mode):
 
 def _ball_step_vs_oracle(mlib, mode, lift, limits, player, shapes=None):
     n = 32
-    rng = np.random.default_rng({"flight": 1, "ground": 2, "hit": 3, "body": 4}[mode] + int(10 * lift))
+    rng = np.random.default_rng({"flight": 1, "ground": 2, "hit": 3, "body": 4, "joint": 5}[mode] + int(10 * lift))
     extra = {} if shapes is None else {"body_model": shapes, "motion_shape_ids": np.arange(8) % len(shapes)}
     task = make_rb_task(n, mlib, joint_limits=limits, player=player, **extra)
     rl = task.racket_geometry["racket_link"]
@@ -126,7 +139,7 @@ def _ball_step_vs_oracle(mlib, mode, lift, limits, player, shapes=None):
     task._rigid_body_state[:] = T(np.stack([o.get_state()[3] for o in oracles]).reshape(n * 24, 13))
     ball = _launch(task, rng, mode)
     task._ball_root_states[:] = T(ball)
-    hits_total, ground_total, body_total = 0, 0, 0
+    hits_total, ground_total, body_total, multi_total = 0, 0, 0, 0
     has_hit = np.zeros(n, dtype=bool)
     for step in range(2):
         act = np.concatenate([N(task._target_dof_pos) + rng.normal(0, 0.17, (n, 69)), rng.normal(0, 0.17, (n, 6))], axis=1).astype(np.float32)
@@ -171,6 +184,7 @@ def _ball_step_vs_oracle(mlib, mode, lift, limits, player, shapes=None):
         off = np.einsum("nij,j->ni", Rw, task.racket_geometry["racket_offset"])
         close(N(task._racket_rb_state)[:, 0:3], rbs[:, rl, 0:3] + off, 2e-5, "racket pos")
         close(N(task._racket_rb_state)[:, 7:10], rbs[:, rl, 7:10] + np.cross(rbs[:, rl, 10:13], off), 1e-3, "racket vel")
+        multi_total += sum(int(o.max_hull_points >= 2) for o in oracles)  # envs whose ball touched two links' hulls in one substep
         hits_total += int(hit.sum())
         ground_total += int(((ball_before[:, 9] < -0.5) & (got_ps[:, -1, 9] > 0)).sum())  # balls that bounced within this control step
         body_total += int(((np.linalg.norm(got_ps[:, -1, 7:10] - ball_before[:, 7:10], axis=1) > 3.0) & (hit.sum(1) == 0) & (got_ps[:, -1, 2] > 0.1)).sum())  # deflected by a hull
@@ -179,6 +193,8 @@ def _ball_step_vs_oracle(mlib, mode, lift, limits, player, shapes=None):
         assert hits_total >= n // 4, "the fixture must produce racket hits (%d)" % hits_total
     if mode == "ground":
         assert ground_total >= n // 4, ground_total
+    if mode == "joint":
+        assert multi_total >= n // 8, "the fixture must produce balls that touch two links at once (%d)" % multi_total
     if mode == "body":
         assert body_total >= n // 4, "the fixture must produce ball x hull hits (%d)" % body_total
     task.close()

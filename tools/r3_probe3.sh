@@ -1,5 +1,3 @@
 set -u
-O=gpurun_out; mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_physics.py -q -s 2>&1 > $O/t_rows_full.log
-grep "^\[rows\]\|^\[outliers\]\|^\[limits\]\|passed\|failed\|Error\|assert" $O/t_rows_full.log > $O/t_rows.log
-grep -v "^\[rows\]\|^\[selection\]" $O/t_rows_full.log | tail -30 | cut -c1-300; rm -f $O/t_rows_full.log
+timeout 900 python -m pytest tests/test_gpu_racket_ball.py -q -x 2>&1 | grep -v "^E    .*array\|^E   .*where" | tail -12 | cut -c1-300
+for v in "--racket-ball" "--racket-ball --joint-limits 0"; do echo "[$v] $(timeout 300 python bench.py --no-cpu-baseline $v 2>&1 | tail -1 | cut -c1-130)"; done

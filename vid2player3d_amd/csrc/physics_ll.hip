@@ -256,10 +256,10 @@ constexpr int PARK_TAR = 0, PARK_W0 = 3, PARK_XD0 = 6, PARK_Q = 9, PARK_X = 13, 
               PARK_SLOTS = PARK_SCR + 1;  // LDS parking slots (dwords per lane)
 constexpr int ROOTLAM_FLOATS = 2 * 24;  // (PARK2) Lambda of the two root links while the contacts are generated
 // ball block (80 floats per env, after the parking area of the wave): state 13 | aero force 3 | ground contact: active gap bias lambda3 |
-// point j at BL_RK + 16 j: active gap bias rl3 n3 lambda3 (j = 0, 1: against the racket's cylinders; j = 2: against the hull of link
-// BL_HLINK, stored + 1, 0 = none) | velocity at the start of the substep 3
+// point j at BL_RK + 16 j: active gap bias rl3 n3 lambda3 link (j = 0, 1: against the racket's cylinders; j = 2 .. 4: against the hulls
+// of up to three links, RK_LINK = the link that owns the point) | velocity at the start of the substep 3
 constexpr int BL_POS = 0, BL_QUAT = 3, BL_VEL = 7, BL_ANG = 10, BL_F = 13, BL_GA = 16, BL_GGAP = 17, BL_GBIAS = 18, BL_GLAM = 19, BL_RK = 24,
-              RK_A = 0, RK_GAP = 1, RK_BIAS = 2, RK_RL = 3, RK_N = 6, RK_LAM = 9, BL_V0 = 72, BL_HLINK = 75, BL_SLOTS = 80;
+              RK_A = 0, RK_GAP = 1, RK_BIAS = 2, RK_RL = 3, RK_N = 6, RK_LAM = 9, RK_LINK = 12, NBREC = 5, BL_V0 = BL_RK + 16 * NBREC, BL_SLOTS = BL_V0 + 8;
 constexpr int LDS_FLOATS_PER_WAVE = PARK_SLOTS * 64 + 2 * BL_SLOTS + ROOTLAM_FLOATS;
 // ball x hull narrow phase, out of line: it runs on the few substeps in which a ball is within reach of a link, and inlined its
 // registers would be spilled around on every substep
@@ -623,9 +623,12 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
             if (ball_lane) {
                 const V3 bp{bl[BL_POS], bl[BL_POS + 1], bl[BL_POS + 2]}, bv{bl[BL_VEL], bl[BL_VEL + 1], bl[BL_VEL + 2]}, bw{bl[BL_ANG], bl[BL_ANG + 1], bl[BL_ANG + 2]};
                 bl[BL_V0] = bv.x; bl[BL_V0 + 1] = bv.y; bl[BL_V0 + 2] = bv.z;  // (the hull points' activation test reads the velocity of the start of the substep)
-                bl[BL_HLINK] = 0.f;
-                bl[BL_RK + 32 + RK_A] = 0.f;
-                bl[BL_RK + 32 + RK_LAM] = 0.f; bl[BL_RK + 32 + RK_LAM + 1] = 0.f; bl[BL_RK + 32 + RK_LAM + 2] = 0.f;
+#pragma unroll
+                for (int j = 2; j < NBREC; ++j) {
+                    lds_vfloat* rk = bl + BL_RK + 16 * j;
+                    rk[RK_A] = 0.f; rk[RK_LINK] = -1.f;
+                    rk[RK_LAM] = 0.f; rk[RK_LAM + 1] = 0.f; rk[RK_LAM + 2] = 0.f;
+                }
                 if (sub % BP.sub_per_sim == 0) {
                     // the reference's bounce test on the ball height at the start of every simulate() call (apply_external_force_to_ball, :731-737)
                     // (system-scope accesses: with substep jobs the calls of one step run in different workgroups)
@@ -731,19 +734,25 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                         const float g = dist - BP.radius;
                         if (g < coff + h * fmaxf(0.f, -vrel)) gap = g;
                     }
-                    // the nearest of the env's candidates (ties: the lower link)
-                    float gmin = gap;
+                    // the (up to) three nearest of the env's candidates, nearest first (ties: the lower link): one point per overlapping link,
+                    // as PhysX generates one per overlapping pair - the LDS block holds three next to the cylinders' two
+#pragma unroll 1
+                    for (int k = 0; k < NBREC - 2; ++k) {
+                        float gmin = gap;
 #pragma unroll
-                    for (int sh = 1; sh < 32; sh <<= 1) gmin = fminf(gmin, __shfl_xor(gmin, sh));
-                    const unsigned long long wb = __ballot(gap == gmin && gap < 3.0e38f);
-                    const unsigned wmine = half ? (unsigned)(wb >> 32) : (unsigned)wb;
-                    if (wmine && lb == __ffs(wmine) - 1) {
-                        lds_vfloat* rk = bl + BL_RK + 32;
-                        rk[RK_A] = 1.f;
-                        rk[RK_GAP] = gap;
-                        rk[RK_RL] = rlw.x; rk[RK_RL + 1] = rlw.y; rk[RK_RL + 2] = rlw.z;
-                        rk[RK_N] = nw.x; rk[RK_N + 1] = nw.y; rk[RK_N + 2] = nw.z;
-                        bl[BL_HLINK] = (float)(lb + 1);
+                        for (int sh = 1; sh < 32; sh <<= 1) gmin = fminf(gmin, __shfl_xor(gmin, sh));
+                        const unsigned long long wb = __ballot(gap == gmin && gap < 3.0e38f);
+                        if (!wb) break;
+                        const unsigned wmine = half ? (unsigned)(wb >> 32) : (unsigned)wb;
+                        if (wmine && lb == __ffs(wmine) - 1) {
+                            lds_vfloat* rk = bl + BL_RK + 16 * (2 + k);
+                            rk[RK_A] = 1.f;
+                            rk[RK_GAP] = gap;
+                            rk[RK_RL] = rlw.x; rk[RK_RL + 1] = rlw.y; rk[RK_RL + 2] = rlw.z;
+                            rk[RK_N] = nw.x; rk[RK_N + 1] = nw.y; rk[RK_N + 2] = nw.z;
+                            rk[RK_LINK] = (float)lb;
+                            gap = 3.0e38f;  // taken
+                        }
                     }
                 }
             }
@@ -1141,10 +1150,14 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                 Lam.C = Sym3{lv[15], lv[16], lv[17], lv[18], lv[19], lv[20]};
             }
             // (with a ball: the racket's link joins the touched links while the ball is in contact with a cylinder)
-            const int hlink = BALL ? (int)bl[BL_HLINK] - 1 : -1;  // link whose hull the ball touches (-1: none)
-            // (point j of the ball block belongs to this lane's link: j = 0, 1 the racket's cylinders, j = 2 the hull point)
-            auto ball_rec_mine = [&](int j) -> bool { return j < 2 ? lb == BP.racket_link : lb == hlink; };
-            const bool ballhit = BALL && valid && ((lb == BP.racket_link && (bl[BL_RK + RK_A] != 0.f || bl[BL_RK + 16 + RK_A] != 0.f)) || lb == hlink);
+            // (point j of the ball block belongs to this lane's link: j = 0, 1 the racket's cylinders, j = 2 .. 4 the hull points)
+            auto ball_rec_mine = [&](int j) -> bool { return j < 2 ? lb == BP.racket_link : lb == (int)bl[BL_RK + 16 * j + RK_LINK]; };
+            bool myhull = false;  // this link's hull carries a ball point
+            if (BALL) {
+#pragma unroll
+                for (int j = 2; j < NBREC; ++j) myhull = myhull || (bl[BL_RK + 16 * j + RK_A] != 0.f && lb == (int)bl[BL_RK + 16 * j + RK_LINK]);
+            }
+            const bool ballhit = BALL && valid && ((lb == BP.racket_link && (bl[BL_RK + RK_A] != 0.f || bl[BL_RK + 16 + RK_A] != 0.f)) || myhull);
             const bool ballground = BALL && ball_lane && bl[BL_GA] != 0.f;
             const unsigned long long tb = __ballot(valid && (cnt > 0 || ballhit));
             const unsigned m0 = (unsigned)tb, m1 = (unsigned)(tb >> 32);
@@ -1273,7 +1286,7 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                     const V3 bv{bl[BL_VEL], bl[BL_VEL + 1], bl[BL_VEL + 2]}, bw{bl[BL_ANG], bl[BL_ANG + 1], bl[BL_ANG + 2]};
                     const float ih = PHYS_RCP(h);
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) {
+                    for (int j = 0; j < NBREC; ++j) {
                         lds_vfloat* rk = bl + BL_RK + 16 * j;
                         if (rk[RK_A] != 0.f && ball_rec_mine(j)) {
                             const V3 n{rk[RK_N], rk[RK_N + 1], rk[RK_N + 2]}, rl{rk[RK_RL], rk[RK_RL + 1], rk[RK_RL + 2]};
@@ -1591,7 +1604,7 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                                 // a free sphere (1/m, 1/I), the link side goes through Lambda_b like every row of this block
                                 V3 bv{bl[BL_VEL], bl[BL_VEL + 1], bl[BL_VEL + 2]}, bw{bl[BL_ANG], bl[BL_ANG + 1], bl[BL_ANG + 2]};
 #pragma unroll 1
-                                for (int j = 0; j < 3; ++j) {
+                                for (int j = 0; j < NBREC; ++j) {
                                     lds_vfloat* rk = bl + BL_RK + 16 * j;
                                     if (rk[RK_A] == 0.f || !ball_rec_mine(j)) continue;
                                     const V3 n{rk[RK_N], rk[RK_N + 1], rk[RK_N + 2]}, rl{rk[RK_RL], rk[RK_RL + 1], rk[RK_RL + 2]};
@@ -1794,7 +1807,7 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                                     // a free sphere (1/m, 1/I), the link side goes through Lambda_b like every row of this block
                                     V3 bv{bl[BL_VEL], bl[BL_VEL + 1], bl[BL_VEL + 2]}, bw{bl[BL_ANG], bl[BL_ANG + 1], bl[BL_ANG + 2]};
 #pragma unroll 1
-                                    for (int j = 0; j < 3; ++j) {
+                                    for (int j = 0; j < NBREC; ++j) {
                                         lds_vfloat* rk = bl + BL_RK + 16 * j;
                                         if (rk[RK_A] == 0.f || !ball_rec_mine(j)) continue;
                                         const V3 n{rk[RK_N], rk[RK_N + 1], rk[RK_N + 2]}, rl{rk[RK_RL], rk[RK_RL + 1], rk[RK_RL + 2]};
@@ -1982,15 +1995,15 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
             }
         }
         if (BALL) {
-            // force on the ball in this substep from the racket (sum over the two cylinders) and from the hull point, world axes
-            V3 frk{0.f, 0.f, 0.f}, fbd{0.f, 0.f, 0.f};
-            const int hl = (int)bl[BL_HLINK] - 1;
-            if ((ball_lane || (valid && (lb == BP.racket_link || lb == hl)))) {
+            auto ball_rec_mine_out = [&](int j) -> bool { return j < 2 ? lb == BP.racket_link : lb == (int)bl[BL_RK + 16 * j + RK_LINK]; };
+            // force on the ball in this substep from the racket (sum over the two cylinders) and from the hull points, world axes
+            V3 frk{0.f, 0.f, 0.f}, fbd{0.f, 0.f, 0.f}, fmine{0.f, 0.f, 0.f};  // from the racket, from all hulls, from this lane's hull
+            {
                 const float ih = PHYS_RCP(h);
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
+                for (int j = 0; j < NBREC; ++j) {
                     lds_vfloat* rk = bl + BL_RK + 16 * j;
-                    if (rk[RK_A] != 0.f) {
+                    if (rk[RK_A] != 0.f && (ball_lane || (valid && ball_rec_mine_out(j)))) {
                         const V3 n{rk[RK_N], rk[RK_N + 1], rk[RK_N + 2]};
                         V3 t1, t2;
                         t1 = cross(n, V3{0.f, 0.f, 1.f});
@@ -1998,7 +2011,8 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                         t1 = rsqrtf(dot(t1, t1)) * t1;
                         t2 = cross(n, t1);
                         const V3 f = ih * (rk[RK_LAM] * n + rk[RK_LAM + 1] * t1 + rk[RK_LAM + 2] * t2);
-                        if (j < 2) frk = frk + f; else fbd = fbd + f;
+                        if (j < 2) frk = frk + f;
+                        else { fbd = fbd + f; if (!ball_lane) fmine = fmine + f; }
                     }
                 }
             }
@@ -2040,7 +2054,7 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
             }
             if ((last || (BP.contact_sum && !replay && sub % BP.sub_per_sim == BP.sub_per_sim - 1)) && valid && live_env && !frozen) {
                 // the reaction on the touched link enters its net contact force below
-                const V3 fr = mask(lb == BP.racket_link, frk) + mask(lb == hl, fbd);
+                const V3 fr = mask(lb == BP.racket_link, frk) + fmine;
                 park[PARK_W0 * 64] = fr.x; park[(PARK_W0 + 1) * 64] = fr.y; park[(PARK_W0 + 2) * 64] = fr.z;
             }
         }

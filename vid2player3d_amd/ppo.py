@@ -192,7 +192,7 @@ class PPOAgent:
     def __init__(self, task, horizon_length=32, gamma=0.99, tau=0.95, learning_rate=2e-5, e_clip=0.2, critic_coef=5.0, mini_epochs=6,
                  minibatch_envs=512, grad_norm=50.0, units=(1024, 1024, 512), sigma_init=-1.756, seed=0, group=None,
                  normalize_value=True, normalize_advantage=True, entropy_coef=0.0, residual_action=True, reuse_next_values=True,
-                 truncate_grads=True, overlap_critic=True):
+                 truncate_grads=True, overlap_critic=True, mixed_precision=False):
         tasks = list(task) if isinstance(task, (list, tuple)) else [task]
         self.tasks, self.task = tasks, tasks[0]
         self.horizon_length, self.gamma, self.tau = horizon_length, gamma, tau
@@ -200,6 +200,10 @@ class PPOAgent:
         self.grad_norm, self.truncate_grads = grad_norm, truncate_grads
         self.normalize_value, self.normalize_advantage = normalize_value, normalize_advantage
         self.reuse_next_values, self.overlap_critic = reuse_next_values, overlap_critic
+        # cfg `mixed_precision` (amass_im.yaml: False): the reference wraps the forward pass and the losses of calc_gradients in
+        # torch.cuda.amp.autocast and scales the loss (im_agent.py:509, 548-563); the rollout stays float32 there as well
+        self.mixed_precision = bool(mixed_precision)
+        self.scaler = torch.amp.GradScaler("cuda", enabled=self.mixed_precision) if self.mixed_precision else None
         self.group = group
         self.device = torch.device(self.task.device)
         if any(str(t.device) != str(self.task.device) or t.context_padding != self.task.context_padding for t in tasks):
@@ -491,18 +495,21 @@ class PPOAgent:
         self.set_train()
         d = {k: v.reshape((-1, v.shape[-1]) if v.dim() > 2 else (-1,)) for k, v in input_dict.items()}
         alive, advantage = d["alive"], d["advantages"]
-        res = self.model.forward_train(d["feat_raw"], d["target_dof_pad"], d["actions"], self.group)
-        # _actor_loss / _critic_loss (common_agent.py:491-520; clip_value False), bound_loss with bounds_loss_coef None = 0
-        ratio = torch.exp(d["old_logp_actions"] - res["prev_neglogp"])
-        a_loss = torch.max(-advantage * ratio, -advantage * torch.clamp(ratio, 1.0 - self.e_clip, 1.0 + self.e_clip))
-        c_loss = (d["returns"] - res["values"]) ** 2
-        mask = alive.unsqueeze(1)
-        a_l, c_l, ent = masked_mean(a_loss.unsqueeze(1), mask), masked_mean(c_loss, mask), masked_mean(res["entropy"].unsqueeze(1), mask)
-        loss = a_l + self.critic_coef * c_l - self.entropy_coef * ent
+        with torch.autocast(device_type=self.device.type, dtype=torch.float16, enabled=self.mixed_precision):
+            res = self.model.forward_train(d["feat_raw"], d["target_dof_pad"], d["actions"], self.group)
+            # _actor_loss / _critic_loss (common_agent.py:491-520; clip_value False), bound_loss with bounds_loss_coef None = 0
+            ratio = torch.exp(d["old_logp_actions"] - res["prev_neglogp"])
+            a_loss = torch.max(-advantage * ratio, -advantage * torch.clamp(ratio, 1.0 - self.e_clip, 1.0 + self.e_clip))
+            c_loss = (d["returns"] - res["values"]) ** 2
+            mask = alive.unsqueeze(1)
+            a_l, c_l, ent = masked_mean(a_loss.unsqueeze(1), mask), masked_mean(c_loss, mask), masked_mean(res["entropy"].unsqueeze(1), mask)
+            loss = a_l + self.critic_coef * c_l - self.entropy_coef * ent
         params = [p for p in self.model.parameters() if p.requires_grad]
         for p in params:
             p.grad = None
-        loss.backward()
+        (self.scaler.scale(loss) if self.mixed_precision else loss).backward()
+        if self.mixed_precision:
+            self.scaler.unscale_(self.optimizer)
         world = _world(self.group)
         if world > 1:  # data parallel over env shards: one flat all-reduce of the gradients over RCCL, averaged (Horovod's DistributedOptimizer)
             flat = torch.cat([p.grad.reshape(-1) for p in params])
@@ -514,7 +521,11 @@ class PPOAgent:
                 o += p.numel()
         if self.truncate_grads:
             nn.utils.clip_grad_norm_(params, self.grad_norm)
-        self.optimizer.step()
+        if self.mixed_precision:
+            self.scaler.step(self.optimizer)
+            self.scaler.update()
+        else:
+            self.optimizer.step()
         with torch.no_grad():
             kl = (policy_kl(res["mus"].detach(), res["sigmas"].detach(), d["mu"], d["sigma"]) * alive).sum() / alive.numel()
             clip_frac = (torch.abs(ratio.detach() - 1.0) > self.e_clip).float().mean()
