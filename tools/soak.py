@@ -33,4 +33,6 @@ for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 2000):
                                                                             float(task._has_bounce.float().mean()), float(task._has_racket_ball_contact.float().mean()))
         print(i + 1, "finite", ok, "perm ok", okp, "zmin %.3f" % zmin, "alive %.3f" % float((task.reset_buf == 0).float().mean()) + extra)
         bad += (not ok) + (not okp)
+task.check()
+print("substep jobs recomputed after waiting in vain:", task.job_recoveries())
 print("SOAK", "OK" if bad == 0 else "FAILED")
