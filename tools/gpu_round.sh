@@ -31,4 +31,8 @@ V2P_PHASE_TIMING=1 timeout 300 python bench.py --steps 64 --warmup 0 --no-cpu-ba
 V2P_PHASE_HEAVY=1 V2P_PHASE_TIMING=1 timeout 300 python bench.py --steps 64 --warmup 0 --no-cpu-baseline 2>&1 | grep phase > $O/phase_heavy.log
 [ -f variants/libv2p_nowalk.so ] && bash tools/walk_ab.sh > $O/walk_ab.log 2>&1
 python tools/epoch_profile.py --epochs 4 > $O/epoch_profile.txt 2>&1
+timeout 600 python tools/limit_cost.py > $O/limit_cost.txt 2>&1
+timeout 900 python tools/soak.py 6000 2>&1 | tail -4 > $O/soak.log
+timeout 900 python tools/soak.py 6000 racket 2>&1 | tail -4 > $O/soak_racket_ball.log
+timeout 600 python bench.py --ppo --ppo-epochs 60 2> $O/ppo_learning.log > /dev/null
 tail -3 $O/pytest_gpu.log; tail -2 $O/smoke.log; tail -1 $O/bench.log | cut -c1-1500; cut -c1-260 $O/bench_variants.log; tail -1 $O/bench_ppo.log | cut -c1-400; head -8 $O/rocprof_stats.txt
