@@ -75,6 +75,8 @@ def _run_pair(mlib, n, contact, seed, lift=0.0, vel_sigma=0.5, steps=1, hold="fi
     par = default_params(enable_contact=contact)
     par.solver_type = {"pgs": 0, "tgs": 1}[solver]
     par.joint_limits = int(limits)
+    if "limit_margin" in env:
+        par.limit_margin = float(env["limit_margin"])
     if shapes is None:
         oracle = BatchOracle(task.body_model, len(ids_o), par)
     else:  # the oracle of env e simulates the body shape of its clip
