@@ -30,7 +30,13 @@ class MotionLib:
         self._num_dof = self._dof_offsets[-1]
 
         def dev(x, dtype):
-            t = torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x)
+            if torch.is_tensor(x):
+                t = x
+            else:
+                import warnings
+                with warnings.catch_warnings():  # (a read-only mapped file: the tensor is only ever the source of the copy to the device)
+                    warnings.simplefilter("ignore")
+                    t = torch.as_tensor(np.asarray(x))
             return t.to(device=self._device, dtype=dtype).contiguous()
 
         for k in mt.TABLE_KEYS:
@@ -56,6 +62,26 @@ class MotionLib:
         lib = cls(mt.build_tables(clips, body_model.parents, body_model.local_pos), device, **kw)
         lib._single_skeleton = True  # every clip was built on this one skeleton, whatever beta labels the clips carry
         return lib
+
+    @classmethod
+    def from_flat_file(cls, path, device, **kw):
+        """A library saved with `save_flat` (motion_tables.save_flat): the file is memory-mapped and goes to the device table by table."""
+        single = kw.pop("single_skeleton", False)
+        lib = cls(mt.load_flat(path, mmap=True), device, **kw)
+        lib._single_skeleton = single
+        return lib
+
+    def tables(self):
+        """the tables as a dict of numpy arrays (what motion_tables.build_tables returns): for save_flat"""
+        out = {k: getattr(self, k).cpu().numpy() for k in mt.TABLE_KEYS}
+        for k in mt.CLIP_KEYS:
+            v = getattr(self, "_" + k, None) if k != "length_starts" else self.length_starts
+            if v is not None:
+                out[k] = v.cpu().numpy()
+        return out
+
+    def save_flat(self, path):
+        return mt.save_flat(path, self.tables())
 
     def generate_length_starts(self):
         """motion_lib.py:95-99"""

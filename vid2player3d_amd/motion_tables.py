@@ -127,3 +127,55 @@ def build_tables(clips, parents, local_pos):
     starts[0] = 0
     out["length_starts"] = np.cumsum(starts).astype(np.int64)
     return out
+
+
+# ---- one flat, memory-mappable file per motion library -----------------------------------------------------------------------------------
+# (an AMASS-sized library is gigabytes of frame tables: the reference unpickles all of it into host memory, then copies it to the device,
+# `utils/motion_lib.py:67-135`; a mapped file is paged in once, straight into the host-to-device copy, and shared between the ranks of a node)
+FLAT_MAGIC = b"V2PMLIB1"
+_FLAT_ALIGN = 4096
+
+
+def save_flat(path, tables):
+    """tables: the dict of build_tables (or MotionLib.tables()).  Layout: magic 8 B | header length u64 | JSON header {key: [dtype, shape,
+    offset]} | arrays, each at a 4096-byte boundary, C order, little endian."""
+    import json
+
+    keys = [k for k in TABLE_KEYS + CLIP_KEYS if k in tables]
+    arrs = {k: np.ascontiguousarray(np.asarray(tables[k])) for k in keys}
+    header, off = {}, 0
+    for k in keys:
+        header[k] = [arrs[k].dtype.str, list(arrs[k].shape), off]
+        off += -(-arrs[k].nbytes // _FLAT_ALIGN) * _FLAT_ALIGN
+    blob = json.dumps(header).encode()
+    data0 = -(-(16 + len(blob)) // _FLAT_ALIGN) * _FLAT_ALIGN
+    with open(path, "wb") as f:
+        f.write(FLAT_MAGIC)
+        f.write(np.uint64(len(blob)).tobytes())
+        f.write(blob)
+        for k in keys:
+            f.seek(data0 + header[k][2])
+            f.write(arrs[k].tobytes())
+        f.truncate(data0 + off)
+    return path
+
+
+def load_flat(path, mmap=True):
+    """-> dict of arrays; mmap=True: read-only views of the mapped file (np.memmap), nothing is read until it is touched."""
+    import json
+
+    with open(path, "rb") as f:
+        if f.read(8) != FLAT_MAGIC:
+            raise ValueError("%s is not a flat motion library (bad magic)" % path)
+        n = int(np.frombuffer(f.read(8), dtype=np.uint64)[0])
+        header = json.loads(f.read(n).decode())
+    data0 = -(-(16 + n) // _FLAT_ALIGN) * _FLAT_ALIGN
+    out = {}
+    for k, (dt, shape, off) in header.items():
+        if mmap:
+            out[k] = np.memmap(path, dtype=np.dtype(dt), mode="r", offset=data0 + off, shape=tuple(shape)) if int(np.prod(shape)) else np.zeros(shape, dtype=np.dtype(dt))
+        else:
+            with open(path, "rb") as f:
+                f.seek(data0 + off)
+                out[k] = np.frombuffer(f.read(int(np.prod(shape)) * np.dtype(dt).itemsize), dtype=np.dtype(dt)).reshape(shape).copy()
+    return out
