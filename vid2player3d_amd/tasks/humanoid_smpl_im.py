@@ -289,6 +289,8 @@ class HumanoidSMPLIM:
             per_clip = self.body_shapes is not None and len(self.body_shapes) == len(clips) and "motion_shape_ids" not in env
             return MotionLib.from_clips(clips, self.body_shapes if per_clip else self.body_model, self.device)
         path = env.get("motion_file")
+        if path and os.path.isfile(path) and path.endswith(".v2pm"):  # the flat, memory-mappable library file (motion_tables.save_flat)
+            return MotionLib.from_flat_file(path, self.device)
         if path and os.path.isfile(path) and path.endswith(".npz"):
             with np.load(path) as z:
                 return MotionLib({k: z[k] for k in z.files}, self.device)
@@ -297,7 +299,7 @@ class HumanoidSMPLIM:
             from ..legacy_motion_lib import load_legacy_motion_lib
 
             return load_legacy_motion_lib(path, self.device, env.get("motion_file_range"))
-        raise RuntimeError("no motion library: pass cfg['env']['motion_lib'] (MotionLib), 'synthetic_motions', a flat .npz 'motion_file' or the "
+        raise RuntimeError("no motion library: pass cfg['env']['motion_lib'] (MotionLib), 'synthetic_motions', a flat .npz / .v2pm 'motion_file' or the "
                            "reference's .pth file / directory of mlib_part_*.pth")
 
     def _allocate_buffers(self):
