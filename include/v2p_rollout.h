@@ -188,9 +188,10 @@ typedef struct {
     int32_t solver_type;        /* contact solver: 0 = projected Gauss-Seidel (default), 1 = temporal Gauss-Seidel with frozen Jacobians
                                  * (sim.physx.solver_type of amass_im.yaml:41 is 1 = TGS in PhysX; see oracle/phys/v2p_phys_oracle.c for
                                  * what either means here).  Link-per-lane schedule only. */
-    int32_t substep_jobs;       /* 1: the physics launch of the link-per-lane schedule is cut into (substep, env pair) jobs that hand the
+    int32_t substep_jobs;       /* 1 (when the env pairs do not fit the GPU's wave slots in one round: > CUs x 8 pairs) or 2 (always): the
+                                 * physics launch of the link-per-lane schedule is cut into (substep, env pair) jobs that hand the
                                  * state over through memory - 4x finer load balancing of the launch; results are bit-identical to 0
-                                 * (one workgroup per env pair runs all substeps).  PGS, contacts on (with or without racket + ball, joint limits). */
+                                 * (one workgroup per env pair runs all substeps).  Every solver / contact setting of the link-per-lane schedule. */
     int32_t job_mono_permille;  /* substep_jobs: share of the env pairs (the heaviest) whose substeps stay in one workgroup; -1 = default (250) */
     int32_t pair_mix_permille;  /* pair_envs_by_load: share of the envs (the heaviest) that share their wave with one of the lightest envs
                                  * instead of with an equally heavy one (a wave costs the union of its two envs' contact structure, and the

@@ -408,7 +408,7 @@ def test_substep_jobs_are_invisible(mlib, n):
     after step, under load (8192 envs = 16384 jobs on ~2048 wave slots: most hand-offs cross workgroups, CUs and XCDs)."""
     outs = []
     for jobs in (False, True):
-        task = make_task(n, mlib, substep_jobs=jobs)
+        task = make_task(n, mlib, substep_jobs=2 * int(jobs))
         g = torch.Generator(device=DEV)
         g.manual_seed(17)
         task.reset_with_times(None, torch.rand(n, device=DEV, generator=g) * 0.8)
@@ -442,7 +442,7 @@ def test_a_job_that_gives_up_waiting_recomputes_and_changes_nothing(mlib, monkey
     for jobs, spins in ((False, None), (True, "0")):
         if spins is not None:
             monkeypatch.setenv("V2P_JOB_TIMEOUT_SPINS", spins)
-        task = make_task(n, mlib, substep_jobs=jobs)
+        task = make_task(n, mlib, substep_jobs=2 * int(jobs))
         g = torch.Generator(device=DEV)
         g.manual_seed(29)
         task.reset_with_times(None, torch.rand(n, device=DEV, generator=g) * 0.8)
@@ -474,7 +474,7 @@ def test_substep_jobs_with_twelve_substeps_per_control_step(mlib):
     n = 4096
     outs = []
     for jobs in (False, True):
-        task = make_task(n, mlib, sim_overrides={"substeps": 6}, substep_jobs=jobs)
+        task = make_task(n, mlib, sim_overrides={"substeps": 6}, substep_jobs=2 * int(jobs))
         assert task.sim_params.substeps * task.control_freq_inv == 12
         g = torch.Generator(device=DEV)
         g.manual_seed(23)

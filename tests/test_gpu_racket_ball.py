@@ -242,7 +242,7 @@ def test_substep_jobs_are_invisible_with_ball(mlib, n, timeout_spins, monkeypatc
     for jobs in (False, True):
         if jobs and timeout_spins is not None:
             monkeypatch.setenv("V2P_JOB_TIMEOUT_SPINS", timeout_spins)
-        task = make_rb_task(n, mlib, substep_jobs=jobs, debug_contacts=0)
+        task = make_rb_task(n, mlib, substep_jobs=2 * int(jobs), debug_contacts=0)
         g = torch.Generator(device=DEV)
         g.manual_seed(23)
         task.reset_with_times(None, torch.rand(n, device=DEV, generator=g) * 0.8)

@@ -374,6 +374,12 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
     }
     e->pair_period = c->pair_envs_by_load ? 1 : 0;
     e->substep_jobs = c->substep_jobs ? 1 : 0;
+    {   // 1 = the engine decides launch by launch: cutting pays once the env pairs no longer fit the GPU's wave slots in one round
+        // (CUs x 4 SIMDs x 3 waves; measured: at <= 2/3 of the slots whole control steps per workgroup are 0.3 ... 8 % faster); 2 = always
+        hipDeviceProp_t prop;
+        e->job_min_blocks = 0;
+        if (c->substep_jobs == 1 && hipGetDeviceProperties(&prop, device) == hipSuccess) e->job_min_blocks = prop.multiProcessorCount * 8;
+    }
     // (mixing trades total work for a shorter critical path: it pays while the launch is as long as its heaviest pair, i.e. up to
     // ~4 env pairs per wave slot; beyond that the launch is throughput bound and pairs of equals are cheaper)
     // (the kernels with joint-limit rows or a ball run 2 waves per SIMD: there pairs of equals measured best, profiles/r02g_racket_ball_sweep.txt)

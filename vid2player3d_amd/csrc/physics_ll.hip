@@ -2430,7 +2430,7 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s, float* actions, int* fuse
     a.job_mono = (int)blocks;
     auto job_grid = [&](int& rc) -> dim3 {
         rc = V2P_OK;
-        const bool cut = env->substep_jobs && env->job_progress && blocks > 1;
+        const bool cut = env->substep_jobs && env->job_progress && blocks > 1 && (int)blocks > env->job_min_blocks;
         if (cut) {
             // substep jobs: one launch of job_mono + nsub x (blocks - job_mono) workgroups, substep-major
             a.job_epoch = ++env->job_epoch;

@@ -144,6 +144,7 @@ struct v2p_env {
     int pair_period;          // 0 = pairing off (v2p_sim_cfg.pair_envs_by_load = 0), else on
     int substeps_per_sim;     // substeps of one simulate() call
     int substep_jobs;         // v2p_sim_cfg.substep_jobs: the physics launch is cut into (substep, env pair) jobs
+    int job_min_blocks;       // ... when it has more env pairs than this (0: always)
     int32_t* job_progress;    // [waves + 1] progress word per wave slot, last = error flag
     float* job_hand;          // [nsub - 1][N][HAND_FLOATS] the state as one substep job hands it to the next (16-byte chunks), a slot per substep
     long job_timeout_spins;   // see PhysArgs

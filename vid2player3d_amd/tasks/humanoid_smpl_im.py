@@ -399,7 +399,8 @@ class HumanoidSMPLIM:
         # PhysX's TGS; the engine's TGS restates the published algorithm with frozen Jacobians, see oracle/phys/v2p_phys_oracle.c)
         c.solver_type = {"pgs": 0, "tgs": 1}[env.get("contact_solver", "pgs")]
         # physics launch cut into (substep, env pair) jobs: finer load balancing, bit-identical results (tests); on by default
-        c.substep_jobs = int(env.get("substep_jobs", True)) if c.solver_type == 0 and c.enable_contact and c.schedule == 0 else 0
+        # (True / 1: the engine cuts launches that do not fit the wave slots in one round; 2: always; every solver / contact setting)
+        c.substep_jobs = int(env.get("substep_jobs", True)) if c.schedule == 0 else 0
         c.job_mono_permille = int(env.get("job_mono_permille", -1))  # -1: the engine's defaults
         c.pair_mix_permille = int(env.get("pair_mix_permille", -1))
         # joint ranges of the MJCF enforced as limit rows (Isaac Gym always enforces them; only the racket arm of the player MJCFs has
