@@ -205,7 +205,7 @@ typedef struct {
                                  * limit row in the contact solver (the racket arm of the player MJCFs; the amass MJCF has none).
                                  * Link-per-lane schedule, PGS, contacts on.  0 (default): ranges are ignored. */
     /* ---- ABI 9 */
-    float limit_margin;         /* radians; < 0 = default (0.05).  A limit row exists in a substep only while its DOF is within reach of the
+    float limit_margin;         /* radians; <= 0 = default (0.05).  A limit row exists in a substep only while its DOF is within reach of the
                                  * limit: C < limit_margin + h * max(0, rate of approach after the unconstrained update v*), C = distance to
                                  * the nearer limit - the speculative activation every other row of the model has (contact_offset for hull
                                  * vertices, the closing distance of a substep for the ball), PhysX's `contactDistance` of a joint limit.

@@ -335,7 +335,7 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
     p.freeze_terminated = c->freeze_terminated_envs;
     p.solver_type = c->solver_type;
     p.joint_limits = c->joint_limits ? 1 : 0;
-    p.limit_margin = c->limit_margin < 0.f ? 0.05f : c->limit_margin;
+    p.limit_margin = c->limit_margin <= 0.f ? 0.05f : c->limit_margin;  // (a zero-initialised cfg gets the default)
     p.context_length = c->context_length; p.context_padding = c->context_padding;
     p.dt = (float)c->control_freq_inv * c->sim_dt;
     memcpy(p.term_heights, c->term_heights, sizeof(p.term_heights));
