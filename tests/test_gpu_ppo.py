@@ -87,3 +87,26 @@ def test_train_epoch_runs_and_improves_nothing_silly(setup):
     assert any(not torch.equal(a, b) for a, b in zip(w0, agent.actor.parameters()))
     assert "fps step" in agent.format_epoch_line(r)
     task.close()
+
+
+def test_train_loop_saves_and_restores_reference_style_checkpoints(setup, tmp_path):
+    """PPOAgent.train (ImitatorAgent.train, im_agent.py:164-269): epochs with the reference's log line, `<name>_latest.pth` in the reference's
+    checkpoint layout; a second agent restored from it rolls out the same epoch."""
+    from tests.test_ppo_reference import AMASS_IM_PARAMS
+    from vid2player3d_amd.ppo import PPOAgent
+
+    _, _, lib = setup
+    task = make_task(128, lib)
+    lines = []
+    agent = PPOAgent.from_config(task, AMASS_IM_PARAMS, units=(64, 32), minibatch_envs=64, mini_epochs=2)
+    agent.save_freq = 1
+    r = agent.train(max_epochs=2, log=lines.append, network_path=str(tmp_path))
+    assert agent.epoch_num == 2 and len(lines) == 2 and "fps step" in lines[0] and np.isfinite(r["step_rewards"])
+    for name in ("Humanoid_latest.pth", "Humanoid_epoch00001.pth", "Humanoid_epoch00002.pth"):
+        assert (tmp_path / name).exists(), name
+    other = PPOAgent.from_config(task, AMASS_IM_PARAMS, units=(64, 32), minibatch_envs=64, mini_epochs=2)
+    other.restore(str(tmp_path / "Humanoid_latest.pth"))
+    assert other.epoch_num == 2 and other.frame == agent.frame
+    for (k, x), (_, y) in zip(agent.model.state_dict().items(), other.model.state_dict().items()):
+        assert torch.equal(x, y), k
+    task.close()

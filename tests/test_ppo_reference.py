@@ -176,3 +176,69 @@ def test_two_ranks_equal_one_process_on_the_concatenated_batch():
     np.testing.assert_allclose(got[0][4], got[1][4])
     v = agent.value_mean_std
     np.testing.assert_allclose(got[0][4], [float(v.running_mean), float(v.running_var), float(v.count)], rtol=1e-9)
+
+
+# ---------------------------------------------------------------- the reference agent's configuration and checkpoint surface
+AMASS_IM_PARAMS = {  # the `params` block of embodied_pose/cfg/amass_im.yaml:55-143, as yaml.safe_load returns it
+    "seed": 7, "algo": {"name": "pose_im_rnn"}, "model": {"name": "pose_im"},
+    "network": {"name": "pose_im_rnn", "separate": True, "use_running_obs": True, "running_obs_type": "ours", "context_padding": 8,
+                "space": {"continuous": {"mu_activation": "None", "sigma_activation": "None", "mu_init": {"name": "default"},
+                                         "sigma_init": {"name": "const_initializer", "val": -1.756}, "fixed_sigma": True, "learn_sigma": False}},
+                "mlp": {"units": [1024, 1024, 512], "activation": "relu", "d2rl": False}},
+    "config": {"name": "Humanoid", "ppo": True, "mixed_precision": False, "normalize_input": False, "normalize_value": True, "normalize_advantage": True,
+               "gamma": 0.99, "tau": 0.95, "learning_rate": "2e-5", "lr_schedule": "constant", "max_epochs": 10000, "save_frequency": 200,
+               "entropy_coef": 0.0, "truncate_grads": True, "grad_norm": 50.0, "e_clip": 0.2, "horizon_length": 32, "minibatch_size": 512,
+               "mini_epochs": 6, "critic_coef": 5, "clip_value": False},
+}
+
+
+def test_agent_from_the_references_yaml_block():
+    from vid2player3d_amd.ppo import PPOAgent
+
+    params = AMASS_IM_PARAMS
+    ref_yaml = "/root/reference/embodied_pose/cfg/amass_im.yaml"
+    if os.path.exists(ref_yaml):  # (build container only) the literal above IS what the reference's file says
+        import yaml
+
+        with open(ref_yaml) as f:
+            real = yaml.safe_load(f)["params"]
+        for blk in ("config", "network"):
+            for k, v in AMASS_IM_PARAMS[blk].items():
+                if k not in ("mlp", "space"):
+                    assert real[blk][k] == v or str(real[blk][k]) == str(v), (blk, k, real[blk][k], v)
+        assert real["network"]["mlp"]["units"] == [1024, 1024, 512] and real["network"]["space"]["continuous"]["sigma_init"]["val"] == -1.756
+        params = real
+    a = PPOAgent.from_config(stub_task(8192), params, units=(32, 16))  # (small MLPs: the test only reads the hyper-parameters)
+    assert (a.horizon_length, a.gamma, a.tau, a.last_lr, a.e_clip, a.critic_coef, a.mini_epochs, a.minibatch_envs, a.grad_norm) == (32, 0.99, 0.95, 2e-5, 0.2, 5, 6, 512, 50.0)
+    assert a.normalize_value and a.normalize_advantage and not a.mixed_precision and a.max_epochs == 10000 and a.save_freq == 200
+    assert float(a.model.sigma[0]) == pytest.approx(-1.756) and a.model.residual_action
+    bad = {**AMASS_IM_PARAMS, "config": {**AMASS_IM_PARAMS["config"], "clip_value": True}}
+    with pytest.raises(NotImplementedError):
+        PPOAgent.from_config(stub_task(), bad)
+
+
+def test_checkpoint_round_trip_with_the_references_names(tmp_path):
+    agent = make_agent()
+    feat = torch.as_tensor(oracle_features(golden_batch()["obses"].numpy(), TR["e0_context_feat"]))
+    agent.set_train()
+    ds = agent.prepare_dataset(golden_batch(), feat_raw=feat)
+    agent.calc_gradients({k: v[:3] for k, v in ds.items()})  # (an optimizer with state, normalisers that have seen data)
+    agent.epoch_num, agent.frame = 17, 17 * 192
+    path = agent.save(str(tmp_path / "Humanoid_latest"))
+    ck = torch.load(path, weights_only=False)
+    # the key names of a reference checkpoint's `model` entry (tests/golden/ppo_trace.npz holds the reference module's own state_dict)
+    assert set(ck["model"]) == set(reference_weights()) and set(ck["reward_mean_std"]) == {"running_mean", "running_var", "count"}
+    other = make_agent()
+    other.restore(path)
+    for (k, x), (_, y) in zip(agent.model.state_dict().items(), other.model.state_dict().items()):
+        assert torch.equal(x, y), k
+    assert torch.equal(agent.model.running_obs.mean, other.model.running_obs.mean) and int(other.model.running_obs.n) == int(agent.model.running_obs.n)
+    assert float(other.value_mean_std.count) == float(agent.value_mean_std.count) and (other.epoch_num, other.frame) == (17, 17 * 192)
+    # both continue identically (the optimizer state came along)
+    ra = agent.calc_gradients({k: v[3:] for k, v in ds.items()})
+    other.set_train()
+    other.dataset = ds
+    rb = other.calc_gradients({k: v[3:] for k, v in ds.items()})
+    assert float(ra["actor_loss"]) == float(rb["actor_loss"])
+    for (k, x), (_, y) in zip(agent.model.state_dict().items(), other.model.state_dict().items()):
+        assert torch.equal(x, y), k

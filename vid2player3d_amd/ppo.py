@@ -568,6 +568,91 @@ class PPOAgent:
                 "step_rewards": acc_h[4] / max(acc_h[3], 1.0), "step_sub_rewards": [s / max(acc_h[3], 1.0) for s in sub_h],
                 "alive_ratio": tail_h[4], "a_loss": tail_h[0], "c_loss": tail_h[1], "kl": tail_h[2], "clip_frac": tail_h[3]}
 
+    # ------------------------------------------------------------------ the reference agent's configuration and checkpoint surface
+    @classmethod
+    def from_config(cls, task, params, group=None, **overrides):
+        """`params`: the `params` block of the reference's yaml (cfg/amass_im.yaml:55-143: `config` = the PPO hyper-parameters rl_games'
+        A2CBase reads, `network` = what ImitatorBuilder reads).  Options this agent does not build are refused, not ignored."""
+        cfg, net = params.get("config", {}), params.get("network", {})
+        space = net.get("space", {}).get("continuous", {})
+        if not space.get("fixed_sigma", True) or space.get("learn_sigma", False):
+            raise NotImplementedError("a learned sigma is not built (cfg/amass_im.yaml: fixed_sigma True, learn_sigma False)")
+        for key, want in (("use_ik", False), ("kinematic_pretrained", False)):
+            if net.get(key, want) != want:
+                raise NotImplementedError("network.%s = %r is not built" % (key, net.get(key)))
+        if not net.get("use_running_obs", False) or net.get("running_obs_type", "rl_game") != "ours":
+            raise NotImplementedError("the in-network observation normaliser is RunningNorm ('use_running_obs: True, running_obs_type: ours', cfg/amass_im.yaml:67-68)")
+        if cfg.get("normalize_input", False) or cfg.get("clip_value", False) or cfg.get("bounds_loss_coef") is not None or cfg.get("lr_schedule", "constant") != "constant":
+            raise NotImplementedError("normalize_input / clip_value / bounds_loss_coef / a learning-rate schedule are not built (off in both reference configs)")
+        kw = dict(horizon_length=cfg.get("horizon_length", 32), gamma=cfg.get("gamma", 0.99), tau=cfg.get("tau", 0.95),
+                  learning_rate=float(cfg.get("learning_rate", 2e-5)), e_clip=cfg.get("e_clip", 0.2), critic_coef=cfg.get("critic_coef", 5.0),
+                  mini_epochs=cfg.get("mini_epochs", 6), minibatch_envs=cfg.get("minibatch_size", 512), grad_norm=cfg.get("grad_norm", 50.0),
+                  truncate_grads=cfg.get("truncate_grads", True), entropy_coef=cfg.get("entropy_coef", 0.0),
+                  normalize_value=cfg.get("normalize_value", True), normalize_advantage=cfg.get("normalize_advantage", True),
+                  mixed_precision=cfg.get("mixed_precision", False), units=tuple(net.get("mlp", {}).get("units", (1024, 1024, 512))),
+                  sigma_init=float(space.get("sigma_init", {}).get("val", -1.756)), residual_action=net.get("residual_action", True),
+                  seed=params.get("seed", 0), group=group)
+        kw.update(overrides)
+        agent = cls(task, **kw)
+        agent.max_epochs, agent.save_freq = int(cfg.get("max_epochs", 10000)), int(cfg.get("save_frequency", 0))
+        agent.config_name = cfg.get("name", "Humanoid")
+        return agent
+
+    def get_full_state_weights(self):
+        """The checkpoint dict of the reference's agent (rl_games A2CBase.get_full_state_weights [1.1.4, from memory] through
+        CommonAgent / ImitatorAgent.restore, im_agent.py:109-112): `model` with the `a2c_network.` names, RunningNorm buffers included,
+        `reward_mean_std` = the value normaliser, optimizer, epoch, frame."""
+        model = {"a2c_network." + k: v.detach().clone() for k, v in self.model.state_dict().items()}
+        model.update({"a2c_network.running_obs." + k: v.detach().clone() for k, v in self.model.running_obs.state_dict().items()})
+        v = self.value_mean_std
+        return {"model": model, "reward_mean_std": {"running_mean": v.running_mean.clone(), "running_var": v.running_var.clone(), "count": v.count.clone()},
+                "optimizer": self.optimizer.state_dict(), "epoch": self.epoch_num, "frame": self.frame, "last_mean_rewards": getattr(self, "last_mean_rewards", -100500)}
+
+    def set_full_state_weights(self, weights, optimizer=True):
+        self.model.load_reference_state_dict(weights["model"])
+        r = weights.get("reward_mean_std")
+        if r is not None:
+            v = self.value_mean_std
+            v.running_mean = torch.as_tensor(r["running_mean"], dtype=torch.float64, device=self.device).reshape(1).clone()
+            v.running_var = torch.as_tensor(r["running_var"], dtype=torch.float64, device=self.device).reshape(1).clone()
+            v.count = torch.as_tensor(r["count"], dtype=torch.float64, device=self.device).reshape(()).clone()
+        if optimizer and "optimizer" in weights:
+            self.optimizer.load_state_dict(weights["optimizer"])
+        self.epoch_num, self.frame = int(weights.get("epoch", 0)), int(weights.get("frame", 0))
+        self.last_mean_rewards = weights.get("last_mean_rewards", -100500)
+
+    def save(self, fn):
+        """rl_games torch_ext.save_checkpoint: `<fn>.pth`"""
+        torch.save(self.get_full_state_weights(), fn + ".pth")
+        return fn + ".pth"
+
+    def restore(self, path):
+        self.set_full_state_weights(torch.load(path, map_location=self.device, weights_only=False))
+
+    def load_pretrained(self, path):
+        """ImitatorAgent.load_pretrained (im_agent.py:114-155) for EmbodyPose checkpoints: the weights and normalisers, not the optimizer"""
+        self.set_full_state_weights(torch.load(path, map_location=self.device, weights_only=False), optimizer=False)
+
+    def train(self, max_epochs=None, log=print, network_path=None):
+        """ImitatorAgent.train (im_agent.py:164-269): epochs of train_epoch with the reference's log line; checkpoints `<name>_latest` /
+        `<name>_epoch%05d` every save_frequency epochs and at the end."""
+        import os
+
+        last = getattr(self, "max_epochs", 10000) if max_epochs is None else self.epoch_num + int(max_epochs)
+        name = getattr(self, "config_name", "Humanoid")
+        r = None
+        while self.epoch_num < last:
+            r = self.train_epoch()
+            self.last_mean_rewards = r["mean_rewards"]
+            if log:
+                log(self.format_epoch_line(r))
+            if network_path and getattr(self, "save_freq", 0) > 0 and self.epoch_num % self.save_freq == 0:
+                self.save(os.path.join(network_path, "%s_latest" % name))
+                self.save(os.path.join(network_path, "%s_epoch%05d" % (name, self.epoch_num)))
+        if network_path:
+            self.save(os.path.join(network_path, "%s_latest" % name))
+        return r
+
     def format_epoch_line(self, r):
         """the reference's per-epoch line (im_agent.py:211-214)"""
         return ("%d\tT_play %.2f\tT_update %.2f\tstep_rewards %.4f %s\teps_len %.2f\talive %.2f\tfps step %d\tfps total %d"
