@@ -430,6 +430,36 @@ def test_substep_jobs_are_invisible(mlib, n):
             assert np.array_equal(x, y), "step %d, tensor %d: %d of %d values differ (max %.3e)" % (k, j, int((x != y).sum()), x.size, float(np.abs(x.astype(np.float64) - y).max()))
 
 
+@pytest.mark.parametrize("what,env", [("tgs", dict(contact_solver="tgs")), ("pd only", dict(enable_contact=False)), ("limits", dict(joint_limits=True))])
+def test_substep_jobs_are_invisible_in_every_instantiation(mlib, what, env):
+    """TGS, the contact-free kernel and the joint-limit kernel cut into substep jobs (forced: at this size the engine would keep whole
+    control steps per workgroup) == one workgroup per env pair, bit for bit, over several steps incl. the fused post-physics."""
+    n = 1500
+    if what == "limits":
+        from vid2player3d_amd.model import load_baked_model
+        from vid2player3d_amd.racket import with_racket
+
+        env = dict(env, body_model=with_racket(load_baked_model())[0])
+    outs = []
+    for jobs in (0, 2):
+        task = make_task(n, mlib, substep_jobs=jobs, **env)
+        g = torch.Generator(device=DEV)
+        g.manual_seed(31)
+        task.reset_with_times(None, torch.rand(n, device=DEV, generator=g) * 0.8)
+        snaps = []
+        for k in range(6):
+            a = torch.cat([task._target_dof_pos + 0.4 * torch.randn((n, 69), device=DEV, generator=g), 0.3 * torch.randn((n, 6), device=DEV, generator=g)], dim=1).contiguous()
+            task.step(a)
+            snaps.append([N(task._rigid_body_state).copy(), N(task._dof_state).copy(), N(task._contact_forces).copy(), N(task.dof_force_tensor).copy(),
+                          N(task.rew_buf).copy(), N(task.reset_buf).copy(), N(task.obs_buf).copy()])
+        task.check()
+        outs.append(snaps)
+        task.close()
+    for k, (sa, sb) in enumerate(zip(*outs)):
+        for j, (x, y) in enumerate(zip(sa, sb)):
+            assert np.array_equal(x, y), "%s step %d, tensor %d: %d of %d values differ" % (what, k, j, int((x != y).sum()), x.size)
+
+
 def test_a_job_that_gives_up_waiting_recomputes_and_changes_nothing(mlib, monkeypatch):
     """Forward progress of the substep jobs must not rest on the dispatch order.  With the time-out set to zero polls every job whose
     predecessor has not finished at its first look gives up at once and recomputes the pair's earlier substeps itself, while the
