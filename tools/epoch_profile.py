@@ -22,9 +22,11 @@ def main():
     ap.add_argument("--epochs", type=int, default=6)
     ap.add_argument("--num-envs", type=int, default=8192)
     ap.add_argument("--action-noise", type=float, default=0.17)
+    ap.add_argument("--job-mono", type=int, default=None, help="v2p_sim_cfg.job_mono_permille")
+    ap.add_argument("--brief", action="store_true", help="one line: ms of every 4th step")
     args = ap.parse_args()
     n = args.num_envs
-    task = bench.build_task(n, 0, seed=7, substep_jobs=True)
+    task = bench.build_task(n, 0, seed=7, substep_jobs=True, env_extra={} if args.job_mono is None else {"job_mono_permille": args.job_mono})
     from vid2player3d_amd.model import load_baked_model
     parents = np.asarray(load_baked_model().parents)
     dev = task.device
@@ -59,6 +61,9 @@ def main():
             G = (touched & ~cont).sum(1).float()
             kmax[ep - 1, k] = K.max().item(); k99[ep - 1, k] = torch.quantile(K, 0.99).item(); kmean[ep - 1, k] = K.mean().item()
             gmax[ep - 1, k] = G.max().item(); g99[ep - 1, k] = torch.quantile(G, 0.99).item()
+    if args.brief:
+        print("job_mono %s: " % args.job_mono + " ".join("%d:%.3f" % (k, ms[:, k].mean()) for k in range(0, H, 4)) + " 31:%.3f | mean %.4f" % (ms[:, 31].mean(), ms.mean()))
+        return
     print("step  ms/step   touched bodies max / p99 / mean    groups max / p99")
     for k in range(H):
         print("%3d   %.4f    %5.1f %5.1f %5.2f                 %5.1f %5.1f" % (k, ms[:, k].mean(), kmax[:, k].mean(), k99[:, k].mean(), kmean[:, k].mean(), gmax[:, k].mean(), g99[:, k].mean()))

@@ -395,6 +395,7 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
         if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->job_hand, sizeof(float) * HAND_FLOATS * N * (size_t)(p.nsub > 1 ? p.nsub - 1 : 1)), "hipMalloc(job_hand)");
         // ~20 ms: far beyond the longest chain of substeps of a launch.  (V2P_JOB_TIMEOUT_SPINS: tests force the recovery path with 0)
         e->job_timeout_spins = getenv("V2P_JOB_TIMEOUT_SPINS") ? atol(getenv("V2P_JOB_TIMEOUT_SPINS")) : 50000l;
+        e->job_interleave = getenv("V2P_JOB_INTERLEAVE") ? atoi(getenv("V2P_JOB_INTERLEAVE")) : 1;  // (A/B switch)
     }
     if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->pair_key, sizeof(int32_t) * N), "hipMalloc(pair_key)");
     if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->pair_pos, sizeof(int32_t) * N), "hipMalloc(pair_pos)");

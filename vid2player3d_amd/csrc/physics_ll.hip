@@ -331,7 +331,19 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
     const int jcut = JOBS && nblk > a.job_mono ? nblk - a.job_mono : 1;     // pairs that are cut into substep jobs
     const int jrel = JOBS ? jid - a.job_mono : 0;
     const int sjob = mono ? 0 : jrel / jcut;                               // the substep this job runs
-    const int bid = mono ? jid : a.job_mono + jrel % jcut;
+    // Order of the cut pairs within a substep.  Wave slots 0 .. pl_mix - 1 hold a heavy env next to a light one, the slots behind them
+    // pairs of equals in descending rank - and the first of THOSE (two mid-heavy envs: the union of two contact structures) cost as much
+    // as the heavy x light slots in front of them, yet were dispatched behind all of them: they ended every launch (job timeline:
+    // the last 15 % of a launch ran at half occupancy).  The two lists are dispatched alternately, so both kinds of long job start early
+    // and the tail of a substep is made of short ones.  (Only the order of dispatch changes: results are bit-identical.)
+    int jpair = jrel % jcut;
+    if (JOBS && !mono && a.job_interleave) {
+        const int nmix = a.pl_mix > a.job_mono ? (a.pl_mix < nblk ? a.pl_mix : nblk) - a.job_mono : 0;  // cut slots that are heavy x light
+        const int neq = jcut - nmix, both = 2 * (nmix < neq ? nmix : neq);
+        if (jpair < both) jpair = (jpair & 1) ? nmix + (jpair >> 1) : (jpair >> 1);
+        else jpair = nmix < neq ? jpair : jpair - neq;   // the rest of the longer list (neq >= nmix: positions keep their index)
+    }
+    const int bid = mono ? jid : a.job_mono + jpair;
     const int64_t slot = ((int64_t)bid * LL_WPB + (threadIdx.x >> 6)) * 2 + half;
     const bool live_env = slot < N;
     const bool first_job = mono || sjob == 0, last_job = mono || sjob == a.p.nsub - 1;
@@ -2427,6 +2439,7 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s, float* actions, int* fuse
     a.job_progress = env->job_progress;
     a.job_hand = env->job_hand;
     a.job_timeout_spins = env->job_timeout_spins;
+    a.job_interleave = env->job_interleave;
     a.job_mono = (int)blocks;
     auto job_grid = [&](int& rc) -> dim3 {
         rc = V2P_OK;

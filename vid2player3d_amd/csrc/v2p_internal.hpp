@@ -148,6 +148,7 @@ struct v2p_env {
     int32_t* job_progress;    // [waves + 1] progress word per wave slot, last = error flag
     float* job_hand;          // [nsub - 1][N][HAND_FLOATS] the state as one substep job hands it to the next (16-byte chunks), a slot per substep
     long job_timeout_spins;   // see PhysArgs
+    int job_interleave;
     int64_t job_recoveries;   // jobs that gave up waiting and recomputed, as last fetched (v2p_env_check / _check_async)
     int job_epoch;
     int pair_mix_permille;    // share of the envs (the heaviest) that are paired with the lightest ones instead of with each other
