@@ -496,14 +496,18 @@ def test_a_job_that_gives_up_waiting_recomputes_and_changes_nothing(mlib, monkey
             assert np.array_equal(x, y), "step %d, tensor %d: %d of %d values differ (max %.3e)" % (k, j, int((x != y).sum()), x.size, float(np.abs(x.astype(np.float64) - y).max()))
 
 
-def test_substep_jobs_with_twelve_substeps_per_control_step(mlib):
+@pytest.mark.parametrize("job_len", [None, "2", "5"])
+def test_substep_jobs_with_twelve_substeps_per_control_step(mlib, job_len, monkeypatch):
     """sim.substeps 6 x controlFrequencyInv 2 = 12 substeps per control step (vid2player's controller configs,
     vid2player/cfg/*.yaml `substeps: 6`): the progress word of a pair counts launch x (nsub + 1) + substep, so the hand-overs of one
     launch can never satisfy the waits of the next (with the stride fixed at 8 they did from nsub = 9 on).  Jobs on == jobs off, bit
     for bit, over several launches."""
+    # job_len: substeps per job (the engine takes 2 for launches with plenty of jobs; 5: an uneven split of the 12, 5 + 5 + 2)
     n = 4096
     outs = []
     for jobs in (False, True):
+        if jobs and job_len is not None:
+            monkeypatch.setenv("V2P_JOB_LEN", job_len)
         task = make_task(n, mlib, sim_overrides={"substeps": 6}, substep_jobs=2 * int(jobs))
         assert task.sim_params.substeps * task.control_freq_inv == 12
         g = torch.Generator(device=DEV)

@@ -378,7 +378,9 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
         // (CUs x 4 SIMDs x 3 waves; measured: at <= 2/3 of the slots whole control steps per workgroup are 0.3 ... 8 % faster); 2 = always
         hipDeviceProp_t prop;
         e->job_min_blocks = 0;
-        if (c->substep_jobs == 1 && hipGetDeviceProperties(&prop, device) == hipSuccess) e->job_min_blocks = prop.multiProcessorCount * 8;
+        const bool have = hipGetDeviceProperties(&prop, device) == hipSuccess;
+        if (c->substep_jobs == 1 && have) e->job_min_blocks = prop.multiProcessorCount * 8;
+        e->job_len2_blocks = have ? prop.multiProcessorCount * 32 : 8192;
     }
     // (mixing trades total work for a shorter critical path: it pays while the launch is as long as its heaviest pair, i.e. up to
     // ~4 env pairs per wave slot; beyond that the launch is throughput bound and pairs of equals are cheaper)
@@ -395,6 +397,9 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
         if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->job_hand, sizeof(float) * HAND_FLOATS * N * (size_t)(p.nsub > 1 ? p.nsub - 1 : 1)), "hipMalloc(job_hand)");
         // ~20 ms: far beyond the longest chain of substeps of a launch.  (V2P_JOB_TIMEOUT_SPINS: tests force the recovery path with 0)
         e->job_timeout_spins = getenv("V2P_JOB_TIMEOUT_SPINS") ? atol(getenv("V2P_JOB_TIMEOUT_SPINS")) : 50000l;
+        // substeps per job: 1 while the launch is short of jobs, 2 once there are plenty (>= CUs x 32 env pairs: measured crossover at
+        // 16384 envs - a job's prologue / hand-over is ~8 % of a one-substep job); V2P_JOB_LEN: A/B switch
+        e->job_len = getenv("V2P_JOB_LEN") ? atoi(getenv("V2P_JOB_LEN")) : 0;
         e->job_interleave = getenv("V2P_JOB_INTERLEAVE") ? atoi(getenv("V2P_JOB_INTERLEAVE")) : 1;  // (A/B switch)
     }
     if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->pair_key, sizeof(int32_t) * N), "hipMalloc(pair_key)");

@@ -149,6 +149,8 @@ struct v2p_env {
     float* job_hand;          // [nsub - 1][N][HAND_FLOATS] the state as one substep job hands it to the next (16-byte chunks), a slot per substep
     long job_timeout_spins;   // see PhysArgs
     int job_interleave;
+    int job_len;              // substeps per job; 0 = the engine decides (2 for launches of >= job_len2_blocks env pairs, else 1)
+    int job_len2_blocks;
     int64_t job_recoveries;   // jobs that gave up waiting and recomputed, as last fetched (v2p_env_check / _check_async)
     int job_epoch;
     int pair_mix_permille;    // share of the envs (the heaviest) that are paired with the lightest ones instead of with each other
