@@ -464,6 +464,20 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
     const int sub0 = handed ? sjob * jlen : 0, sub1 = mono ? nsub : (nsub ? ((sjob + 1) * jlen < nsub ? (sjob + 1) * jlen : nsub) : 0);
     auto ldin = [&](const float* p) -> float { return handed ? cload(p) : *p; };
 
+    // inputs of the fused pre-physics, REQUESTED here, in front of the hand-over loads (inline asm that waits for its own loads), and used
+    // behind them: the two memory latencies of a job's prologue overlap
+    const bool pre_on = a.actions && valid && live_env;
+    long long pre_reset = 0;
+    float pre_a0 = 0.f, pre_a1 = 0.f, pre_a2 = 0.f, pre_q0 = 0.f, pre_q1 = 0.f, pre_q2 = 0.f;
+    if (pre_on) {
+        pre_reset = a.reset[e];
+        if (b != 0) {
+            const float* ap = a.actions + e * NACT + 3 * (b - 1);
+            const float* qd = a.x_dof + (e * NDOF + 3 * (b - 1)) * 2;
+            pre_a0 = ap[0]; pre_a1 = ap[1]; pre_a2 = ap[2];
+            pre_q0 = qd[0]; pre_q1 = qd[2]; pre_q2 = qd[4];
+        }
+    }
     // ---- state: the root lane carries the root pose/velocity, every other lane its joint
     Q4 q{0.f, 0.f, 0.f, 1.f}, jq{0.f, 0.f, 0.f, 1.f};
     V3 x{0.f, 0.f, 0.f}, w{0.f, 0.f, 0.f}, xd{0.f, 0.f, 0.f}, wt{0.f, 0.f, 0.f}, tar{0.f, 0.f, 0.f};
@@ -515,37 +529,39 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
     // the residual root wrench of the fused step: lanes 0 (force) and 25 (torque) of the env keep it in the PARK_TAR slots of their LDS columns
     // (neither has a joint target)
     float* const wrench_park = park_all + (threadIdx.x >> 6) * LDS_FLOATS_PER_WAVE + base;
-    if (a.actions && valid && live_env) {
+    if (pre_on) {
         // ---- pre-physics fused in (same functions, same rounding as env_pre_kernel below): lane b owns the three action components of
         // its joint, the root lane the residual wrench; dead envs are masked in place on the caller's tensor.  EVERY job of the env derives
         // the PD targets and the wrench itself - from the caller's actions and the exposed state of the start of the step, which nothing
         // overwrites before the env's last job has read them - instead of having the first job hand them over through `ctrl`: 75 dword
         // write-through stores per env, each its own fabric write (PMC: WRITE_SIZE)
-        const bool dead = a.reset[e] == 1;
+        const bool dead = pre_reset == 1;
         if (b != 0) {
             float* ap = a.actions + e * NACT + 3 * (b - 1);
-            float ax = ap[0], ay = ap[1], az = ap[2];
+            float ax = pre_a0, ay = pre_a1, az = pre_a2;
             if (dead) {
                 ax = ay = az = 0.f;
                 if (first_job) { ap[0] = 0.f; ap[1] = 0.f; ap[2] = 0.f; }
             }
-            const float* qd = a.x_dof + (e * NDOF + 3 * (b - 1)) * 2;
             const float lim = P.pd_tar_lim;
-            tar = V3{strict::pd_clamp(ax, qd[0], lim), strict::pd_clamp(ay, qd[2], lim), strict::pd_clamp(az, qd[4], lim)};
+            tar = V3{strict::pd_clamp(ax, pre_q0, lim), strict::pd_clamp(ay, pre_q1, lim), strict::pd_clamp(az, pre_q2, lim)};
             if (first_job) {
                 float* pt = a.pd_target + e * NDOF + 3 * (b - 1);
                 pt[0] = tar.x; pt[1] = tar.y; pt[2] = tar.z;
             }
         } else {
             float* ap = a.actions + e * NACT + NDOF;
-            float af[6];
+            float af[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const bool need_wrench = sub0 < P.hold_sub && !handed;
+            if (!dead && need_wrench) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) af[k] = ap[k];
-            if (dead) {
-#pragma unroll
-                for (int k = 0; k < 6; ++k) { af[k] = 0.f; if (first_job) ap[k] = 0.f; }
+                for (int k = 0; k < 6; ++k) af[k] = ap[k];
             }
-            if (sub0 < P.hold_sub && !handed) {  // (a job past the substeps that hold the wrench has no use for it; a later job is handed it)
+            if (dead && first_job) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) ap[k] = 0.f;
+            }
+            if (need_wrench) {  // (a job past the substeps that hold the wrench has no use for it; a later job is handed it)
                 const float* rq4 = a.x_rb + e * NB * 13 + 3;
                 strict::V3 F, Tq;
                 strict::residual_wrench2(rq4, af, P.res_force_scale, P.res_torque_scale, F, Tq);
