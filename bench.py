@@ -464,7 +464,10 @@ def main():
                                       (", TERMINATED ENVS FROZEN (not reference behaviour)" if args.freeze_terminated else "") + (", STUB TASK (launch-logic test, not a measurement)" if stub else "")),
                        "num_envs_per_gpu": n, "global_envs": world * n, "parallelism": "env-sharded x%d, no data-path collective" % world,
                        "world_size_seen": world_seen, "world_size_matches_gpus": world_seen == args.gpus, "backend": None if dist is None else ("gloo" if stub else "nccl(rccl)"),
-                       "per_rank_env_steps_per_s": per_rank, "alive_fraction_at_end": alive, "substep_jobs": bool(args.substep_jobs)},
+                       "per_rank_env_steps_per_s": per_rank, "alive_fraction_at_end": alive, "substep_jobs": bool(args.substep_jobs),
+                       # (early steps of an epoch - standing humanoids - are lighter than late ones: only whole epochs average like a rollout does)
+                       "timed_steps_cover_whole_epochs": args.steps % HORIZON == 0 and args.warmup % HORIZON == 0,
+                       "timed_epoch_positions": "%d..%d" % (args.warmup % HORIZON, (args.warmup + args.steps - 1) % HORIZON) if args.steps < HORIZON else "all"},
             "roofline": roof,
         }
         if not stub:
