@@ -34,7 +34,7 @@ extern "C" {
 #define V2P_NUM_OBS 461
 #define V2P_MOTION_STATE_DIM 331  /* root_pos3 root_rot4 dof_pos69 root_vel3 root_ang_vel3 dof_vel69 key_pos12 rb_pos72 rb_rot96 */
 #define V2P_CONTEXT_DIM 378       /* body_pos72 body_rot96 dof_pos69 body_pos_gt72 dof_pos_gt69 (humanoid_smpl_im.py:202) */
-#define V2P_ABI_VERSION 9
+#define V2P_ABI_VERSION 10
 
 typedef enum {
     V2P_OK = 0,
@@ -253,6 +253,12 @@ void v2p_env_destroy(v2p_env* e);
  * RSI phases; the caller draws them (MotionLib.sample_time, motion_lib.py:138-159) so that
  * the RNG stays on the Python side.  Fills state, target, obs, context. */
 int v2p_env_reset(v2p_env* e, const int64_t* env_ids, int64_t n, const float* motion_times, void* stream);
+/* HumanoidSMPLIM._init_context(motion_ids, motion_times) on its own (humanoid_smpl_im.py:530-563): the context window of the given envs
+ * rebuilt around motion_times [n] (device) - frames motion_times + dt + dt * (-padding .. length + padding - 1) of each env's own clip -
+ * into context_feat / context_mask, nothing else touched.  The reference's player calls it every context_length steps with the
+ * current clip times (players/im_player.py:238-240): an evaluation rollout runs past the 32-step window without a reset.
+ * V2P_ERR_INVALID when the env was created without a context buffer. */
+int v2p_env_context(v2p_env* e, const int64_t* env_ids, int64_t n, const float* motion_times, void* stream);
 
 /* BaseTask.step(actions) (base_task.py:147-165) = pre_physics_step + _physics_step +
  * post_physics_step.  actions [N,75] is masked IN PLACE for envs whose reset flag is set

@@ -242,3 +242,25 @@ def test_checkpoint_round_trip_with_the_references_names(tmp_path):
     assert float(ra["actor_loss"]) == float(rb["actor_loss"])
     for (k, x), (_, y) in zip(agent.model.state_dict().items(), other.model.state_dict().items()):
         assert torch.equal(x, y), k
+
+
+def test_player_from_the_references_yaml_block():
+    """players/im_player.py + rl_games' BasePlayer defaults [1.1.4, from memory]: 2000 games, deterministic, max_steps 27000"""
+    from vid2player3d_amd.player import ImitatorPlayer
+
+    task = stub_task(16)
+    p = ImitatorPlayer.from_config(task, AMASS_IM_PARAMS, units=(32, 16))
+    assert (p.games_num, p.is_determenistic, p.n_game_life, p.print_stats, p.max_steps, p.config_name) == (2000, True, 1, True, 27000, "Humanoid")
+    assert float(p.model.sigma[0]) == pytest.approx(-1.756) and p.model.residual_action and not p.model.training
+    with_player = {**AMASS_IM_PARAMS, "config": {**AMASS_IM_PARAMS["config"], "player": {"games_num": 5, "determenistic": False, "print_stats": False}}}
+    p = ImitatorPlayer.from_config(task, with_player, units=(32, 16))
+    assert (p.games_num, p.is_determenistic, p.print_stats) == (5, False, False)
+    with pytest.raises(NotImplementedError):
+        ImitatorPlayer.from_config(task, {**AMASS_IM_PARAMS, "config": {**AMASS_IM_PARAMS["config"], "normalize_input": True}})
+    # a checkpoint of the training agent carries what the player loads (im_player.py:43-51: `model`, normalisers inside it)
+    agent = make_agent()
+    q = ImitatorPlayer(stub_task(), units=tuple(int(u) for u in G["units"]))
+    q.set_weights(agent.get_full_state_weights())
+    for (k, x), (_, y) in zip(agent.model.state_dict().items(), q.model.state_dict().items()):
+        assert torch.equal(x, y), k
+    assert float(q.value_mean_std.running_mean) == float(agent.value_mean_std.running_mean)

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "libv2p_rollout.so")
 
 NUM_BODIES, NUM_DOF, NUM_ACTIONS, NUM_OBS = 24, 69, 75, 461
 MOTION_STATE_DIM, CONTEXT_DIM = 331, 378
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 c_f = C.POINTER(C.c_float)
 c_i32 = C.POINTER(C.c_int32)
@@ -100,6 +100,7 @@ def load():
         "v2p_env_create": [vp, vp, C.POINTER(SimCfg), vp, C.c_int64, C.POINTER(EnvBuffers), C.c_int, C.POINTER(vp)],
         "v2p_env_create_shapes": [C.POINTER(vp), C.c_int32, c_i32, vp, C.POINTER(SimCfg), vp, C.c_int64, C.POINTER(EnvBuffers), C.c_int, C.POINTER(vp)],
         "v2p_env_reset": [vp, vp, C.c_int64, vp, vp],
+        "v2p_env_context": [vp, vp, C.c_int64, vp, vp],
         "v2p_env_step": [vp, vp, vp],
         "v2p_env_pre_physics": [vp, vp, vp],
         "v2p_env_physics": [vp, vp],
@@ -132,7 +133,7 @@ def load():
 
 EXPORTED_SYMBOLS = (
     "v2p_model_create", "v2p_model_destroy", "v2p_mlib_create", "v2p_mlib_destroy", "v2p_motion_state", "v2p_reward", "v2p_reset_flags",
-    "v2p_obs_imitation", "v2p_obs_imitation_packed", "v2p_policy_head", "v2p_gae", "v2p_env_create", "v2p_env_create_shapes", "v2p_env_destroy", "v2p_env_reset", "v2p_env_step", "v2p_env_pre_physics", "v2p_env_physics", "v2p_env_export",
+    "v2p_obs_imitation", "v2p_obs_imitation_packed", "v2p_policy_head", "v2p_gae", "v2p_env_create", "v2p_env_create_shapes", "v2p_env_destroy", "v2p_env_reset", "v2p_env_context", "v2p_env_step", "v2p_env_pre_physics", "v2p_env_physics", "v2p_env_export",
     "v2p_env_post_physics", "v2p_env_push_state", "v2p_env_target_index", "v2p_env_set_schedule", "v2p_env_debug_contacts", "v2p_env_debug_contacts_substeps", "v2p_env_debug_pairing", "v2p_env_attach_ball", "v2p_env_check", "v2p_env_check_async", "v2p_env_job_recoveries", "v2p_env_profile_begin", "v2p_env_profile_end", "v2p_last_error", "v2p_abi_version",
 )
 

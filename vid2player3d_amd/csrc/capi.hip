@@ -498,6 +498,13 @@ int v2p_env_reset(v2p_env* e, const int64_t* env_ids, int64_t n, const float* mo
     return launch_env_reset(e, env_ids, env_ids ? n : e->n, motion_times, (hipStream_t)stream);
 }
 
+int v2p_env_context(v2p_env* e, const int64_t* env_ids, int64_t n, const float* motion_times, void* stream) {
+    if (!e || !motion_times || n < 0 || n > e->n) { set_error("v2p_env_context: bad argument"); return V2P_ERR_INVALID; }
+    if (!e->buf.context_feat) { set_error("v2p_env_context: the env was created without a context buffer"); return V2P_ERR_INVALID; }
+    DeviceGuard g(e->device);
+    return launch_env_context(e, env_ids, env_ids ? n : e->n, motion_times, (hipStream_t)stream);
+}
+
 int v2p_env_pre_physics(v2p_env* e, float* actions, void* stream) {
     if (!e || !actions) { set_error("v2p_env_pre_physics: bad argument"); return V2P_ERR_INVALID; }
     DeviceGuard g(e->device);

@@ -387,13 +387,17 @@ int launch_env_reset(v2p_env* env, const int64_t* env_ids, int64_t n, const floa
     hipLaunchKernelGGL(env_reset_kernel, dim3(blocks), dim3(EB_BLOCK), 0, s, v, env_ids, n, motion_times);
     int rc = check_hip(hipGetLastError(), "env_reset_kernel");
     if (rc) return rc;
-    if (env->buf.context_feat) {
-        int64_t q = n * (env->p.context_length + 2 * env->p.context_padding);
-        unsigned cb = (unsigned)((q + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK);
-        hipLaunchKernelGGL(env_context_kernel, dim3(cb), dim3(EB_BLOCK), 0, s, v, env_ids, n, motion_times);
-        rc = check_hip(hipGetLastError(), "env_context_kernel");
-    }
+    if (env->buf.context_feat) rc = launch_env_context(env, env_ids, n, motion_times, s);
     return rc;
+}
+
+int launch_env_context(v2p_env* env, const int64_t* env_ids, int64_t n, const float* motion_times, hipStream_t s) {
+    if (n <= 0) return V2P_OK;
+    EnvView v = make_view(env);
+    int64_t q = n * (env->p.context_length + 2 * env->p.context_padding);
+    unsigned cb = (unsigned)((q + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK);
+    hipLaunchKernelGGL(env_context_kernel, dim3(cb), dim3(EB_BLOCK), 0, s, v, env_ids, n, motion_times);
+    return check_hip(hipGetLastError(), "env_context_kernel");
 }
 
 // (pre-physics, humanoid_smpl_im.py:125-157, lives in physics_ll.hip: one implementation, compiled once with precise semantics,

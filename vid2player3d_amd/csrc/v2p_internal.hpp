@@ -210,6 +210,7 @@ int launch_policy_head(int64_t n, float* mu, const float* context_feat, int64_t 
 int launch_gae(int64_t horizon, int64_t n, const float* fdones, const float* values, const float* rewards, const float* next_values, float gamma,
                float tau, float* advs, hipStream_t s);
 int launch_env_reset(v2p_env* e, const int64_t* env_ids, int64_t n, const float* motion_times, hipStream_t s);
+int launch_env_context(v2p_env* e, const int64_t* env_ids, int64_t n, const float* motion_times, hipStream_t s);
 int launch_env_pre(v2p_env* e, float* actions, hipStream_t s);
 int launch_env_physics(v2p_env* e, hipStream_t s);
 // actions: fuse pre-physics into the kernel; fused_post (with actions): non-null = post-physics may be fused in as well, *fused_post says whether it was

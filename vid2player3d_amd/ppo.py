@@ -188,7 +188,46 @@ class _Group:
         self.sl = slice(self.lo, self.hi)
 
 
-class PPOAgent:
+class PolicyInference:
+    """The network side of one rollout step, shared by the training agent and the player: needs self.model (ImitatorNetwork),
+    self.obs_enc (ImitationObs), self.value_mean_std, self.normalize_value, self._lib."""
+
+    def _features(self, task, obs, t):
+        """734-d in-network observation of step t (preprocess_input in eval mode: context frame context_padding + t, running statistics
+        applied inside the kernel)"""
+        return self.obs_enc.rollout(obs, task.context_feat, t)
+
+    def _sync_obs_norm(self):
+        rn = self.model.running_obs
+        if rn._seen is None:
+            rn._seen = int(rn.n) > 0
+        if rn._seen:  # (a fresh model does not normalise, running_norm.py:36)
+            self.obs_enc.set_running_stats(rn.mean, rn.std)
+        else:
+            self.obs_enc.set_running_stats(None, None)
+
+    def _value(self, feat):
+        value = self.model.critic(feat)
+        if self.normalize_value:
+            value = self.value_mean_std(value, True)
+        return value
+
+    def _policy_head(self, task, mu, noise, t):
+        """models/im_network_builder.py:226-228 + models/im_models.py:42-46 in one kernel; mu is updated in place"""
+        n = mu.shape[0]
+        action = torch.empty_like(mu)
+        sigma = torch.empty_like(mu)
+        nlp = torch.empty(n, dtype=torch.float32, device=mu.device)
+        ctx = task.context_feat
+        frame = (task.context_padding + int(t)) if self.model.residual_action else -1
+        if frame < 0:
+            raise NotImplementedError("residual_action = False is not built (the reference's default and both configs use True)")
+        _lib.check(self._lib.v2p_policy_head(n, _lib.ptr(mu), _lib.ptr(ctx), ctx.shape[1], frame, _lib.ptr(self.model.sigma), _lib.ptr(noise),
+                                             _lib.ptr(action), _lib.ptr(sigma), _lib.ptr(nlp), _lib.current_stream(mu.device)), "v2p_policy_head")
+        return action, sigma, nlp
+
+
+class PPOAgent(PolicyInference):
     def __init__(self, task, horizon_length=32, gamma=0.99, tau=0.95, learning_rate=2e-5, e_clip=0.2, critic_coef=5.0, mini_epochs=6,
                  minibatch_envs=512, grad_norm=50.0, units=(1024, 1024, 512), sigma_init=-1.756, seed=0, group=None,
                  normalize_value=True, normalize_advantage=True, entropy_coef=0.0, residual_action=True, reuse_next_values=True,
@@ -258,41 +297,6 @@ class PPOAgent:
         self.model.train()
         self.model.running_obs.train()
         self.value_mean_std.train()
-
-    # ------------------------------------------------------------------ network side of the rollout
-    def _features(self, task, obs, t):
-        """734-d in-network observation of step t (preprocess_input in eval mode: context frame context_padding + t, running statistics
-        applied inside the kernel)"""
-        return self.obs_enc.rollout(obs, task.context_feat, t)
-
-    def _sync_obs_norm(self):
-        rn = self.model.running_obs
-        if rn._seen is None:
-            rn._seen = int(rn.n) > 0
-        if rn._seen:  # (a fresh model does not normalise, running_norm.py:36)
-            self.obs_enc.set_running_stats(rn.mean, rn.std)
-        else:
-            self.obs_enc.set_running_stats(None, None)
-
-    def _value(self, feat):
-        value = self.model.critic(feat)
-        if self.normalize_value:
-            value = self.value_mean_std(value, True)
-        return value
-
-    def _policy_head(self, task, mu, noise, t):
-        """models/im_network_builder.py:226-228 + models/im_models.py:42-46 in one kernel; mu is updated in place"""
-        n = mu.shape[0]
-        action = torch.empty_like(mu)
-        sigma = torch.empty_like(mu)
-        nlp = torch.empty(n, dtype=torch.float32, device=mu.device)
-        ctx = task.context_feat
-        frame = (task.context_padding + int(t)) if self.model.residual_action else -1
-        if frame < 0:
-            raise NotImplementedError("residual_action = False is not built (the reference's default and both configs use True)")
-        _lib.check(self._lib.v2p_policy_head(n, _lib.ptr(mu), _lib.ptr(ctx), ctx.shape[1], frame, _lib.ptr(self.model.sigma), _lib.ptr(noise),
-                                             _lib.ptr(action), _lib.ptr(sigma), _lib.ptr(nlp), _lib.current_stream(mu.device)), "v2p_policy_head")
-        return action, sigma, nlp
 
     def get_action_values(self, obs, t, task=None, feat=None, noise=None, value=None):
         """im_agent.py:271-294 (`obs['t']` = t).  feat / value: what `_eval_critic` of the step before has already computed for this

@@ -576,6 +576,10 @@ class HumanoidSMPLIM:
         n = self.num_envs if env_ids is None else env_ids.shape[0]
         _lib.check(self._lib.v2p_env_reset(self._h_env, _lib.ptr(env_ids), n, _lib.ptr(times), self._stream()), "v2p_env_reset")
         self._reset_ref_env_ids = env_ids
+        self._forward_context()
+
+    def _forward_context(self):
+        """The tail of the reference's _init_context (humanoid_smpl_im.py:557-563): a registered model is told the new window."""
         if self.model is not None:
             if not self.is_env_dim_setup:
                 self.model.a2c_network.setup_env_named_dims(self.obs_names, self.obs_shapes, self.obs_dims, self.context_names,
@@ -583,6 +587,22 @@ class HumanoidSMPLIM:
                 self.is_env_dim_setup = True
             with torch.no_grad():
                 self.model.a2c_network.forward_context(self.context_feat, self.context_mask)
+
+    def _init_context(self, motion_ids, motion_times):
+        """HumanoidSMPLIM._init_context (humanoid_smpl_im.py:530-563) on its own: context_feat / context_mask rebuilt around
+        `motion_times` [num_envs] (frames motion_times + dt * (1 - padding ... length + padding)), nothing else touched.  The reference's
+        player calls it every context_length steps with (task._reset_ref_motion_ids, task._cur_ref_motion_times) (players/im_player.py:
+        238-240).  Like the reference's (its `.view(self.num_envs, ...)`) it takes all envs; `motion_ids` must be the envs' own clips -
+        the engine samples each env from the clip it was created with."""
+        if motion_ids is not self._reset_ref_motion_ids:
+            ids = motion_ids.to(device=self.device, dtype=torch.long)
+            if ids.shape != self._reset_ref_motion_ids.shape or not torch.equal(ids, self._reset_ref_motion_ids):
+                raise RuntimeError("_init_context: motion_ids must be the task's _reset_ref_motion_ids (one entry per env)")
+        times = motion_times.to(device=self.device, dtype=torch.float32).contiguous()
+        if tuple(times.shape) != (self.num_envs,):
+            raise RuntimeError("_init_context: motion_times must have one entry per env")
+        _lib.check(self._lib.v2p_env_context(self._h_env, None, self.num_envs, _lib.ptr(times), self._stream()), "v2p_env_context")
+        self._forward_context()
 
     def step(self, actions):
         """BaseTask.step (base_task.py:147-165).  `actions` [N,75] fp32 on this device; rows of envs whose
