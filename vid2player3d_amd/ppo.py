@@ -646,6 +646,9 @@ class PPOAgent(PolicyInference):
         name = getattr(self, "config_name", "Humanoid")
         r = None
         while self.epoch_num < last:
+            for t in self.tasks:
+                if hasattr(t, "pre_epoch"):
+                    t.pre_epoch(self.epoch_num)  # (im_agent.py:180-181)
             r = self.train_epoch()
             self.last_mean_rewards = r["mean_rewards"]
             if log:
