@@ -16,7 +16,8 @@ ranks with no data-path collective ("scaling": "weak").
 
 One JSON line on rank 0, with
   roofline      dominant kernel = physics_ll_kernel.  kernel_ms = its mean duration over the TIMED steps themselves, from HIP
-                events the engine records around every launch on the launch stream (v2p_env_profile_begin/_end).  achieved =
+                events the engine records on the launch stream around one launch in eight, the bracketed position rotating through
+                the epoch (v2p_env_profile_begin_sampled/_end; --kernel-events 1: every launch, which costs 2 %).  achieved =
                 algorithmic HBM bytes of one step (9,896 B per env-step x envs per launch) / kernel_ms against
                 8 TB/s.  The kernel is VALU-issue bound, not HBM bound, so the line also carries valu_frac = fp32 FLOP/s of the
                 kernel / 157.3 TFLOP/s (vector peak), with the FLOPs per launch taken from the committed SQ counter profile
@@ -170,6 +171,16 @@ def make_actions(task, noise):
     return torch.addcmul(noise, tgt75, _ACT_MASK[dev])
 
 
+def make_epoch_actions(task, noise_all, out):
+    """The same stand-in policy for a whole epoch at once, right after the reset: the target DOF positions of step k are frame
+    context_padding + k of the context window the reset has just built (what the reference's residual policy adds to its mean,
+    im_network_builder.py:226-228) - two elementwise kernels per epoch instead of one per step between the physics launches."""
+    pad = task.context_padding
+    torch.add(noise_all[..., :69], task.context_feat[:, pad:pad + noise_all.shape[0], 168:237].transpose(0, 1), out=out[..., :69])
+    out[..., 69:].copy_(noise_all[..., 69:])
+    return out
+
+
 def cpu_baseline(budget_s=12.0, max_steps=HORIZON, sigma=0.17):
     """The oracle on the host cores, same workload (contacts on, sigma-noise actions around the target pose): per control step ONE
     batched C call for the physics of all sample envs (OpenMP over envs, float64 dense restatement) and the numpy task ops
@@ -304,6 +315,8 @@ def main():
     ap.add_argument("--num-envs", type=int, default=8192, help="envs per GPU")
     ap.add_argument("--no-contact", action="store_true", help="BASELINE config 2 (PD only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-events", type=int, default=8, help="HIP events around one physics launch in K of the timed steps (1 = every launch)")
+    ap.add_argument("--actions-per-step", action="store_true", help="stand-in policy evaluated before every step (one elementwise kernel between the physics launches) instead of once per epoch from the context window")
     ap.add_argument("--action-noise", type=float, default=0.17, help="sigma of the stand-in policy (0.17 = SURVEY 8d; small values = tracking-quality actions, fewer falls)")
     ap.add_argument("--solver", choices=["pgs", "tgs"], default="pgs")
     ap.add_argument("--freeze-terminated", action="store_true", help="opt-in engine feature: terminated envs are not simulated until the epoch reset (not reference behaviour)")
@@ -379,6 +392,10 @@ def main():
     gen.manual_seed(7 + rank)
     ng = n // G
     noise = [args.action_noise * torch.randn((n, 75), device=dev, generator=gen) for _ in range(HORIZON)]
+    per_epoch = not args.actions_per_step and not stub and G == 1
+    if per_epoch:
+        noise_all = torch.stack(noise)
+        epoch_actions = torch.empty_like(noise_all)
     streams = [torch.cuda.Stream(device=dev) for _ in range(G)] if G > 1 else [None]
 
     def sync():
@@ -396,7 +413,9 @@ def main():
             for i in range(nsteps):
                 if i % HORIZON == 0:
                     task.reset()
-                task.step_fused(make_actions(task, noise[i % HORIZON]))
+                    if per_epoch:
+                        make_epoch_actions(task, noise_all, epoch_actions)
+                task.step_fused(epoch_actions[i % HORIZON] if per_epoch else make_actions(task, noise[i % HORIZON]))
             return
         # rollout groups: group g's envs on stream g; the launches of the groups interleave on the GPU (each fills the other's tail)
         main = torch.cuda.current_stream(dev)
@@ -411,10 +430,17 @@ def main():
         for st in streams:
             main.wait_stream(st)
 
+    # (runs too short to meet every position of the epoch with the requested stride bracket more launches: 20 steps -> all of them)
+    ev_stride = max(1, min(args.kernel_events, args.steps // HORIZON))
     run(args.warmup)
     barrier()
     for tk in tasks:
-        tk.profile_begin(args.steps)  # events around the physics kernel of every timed step, recorded by the engine on the launch stream
+        # events around the physics kernel of the timed steps, recorded by the engine on the launch stream: one launch in --kernel-events
+        # (default 8; the bracketed position rotates from epoch to epoch, so every position of the epoch is measured), 1 = every launch
+        if stub:
+            tk.profile_begin(args.steps)
+        else:
+            tk.profile_begin(args.steps, stride=ev_stride, period=HORIZON)
     t0 = time.perf_counter()
     run(args.steps)
     barrier()
@@ -445,7 +471,9 @@ def main():
         roof = {"bound": "hbm", "kernel": "physics_ll_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None if traffic is None else traffic["bytes_per_launch"],
                 "traffic_source": None if traffic is None else traffic["source"], "kernel_ms": phys_ms, "kernel_launches_timed": launches,
-                "kernel_ms_source": "HIP events recorded by the engine around every physics launch of the timed steps (launch stream)",
+                "kernel_ms_source": "HIP events recorded by the engine around %s of the timed steps (launch stream)%s" % (
+                    "every physics launch" if ev_stride == 1 else "one physics launch in %d" % ev_stride,
+                    "" if ev_stride == 1 else "; the bracketed step rotates through the positions of the epoch (two event records cost ~8 us of dispatch per bracketed launch: --kernel-events 1 brackets all, -2 % throughput)"),
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * ng,
                 "note": "the kernel is VALU-issue bound, not HBM bound (DESIGN.md): valu_frac is the fraction that says how good it is"}
         if G > 1:
@@ -461,7 +489,7 @@ def main():
                                    % (n, "PD control only (no contact solve)" if args.no_contact else "full contact %s (4 substeps x 4 iterations)" % args.solver.upper(), HORIZON,
                                       args.action_noise, (", one NON-UNIFORM body shape per clip (64 shapes from vertex clouds)" if args.per_clip_shapes else "") + (", djokovic_im variant" if args.djokovic or args.racket_ball else "") + (", RACKET + BALL in every env (reported separately)" if args.racket_ball else "") + (", joint limits on" if (args.joint_limits if args.joint_limits is not None else args.racket_ball) else "") +
                                       (", %d ROLLOUT GROUPS of %d envs on %d streams (reported separately from the headline)" % (G, ng, G) if G > 1 else "") +
-                                      (", TERMINATED ENVS FROZEN (not reference behaviour)" if args.freeze_terminated else "") + (", STUB TASK (launch-logic test, not a measurement)" if stub else "")),
+                                      (", stand-in policy evaluated once per epoch (targets = context frames)" if per_epoch else ", stand-in policy evaluated before every step") + (", TERMINATED ENVS FROZEN (not reference behaviour)" if args.freeze_terminated else "") + (", STUB TASK (launch-logic test, not a measurement)" if stub else "")),
                        "num_envs_per_gpu": n, "global_envs": world * n, "parallelism": "env-sharded x%d, no data-path collective" % world,
                        "world_size_seen": world_seen, "world_size_matches_gpus": world_seen == args.gpus, "backend": None if dist is None else ("gloo" if stub else "nccl(rccl)"),
                        "per_rank_env_steps_per_s": per_rank, "alive_fraction_at_end": alive, "substep_jobs": bool(args.substep_jobs),

@@ -348,6 +348,10 @@ int v2p_env_attach_ball(v2p_env* e, const v2p_ball_cfg* cfg, const v2p_ball_buff
  * the summed kernel time in milliseconds and the number of launches measured.  bench.py's roofline.kernel_ms comes from here, from
  * the very steps it times. */
 int v2p_env_profile_begin(v2p_env* e, int64_t max_launches);
+/* the same around a SAMPLE of the launches (ABI 10): launch L since _begin is bracketed when L % stride == (L / period) % stride, so
+ * that with period = the steps of an epoch every position of the epoch is measured once in `stride` epochs.  Two event records per
+ * launch cost ~8 us of dispatch on this stack (2 % of a 0.41 ms step): bench.py measures one launch in eight. */
+int v2p_env_profile_begin_sampled(v2p_env* e, int64_t max_launches, int32_t stride, int32_t period);
 int v2p_env_profile_end(v2p_env* e, double* physics_ms_total, int64_t* launches);
 
 /* Substep jobs: a job whose predecessor (the previous substep of its env pair, another workgroup of the launch) does not show up within

@@ -374,3 +374,33 @@ def test_replay_tool_on_the_golden_trace(tmp_path, golden_tables, capsys, monkey
     vals = {line[2:50].strip(): float(line[50:]) for line in out.splitlines() if line.startswith("  ")}
     assert vals["obs"] <= 5e-6 and vals["reward"] <= 1e-4 and vals["reset flags"] == 0 and vals["terminate flags"] == 0
     assert vals["target rb_pos"] <= 5e-6 and vals["actions masked in place"] == 0
+
+
+def test_kernel_time_from_events_around_all_or_a_sample_of_the_launches():
+    """v2p_env_profile_begin / _begin_sampled / _end (bench.py's roofline.kernel_ms): launch L is bracketed when
+    L % stride == (L // period) % stride"""
+    import torch
+
+    from tests.gpu_util import DEV, make_task, synth_tables
+    from vid2player3d_amd.motion_lib import MotionLib
+
+    task = make_task(64, MotionLib(synth_tables(), DEV))
+    task.reset()
+    act = torch.zeros((64, 75), device=DEV)
+    task.profile_begin(100)
+    for _ in range(5):
+        task.step(act)
+    ms_all, n_all = task.profile_end()
+    assert n_all == 5 and 0.0 < ms_all < 1e3
+    task.profile_begin(100, stride=4, period=8)
+    for _ in range(32):  # launches 0, 4 | 9, 13 | 18, 22 | 27, 31: two per 8-step epoch, the position moving on by one every epoch
+        task.step(act)
+    ms, n = task.profile_end()
+    assert n == 8 and 0.0 < ms < 1e3
+    task.profile_begin(3, stride=2, period=1000)  # the cap still holds
+    for _ in range(20):
+        task.step(act)
+    assert task.profile_end()[1] == 3
+    with pytest.raises(RuntimeError):
+        task.profile_begin(10, stride=0)
+    task.close()

@@ -513,7 +513,13 @@ int v2p_env_pre_physics(v2p_env* e, float* actions, void* stream) {
 
 // the physics launch of either schedule, bracketed by events while a measurement is open
 static int physics_launch(v2p_env* e, hipStream_t s, float* actions, int* fused_post = nullptr) {
-    const bool rec = e->prof_ev && e->prof_n < e->prof_cap;
+    // (sampled: launch L of the measurement is bracketed when L % stride == (L / period) % stride - every position of a period-long
+    // epoch is met once in `stride` epochs)
+    bool rec = e->prof_ev && e->prof_n < e->prof_cap;
+    if (e->prof_ev) {
+        const int64_t L = e->prof_seen++;
+        if (e->prof_stride > 1) rec = rec && (L % e->prof_stride) == (L / e->prof_period) % e->prof_stride;
+    }
     if (rec) (void)hipEventRecord(e->prof_ev[2 * e->prof_n], s);
     int rc = e->schedule != 0 ? launch_env_physics(e, s) : launch_env_physics_ll(e, s, actions, fused_post);
     if (rec) { (void)hipEventRecord(e->prof_ev[2 * e->prof_n + 1], s); ++e->prof_n; }
@@ -612,10 +618,15 @@ static void profile_free(v2p_env* e) {
     e->prof_cap = e->prof_n = 0;
 }
 
-int v2p_env_profile_begin(v2p_env* e, int64_t max_launches) {
-    if (!e || max_launches <= 0 || max_launches > (1 << 20)) { set_error("v2p_env_profile_begin: bad argument"); return V2P_ERR_INVALID; }
+int v2p_env_profile_begin(v2p_env* e, int64_t max_launches) { return v2p_env_profile_begin_sampled(e, max_launches, 1, 1); }
+
+int v2p_env_profile_begin_sampled(v2p_env* e, int64_t max_launches, int32_t stride, int32_t period) {
+    if (!e || max_launches <= 0 || max_launches > (1 << 20) || stride < 1 || period < 1) { set_error("v2p_env_profile_begin: bad argument"); return V2P_ERR_INVALID; }
     DeviceGuard g(e->device);
     profile_free(e);
+    e->prof_stride = stride;
+    e->prof_period = period;
+    e->prof_seen = 0;
     e->prof_ev = new (std::nothrow) hipEvent_t[2 * max_launches]();
     if (!e->prof_ev) { set_error("v2p_env_profile_begin: out of host memory"); return V2P_ERR_NOMEM; }
     e->prof_cap = max_launches;

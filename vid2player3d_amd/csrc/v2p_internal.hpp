@@ -162,6 +162,8 @@ struct v2p_env {
     int err_pending;
     hipEvent_t* prof_ev;      // 2 events per measured physics launch (v2p_env_profile_begin), else NULL
     int64_t prof_cap, prof_n;
+    int64_t prof_seen;        // physics launches since v2p_env_profile_begin
+    int32_t prof_stride, prof_period;  // which of them are bracketed (v2p_env_profile_begin_sampled)
     int pair_have;            // the last physics launch left (key, pos, start) that have not been scattered into perm yet
 };
 

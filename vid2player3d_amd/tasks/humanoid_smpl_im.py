@@ -690,9 +690,10 @@ class HumanoidSMPLIM:
                           "dispatched in index order?): results are unaffected, the launches lose time; cfg env substep_jobs=False avoids it" % n)
             self._job_recoveries_seen = n
 
-    def profile_begin(self, max_launches):
-        """HIP events around every physics-kernel launch from now on (engine side, on the launch stream)."""
-        _lib.check(self._lib.v2p_env_profile_begin(self._h_env, int(max_launches)), "v2p_env_profile_begin")
+    def profile_begin(self, max_launches, stride=1, period=1):
+        """HIP events around the physics-kernel launches from now on (engine side, on the launch stream): all of them, or launch L when
+        L % stride == (L // period) % stride (period = steps per epoch: every position of the epoch once in `stride` epochs)."""
+        _lib.check(self._lib.v2p_env_profile_begin_sampled(self._h_env, int(max_launches), int(stride), int(period)), "v2p_env_profile_begin_sampled")
 
     def profile_end(self):
         """(summed physics-kernel milliseconds, launches measured) since profile_begin; synchronises."""
