@@ -404,3 +404,23 @@ def test_kernel_time_from_events_around_all_or_a_sample_of_the_launches():
     with pytest.raises(RuntimeError):
         task.profile_begin(10, stride=0)
     task.close()
+
+
+def test_context_frames_are_the_targets_of_the_steps():
+    """What bench.py's per-epoch stand-in policy (and the reference's residual action, im_network_builder.py:226-228) relies on: frame
+    context_padding + k of the window built by the reset holds the target DOF positions of step k (same clip, same time up to the
+    rounding of the accumulated clock)."""
+    import torch
+
+    from tests.gpu_util import DEV, make_task, synth_tables
+    from vid2player3d_amd.motion_lib import MotionLib
+
+    task = make_task(128, MotionLib(synth_tables(), DEV))
+    torch.manual_seed(0)
+    task.reset()
+    pad, worst = task.context_padding, 0.0
+    for k in range(task.context_length):
+        worst = max(worst, float((task._target_dof_pos - task.context_feat[:, pad + k, 168:237]).abs().max()))
+        task.step((0.1 * torch.randn(128, 75, device=DEV)).contiguous())
+    assert worst < 1e-5, worst
+    task.close()
