@@ -36,13 +36,10 @@ from ref_shim import rl_games_restated as RG  # noqa: E402
 RG.register()
 
 import torch  # noqa: E402
-import torch.nn as nn  # noqa: E402
 from torch import optim  # noqa: E402
 
 import agents.im_agent as A  # noqa: E402
 import models.im_models as IM  # noqa: E402
-import models.im_network_builder as NB  # noqa: E402
-from models.running_norm import RunningNorm  # noqa: E402
 from utils.tools import AverageMeter  # noqa: E402
 
 Agent = A.ImitatorAgent
