@@ -424,3 +424,22 @@ def test_context_frames_are_the_targets_of_the_steps():
         task.step((0.1 * torch.randn(128, 75, device=DEV)).contiguous())
     assert worst < 1e-5, worst
     task.close()
+
+
+def test_test_mode_starts_every_clip_at_its_first_frame():
+    """`run.py --test` (humanoid_smpl_im.py:78-81): cfg['args'].test switches the state init to Start (and to the test clips, when named)"""
+    import types
+
+    import torch
+
+    from tests.gpu_util import DEV, synth_tables
+    from vid2player3d_amd.motion_lib import MotionLib
+    from vid2player3d_amd.tasks import HumanoidSMPLIM, default_cfg
+
+    cfg = default_cfg(32, motion_lib=MotionLib(synth_tables(), DEV), sample_first_motions=True, body_shape_mismatch="ignore")
+    cfg["args"] = types.SimpleNamespace(test=True)
+    task = HumanoidSMPLIM(cfg, device_type="cuda", device_id=0)
+    assert task._state_init == HumanoidSMPLIM.StateInit.Start and cfg["env"]["stateInit"] == "Start"
+    task.reset()
+    assert float(task._reset_ref_motion_times.abs().max()) == 0.0 and float(task._cur_ref_motion_times.abs().max()) == 0.0
+    task.close()

@@ -121,6 +121,11 @@ class HumanoidSMPLIM:
         self._pd_control = env.get("pdControl", True)
         if not self._pd_control:
             raise NotImplementedError("pdControl=False (direct torque actuation) is not built; amass_im/djokovic_im use PD targets")
+        if getattr(self.args, "test", False):
+            # `run.py --test` (humanoid_smpl_im.py:78-81): every clip from its first frame, the test clips when the yaml names some
+            env["stateInit"] = "Start"
+            if "test_motion_file" in env:
+                env["motion_file"] = env["test_motion_file"]
         self._state_init = HumanoidSMPLIM.StateInit[env.get("stateInit", "Hybrid")]
         self._hybrid_init_prob = env.get("hybridInitProb", 1.0)
         self.ground_tolerance = env.get("ground_tolerance", 0.0)
