@@ -160,6 +160,17 @@ int v2p_model_create(const v2p_model_desc* d, int device, v2p_model** out) {
             if (h.children[p][0] != p + 1) { set_error("v2p_model_create: links must be in depth-first order (first child of %d is %d)", p, h.children[p][0]); delete m; return V2P_ERR_UNSUPPORTED; }
         }
     }
+    if (h.max_depth > 15) { set_error("v2p_model_create: tree deeper than 15 levels"); delete m; return V2P_ERR_UNSUPPORTED; }
+    h.jump_rounds = 0;
+    while ((1 << h.jump_rounds) <= h.max_depth) ++h.jump_rounds;
+    for (int b = 0; b < NB; ++b) {
+        h.anc_jump[b] = 0;
+        for (int k = 0; k < 4; ++k) {
+            int a = b, steps = 1 << k;
+            while (steps > 0 && a > 0) { a = h.parents[a]; --steps; }
+            h.anc_jump[b] |= ((steps == 0 && b != 0) ? a : 255) << (8 * k);
+        }
+    }
     h.side_depths[0] = 0;
     for (int b = 1; b < NB; ++b) h.side_depths[b] = h.side_depths[h.parents[b]] | ((h.parents[b] != b - 1) ? 1 << h.depth[b] : 0);
     for (int b = 0; b < NB; ++b) {

@@ -242,6 +242,9 @@ constexpr bool PARK2 = V2P_LL_PARK2 != 0;
 #define V2P_LL_PARK3 1
 #endif
 constexpr bool PARK3 = V2P_LL_PARK3 != 0;
+#ifndef V2P_LL_KIN_JUMP
+#define V2P_LL_KIN_JUMP 1     // pass 1 (kinematics) by pointer doubling over the tree instead of level by level
+#endif
 #ifndef V2P_LL_PREFETCH_ROWS
 #define V2P_LL_PREFETCH_ROWS 1
 #endif
@@ -444,6 +447,57 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
     const int cl1 = has1 ? base + c1 : lane, cl2 = has2 ? base + c2 : lane;
     const float aug = MULTI ? a.shape_aug[sid * NB + b] : P.aug[b];
     const int desc = M.desc_mask[b];  // links of the subtree rooted here (self included)
+    const int aj = valid ? M.anc_jump[b] : -1;  // the ancestors 1, 2, 4, 8 levels up, 8 bits each (255 = none): the kinematics by pointer doubling
+    const int jrounds = M.jump_rounds;
+    // Kinematics of the whole tree in jrounds = ceil(log2(depth + 1)) rounds of pointer doubling (4 for the SMPL tree, depth 8) instead of
+    // one step per level: every link holds its pose RELATIVE to the ancestor 2^k levels up (to the world once that ancestor lies above the
+    // root) and composes it with that ancestor's entry - all lanes work in every round, where the level loop has the links of one depth
+    // work and the others wait (~1100 -> ~420 instruction slots per substep).  Poses first, then the velocities the same way:
+    //   w_b = w_A + W,   xd_b = xd_A + w_A x (x_b - x_A) + V       (W, V) of b relative to A;  composing with A's own (W_A, V_A) over A':
+    //   W' = W_A + W,    V' = V_A + W_A x (x_b - x_A) + V
+    // The root's lane holds the world values (the floating base's state) from the start.  qj / wj: the joint's quaternion and rate (body
+    // axes), lp: the joint's offset in the parent's frame.  Out: world pose and velocity of every link, rr = the offset in world axes,
+    // wrel = the joint's rate in world axes.
+    auto kin_jump = [&](Q4& q_, V3& x_, V3& w_, V3& xd_, const Q4& qj, const V3& wj, const V3& lp, V3& rr, V3& wrel) {
+        const bool link = valid && dep >= 1;
+        Q4 Q = link ? qj : q_;
+        V3 X = link ? lp : x_;
+        for (int rd = 0; rd < jrounds; ++rd) {
+            const int al = (aj >> (8 * rd)) & 255;
+            const bool has = al != 255;
+            const int src = has ? base + al : lane;
+            const Q4 Qa = pull(Q, src);
+            const V3 Xa = pull(X, src);
+            if (has) {
+                X = Xa + mul(q2mat(Qa), X);
+                Q = qmul(Qa, Q);
+            }
+        }
+        if (link) {
+            q_ = qnormalize(Q);
+            x_ = X;
+        }
+        const Q4 pq = pull(q_, plane);
+        if (link) {
+            rr = mul(q2mat(pq), lp);
+            wrel = mul(q2mat(q_), wj);
+        }
+        V3 W = link ? wrel : w_, V = link ? V3{0.f, 0.f, 0.f} : xd_;
+        for (int rd = 0; rd < jrounds; ++rd) {
+            const int al = (aj >> (8 * rd)) & 255;
+            const bool has = al != 255;
+            const int src = has ? base + al : lane;
+            const V3 Wa = pull(W, src), Va = pull(V, src), xa = pull(x_, src);
+            if (has) {
+                V = Va + cross(Wa, x_ - xa) + V;
+                W = Wa + W;
+            }
+        }
+        if (link) {
+            w_ = W;
+            xd_ = V;
+        }
+    };
     // opt-in (v2p_sim_cfg.freeze_terminated_envs): an env whose reset flag is set keeps its state; a wave whose two envs are frozen
     // skips the substeps altogether (frozen envs sort to the end of the launch order, so they share waves)
     const bool frozen = P.freeze_terminated && a.reset[e] == 1;
@@ -627,6 +681,17 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
         const V3 lpos{S->local_pos[bo][0], S->local_pos[bo][1], S->local_pos[bo][2]};
         // ================================================================ pass 1: kinematics, root -> leaves by level
         V3 zw{0.f, 0.f, 0.f}, zv{0.f, 0.f, 0.f};
+#if V2P_LL_KIN_JUMP
+        {
+            V3 wrel{0.f, 0.f, 0.f};
+            kin_jump(q, x, w, xd, jq, wt, lpos, r, wrel);
+            if (valid && dep >= 1) {
+                const V3 pw = w - wrel, wpr = cross(pw, r);
+                zw = cross(pw, wrel);
+                zv = cross(pw, wpr);
+            }
+        }
+#else
         for (int d = 1; d <= maxd; ++d) {
             const bool nc = (nonchain >> d) & 1;
             Q4 pq = pp(q, nc);
@@ -643,6 +708,7 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                 zv = cross(pw, wpr);
             }
         }
+#endif
         // (racket + ball: the ball lane and the ball x hull narrow phase run HERE, right after the kinematics, where a lane holds little
         // more than its pose and velocity: further down, next to the link's inertia blocks, their temporaries did not fit)
         if (BALL) {
@@ -2135,6 +2201,12 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
     // ==================================================================== final kinematics -> state, rigid-body state, dof_pos
     // (JOBS: only the job of the last substep produces the exposed tensors and the pairing keys; the others hand the state over)
     const V3 lpos{S->local_pos[bo2][0], S->local_pos[bo2][1], S->local_pos[bo2][2]};
+#if V2P_LL_KIN_JUMP
+    if (last_job) {
+        V3 rr{0.f, 0.f, 0.f}, wrel{0.f, 0.f, 0.f};
+        kin_jump(q, x, w, xd, jq, wt, lpos, rr, wrel);
+    }
+#else
     for (int d = 1; d <= (last_job ? maxd : 0); ++d) {
         const bool nc = (nonchain >> d) & 1;
         Q4 pq = pp(q, nc);
@@ -2147,6 +2219,7 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
             xd = pxd + cross(pw, rr);
         }
     }
+#endif
     if (DIAG && a.wave_times && lane == 0) {
         long long* wt = a.wave_times + ((int64_t)blockIdx.x * LL_WPB + (threadIdx.x >> 6)) * 4;
         wt[0] = wt0; wt[1] = wall_clock64(); wt[2] = ksum * 8 + kdep + 1024 * (long long)tsum + 1048576ll * tmaxs + 1073741824ll * key_pred;

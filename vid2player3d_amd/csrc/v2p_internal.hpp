@@ -54,6 +54,8 @@ struct DevModel {
     int32_t max_hull_count;
     int32_t nonchain_levels;     // bit d set when some link at depth d does not directly follow its parent (parent != link - 1)
     int32_t lam_slot[NB];  // index into the saved-Lambda register sets for branching links (root = 0), -1 otherwise
+    int32_t anc_jump[NB];     // ancestors 1, 2, 4, 8 levels up, 8 bits each (255 = none): kinematics by pointer doubling
+    int32_t jump_rounds;      // ceil(log2(max_depth + 1)), at most 4
     int32_t side_depths[NB];  // bit d set when the ancestor (or self) of the link at depth d is not the FIRST child of its parent
     DevShape shape;
 };
