@@ -19,7 +19,7 @@ One JSON line on rank 0, with
                 events the engine records on the launch stream around one launch in eight, the bracketed position rotating through
                 the epoch (v2p_env_profile_begin_sampled/_end; --kernel-events 1: every launch, which costs 2 %).  achieved =
                 algorithmic HBM bytes of one step (9,896 B per env-step x envs per launch) / kernel_ms against
-                8 TB/s.  The kernel is VALU-issue bound, not HBM bound, so the line also carries valu_frac = fp32 FLOP/s of the
+                8 TB/s.  The kernel is bound by the dependent VALU / LDS chains of its waves, not by HBM, so the line also carries valu_frac = fp32 FLOP/s of the
                 kernel / 157.3 TFLOP/s (vector peak), with the FLOPs per launch taken from the committed SQ counter profile
                 (labelled "from_profiles"); `traffic` (HBM bytes per launch, PMC) is "from_profiles" as well.
   cpu_baseline  the oracle timed on this host's cores on a bounded sample of the same workload (rank 0, N=1 only): the C float64
@@ -475,7 +475,7 @@ def main():
                     "every physics launch" if ev_stride == 1 else "one physics launch in %d" % ev_stride,
                     "" if ev_stride == 1 else "; the bracketed step rotates through the positions of the epoch (two event records cost ~8 us of dispatch per bracketed launch: --kernel-events 1 brackets all, -2 % throughput)"),
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * ng,
-                "note": "the kernel is VALU-issue bound, not HBM bound (DESIGN.md): valu_frac is the fraction that says how good it is"}
+                "note": "the kernel is bound by the dependent VALU / LDS chains of its waves, not by HBM (DESIGN.md): valu_frac is the fraction that says how good it is"}
         if G > 1:
             roof["note"] += "; %d ROLLOUT GROUPS: the launches of the groups overlap on the GPU, kernel_ms is the duration of one group's launch WHILE the others run" % G
         if valu is not None and n == 8192 and G == 1 and not args.no_contact:
