@@ -689,3 +689,36 @@ def test_freeze_terminated_envs_option(mlib):
             if dead.any():
                 assert not np.array_equal(ref[k][1][dead], ref[k - 1][1][dead])  # the default keeps simulating them
     assert died > 10
+
+
+def test_free_fall_at_full_size(mlib):
+    """A size-independent property at BASELINE's env count: 8192 humanoids in free fall (contacts off, the PD targets at the current pose,
+    no joint motion, no spin) - in every control step every link of every env gains g x dt of vertical velocity and falls by the
+    semi-implicit distance sum_k h (v + k h g), whatever its env's initial velocity."""
+    n = 8192
+    task = make_task(n, mlib, enable_contact=False)
+    torch.manual_seed(1)
+    task.reset()
+    g = torch.Generator(device=DEV)
+    g.manual_seed(5)
+    v = torch.randn((n, 3), device=DEV, generator=g)
+    task._humanoid_root_states[:, 2] += 3.0
+    task._humanoid_root_states[:, 7:10] = v
+    task._humanoid_root_states[:, 10:13] = 0.0
+    task._dof_vel.zero_()
+    task._reset_env_tensors(None)
+    actions = torch.cat([task._dof_pos, torch.zeros((n, 6), device=DEV)], dim=1).contiguous()  # PD target = the current pose: no drive torque
+    nsub, gz = 4, -9.81
+    h = task.dt / nsub
+    x_before = None
+    for step in range(2):
+        task.step(actions.clone())
+        torch.cuda.synchronize()
+        v_after = v + torch.tensor([0.0, 0.0, gz * task.dt], device=DEV)
+        assert (task._rigid_body_vel - v_after[:, None, :]).abs().max() < 2e-4
+        assert task._rigid_body_ang_vel.abs().max() < 2e-4 and task._dof_vel.abs().max() < 2e-4
+        if x_before is not None:  # (the rigid-body tensor of before the first step still shows the clip's pose, not the engine's)
+            fall = sum(h * (v + torch.tensor([0.0, 0.0, gz * h * (k + 1)], device=DEV)) for k in range(nsub))
+            assert (task._rigid_body_pos - x_before - fall[:, None, :]).abs().max() < 2e-5
+        x_before, v = task._rigid_body_pos.clone(), v_after
+    task.close()
