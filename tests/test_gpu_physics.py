@@ -722,3 +722,28 @@ def test_free_fall_at_full_size(mlib):
             assert (task._rigid_body_pos - x_before - fall[:, None, :]).abs().max() < 2e-5
         x_before, v = task._rigid_body_pos.clone(), v_after
     task.close()
+
+
+def test_rest_contact_supports_the_weight_at_full_size(mlib):
+    """Another property that needs no reference: 8192 humanoids dropped flat from the default pose (root 0.89 m up, joints at zero) come
+    to rest on the plane - no sinking, no creeping, and the exposed net contact forces (those of the step's last substep) carry the
+    weight: within 15 % in every step, within 5 % averaged over 15 steps."""
+    from vid2player3d_amd.model import load_baked_model
+
+    n = 8192
+    task = make_task(n, mlib, stateInit="Default")
+    task.reset()
+    weight = load_baked_model().total_mass * 9.81
+    act = torch.zeros((n, 75), device=DEV)
+    ratios, heights = [], []
+    for k in range(30):
+        task.step(act.clone())
+        if k >= 15:
+            ratios.append(task._contact_forces[..., 2].sum(dim=1) / weight)
+            heights.append(task._rigid_body_pos[:, 0, 2].clone())
+    r, z = torch.stack(ratios), torch.stack(heights)
+    assert torch.isfinite(r).all() and float(r.min()) > 0.85 and float(r.max()) < 1.15, (float(r.min()), float(r.max()))
+    assert abs(float(r.mean()) - 1.0) < 0.05, float(r.mean())
+    assert float((z - z[0]).abs().max()) < 2e-3 and float(z.min()) > 0.05  # lying on the plane, not in it
+    assert float(task._rigid_body_vel.abs().max()) < 0.2
+    task.close()
