@@ -430,13 +430,13 @@ def main():
         for st in streams:
             main.wait_stream(st)
 
-    # (runs too short to meet every position of the epoch with the requested stride bracket more launches: 20 steps -> all of them)
-    ev_stride = 1 if stub else max(1, min(args.kernel_events, args.steps // HORIZON))
+    # (short runs bracket more launches, at least five: 20 steps -> one in four)
+    ev_stride = 1 if stub else max(1, min(args.kernel_events, args.steps // 5))
     run(args.warmup)
     barrier()
     for tk in tasks:
         # events around the physics kernel of the timed steps, recorded by the engine on the launch stream: one launch in --kernel-events
-        # (default 8; the bracketed position rotates from epoch to epoch, so every position of the epoch is measured), 1 = every launch
+        # (default 8, fewer in runs of less than 40 steps; the bracketed position rotates from epoch to epoch, so every position of the epoch is measured), 1 = every launch
         if stub:
             tk.profile_begin(args.steps)
         else:
