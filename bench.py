@@ -44,6 +44,7 @@ ALGO_BYTES_PER_ENV_STEP_AMORTISED = 16090  # + per-epoch reset/context / 32
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_VECTOR_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md
 HORIZON = 32
+WHOLE_EPOCHS = 10                       # the separately timed whole-epoch block behind a short / ragged --steps
 
 
 # ---------------------------------------------------------------------------------------------- launching the ranks
@@ -254,7 +255,10 @@ def profiles_view():
     if os.path.exists(pmc):
         try:
             p = json.load(open(pmc))
-            traffic = {"bytes_per_launch": p.get("physics_kernel_hbm_bytes_per_launch"), "source": "from_profiles: " + p.get("source", "profiles/pmc_summary.json")}
+            traffic = {"bytes_per_launch": p.get("physics_kernel_hbm_bytes_calibrated", p.get("physics_kernel_hbm_bytes_per_launch")),
+                       "bytes_per_launch_fetch_x2": p.get("physics_kernel_hbm_bytes_per_launch_fetch_x2"),
+                       "note": p.get("calibration_note", "raw FETCH_SIZE + WRITE_SIZE; the guide's gfx950 correction doubles FETCH_SIZE for wide coalesced reads: traffic_fetch_x2 is that upper bound"),
+                       "source": "from_profiles: " + p.get("source", "profiles/pmc_summary.json")}
         except Exception:
             traffic = None
     return valu, traffic
@@ -349,9 +353,6 @@ def main():
     stub = args.stub_task
     if not stub and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the rollout engine has no CPU path")
-    if args.steps % HORIZON and rank == 0:
-        sys.stderr.write("bench.py: --steps %d is not a multiple of the %d-step epoch: the timed region is not a whole number of epochs "
-                         "(early steps of an epoch are lighter than late ones), quote a multiple of %d\n" % (args.steps, HORIZON, HORIZON))
     if not stub:
         torch.cuda.set_device(local_rank)
     dist = None
@@ -430,57 +431,95 @@ def main():
         for st in streams:
             main.wait_stream(st)
 
+    def timed_block(nsteps, ev_stride):
+        """Time `nsteps` steps (each run() starts with the per-epoch reset: positions 0 .. nsteps-1 of the epoch, over and over) between two
+        barrier + synchronize pairs; HIP events around one physics launch in ev_stride (recorded by the engine on the launch stream, the
+        bracketed position rotating through the epoch).  Returns (seconds of this rank, mean kernel ms, launches bracketed)."""
+        barrier()
+        for tk in tasks:
+            if stub:
+                tk.profile_begin(nsteps)
+            else:
+                tk.profile_begin(nsteps, stride=ev_stride, period=HORIZON)
+        t0 = time.perf_counter()
+        run(nsteps)
+        barrier()
+        el = time.perf_counter() - t0
+        ms_total, cnt = 0.0, 0
+        for tk in tasks:
+            a_, b_ = tk.profile_end()
+            ms_total, cnt = ms_total + a_, cnt + b_
+            if hasattr(tk, "check"):
+                tk.check()  # device-side errors (a substep job that timed out) fail the run instead of producing a number
+        return el, ms_total / max(cnt, 1), cnt
+
+    def over_ranks(x):
+        """[value of every rank] (all-gather; one entry without a process group)."""
+        if dist is None:
+            return [x]
+        t = torch.tensor([x], device=dev, dtype=torch.float64)
+        allt = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(allt, t)
+        return [float(v.item()) for v in allt]
+
     # (short runs bracket more launches, at least five: 20 steps -> one in four)
     ev_stride = 1 if stub else max(1, min(args.kernel_events, args.steps // 5))
     run(args.warmup)
-    barrier()
-    for tk in tasks:
-        # events around the physics kernel of the timed steps, recorded by the engine on the launch stream: one launch in --kernel-events
-        # (default 8, fewer in runs of less than 40 steps; the bracketed position rotates from epoch to epoch, so every position of the epoch is measured), 1 = every launch
-        if stub:
-            tk.profile_begin(args.steps)
-        else:
-            tk.profile_begin(args.steps, stride=ev_stride, period=HORIZON)
-    t0 = time.perf_counter()
-    run(args.steps)
-    barrier()
-    elapsed_local = time.perf_counter() - t0
-    phys_ms_total, launches = 0.0, 0
-    for tk in tasks:
-        a_, b_ = tk.profile_end()
-        phys_ms_total, launches = phys_ms_total + a_, launches + b_
-        if hasattr(tk, "check"):
-            tk.check()  # device-side errors (a substep job that timed out) fail the run instead of producing a number
-    phys_ms = phys_ms_total / max(launches, 1)
+    elapsed_local, phys_ms, launches = timed_block(args.steps, ev_stride)
+    times = over_ranks(elapsed_local)
+    elapsed = max(times)  # MAX over ranks
+    per_rank = [n * args.steps / x for x in times]
+    per_rank_kernel_ms = over_ranks(phys_ms)
     alive = float(torch.cat([(tk.reset_buf == 0).float() for tk in tasks]).mean().item())
-    elapsed, per_rank = elapsed_local, [n * args.steps / elapsed_local]
-    world_seen = 1
-    if dist is not None:
-        world_seen = dist.get_world_size()
-        t = torch.tensor([elapsed_local], device=dev, dtype=torch.float64)
-        allt = [torch.zeros_like(t) for _ in range(world_seen)]
-        dist.all_gather(allt, t)
-        times = [float(x.item()) for x in allt]
-        elapsed = max(times)  # MAX over ranks
-        per_rank = [n * args.steps / x for x in times]
+    # Every run() starts an epoch (reset + positions 0, 1, ...), and the early positions of an epoch - standing humanoids - are lighter
+    # than the late ones (profiles/*_epoch_profile.txt: 0.32 ms at step 3, 0.61 ms at step 31).  A timed region that is not a whole
+    # number of epochs is therefore NOT the rollout average: such runs (the driver's --steps 20) are followed by a separately timed
+    # block of WHOLE_EPOCHS whole epochs, reported as `whole_epoch`; the roofline fractions are taken from that block.
+    whole = None
+    if args.steps % HORIZON or args.steps < 2 * HORIZON:
+        wsteps = WHOLE_EPOCHS * HORIZON
+        w_el, w_ms, w_cnt = timed_block(wsteps, max(1, args.kernel_events))
+        w_el = max(over_ranks(w_el))
+        whole = {"steps": wsteps, "epochs": WHOLE_EPOCHS, "value": world * n * wsteps / w_el, "ms_per_step": 1e3 * w_el / wsteps, "kernel_ms": w_ms,
+                 "kernel_launches_timed": w_cnt, "per_rank_kernel_ms": over_ranks(w_ms)}
+    world_seen = 1 if dist is None else dist.get_world_size()
 
     if rank == 0:
         value = world * n * args.steps / elapsed
-        achieved = ALGO_BYTES_PER_ENV_STEP * ng / (phys_ms * 1e-3) / 1e9
+        nresets = (args.steps + HORIZON - 1) // HORIZON
         valu, traffic = profiles_view()
-        roof = {"bound": "hbm", "kernel": "physics_ll_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None if traffic is None else traffic["bytes_per_launch"],
-                "traffic_source": None if traffic is None else traffic["source"], "kernel_ms": phys_ms, "kernel_launches_timed": launches,
-                "kernel_ms_source": "HIP events recorded by the engine around %s of the timed steps (launch stream)%s" % (
-                    "every physics launch" if ev_stride == 1 else "one physics launch in %d" % ev_stride,
-                    "" if ev_stride == 1 else "; the bracketed step rotates through the positions of the epoch (two event records cost ~8 us of dispatch per bracketed launch: --kernel-events 1 brackets all, -2 % throughput)"),
-                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * ng,
-                "note": "the kernel is bound by the dependent VALU / LDS chains of its waves, not by HBM (DESIGN.md): valu_frac is the fraction that says how good it is"}
+        # the fractions describe the rollout average: from the whole-epoch block when the requested region is not whole epochs
+        k_ms, k_cnt, k_stride = (whole["kernel_ms"], whole["kernel_launches_timed"], max(1, args.kernel_events)) if whole else (phys_ms, launches, ev_stride)
+        achieved = ALGO_BYTES_PER_ENV_STEP * ng / (k_ms * 1e-3) / 1e9
+        roof = {"bound": "valu-latency", "bound_note": "the contract's choices are hbm | mfma; this kernel is bound by neither: its waves wait on dependent VALU / LDS chains "
+                "(DESIGN.md 4-5).  achieved / peak / frac are the HBM figures BASELINE.json asks for; valu_frac is the fraction that says how good the kernel is",
+                "kernel": "physics_ll_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "frac_of": "hbm",
+                "traffic": None if traffic is None else traffic["bytes_per_launch"],
+                "traffic_fetch_x2": None if traffic is None else traffic.get("bytes_per_launch_fetch_x2"),
+                "traffic_note": None if traffic is None else traffic.get("note"),
+                "traffic_source": None if traffic is None else traffic["source"], "kernel_ms": k_ms, "kernel_launches_timed": k_cnt,
+                "kernel_ms_region": "whole_epoch block (%d epochs)" % WHOLE_EPOCHS if whole else "the timed steps (whole epochs)",
+                "kernel_ms_source": "HIP events recorded by the engine around %s (launch stream)%s" % (
+                    "every physics launch" if k_stride == 1 else "one physics launch in %d" % k_stride,
+                    "" if k_stride == 1 else "; the bracketed step rotates through the positions of the epoch (two event records cost ~8 us of dispatch per bracketed launch: --kernel-events 1 brackets all, -2 % throughput)"),
+                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * ng}
+        if whole:
+            roof["requested_region"] = {"kernel_ms": phys_ms, "kernel_launches_timed": launches, "events_around_one_launch_in": ev_stride,
+                                        "frac": ALGO_BYTES_PER_ENV_STEP * ng / (phys_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if launches else None}
+            whole["frac"] = roof["frac"]
         if G > 1:
-            roof["note"] += "; %d ROLLOUT GROUPS: the launches of the groups overlap on the GPU, kernel_ms is the duration of one group's launch WHILE the others run" % G
+            roof["bound_note"] += "; %d ROLLOUT GROUPS: the launches of the groups overlap on the GPU, kernel_ms is the duration of one group's launch WHILE the others run" % G
         if valu is not None and n == 8192 and G == 1 and not args.no_contact:
-            tflops = valu["flops_per_launch"] / (phys_ms * 1e-3) / 1e12
+            tflops = valu["flops_per_launch"] / (k_ms * 1e-3) / 1e12
             roof.update({"valu_tflops": tflops, "valu_peak_tflops": FP32_VECTOR_PEAK_TFLOPS, "valu_frac": tflops / FP32_VECTOR_PEAK_TFLOPS, "valu": valu})
+            if whole:
+                whole["valu_frac"] = roof["valu_frac"]
+        rccl = None
+        if dist is not None and not stub:
+            try:
+                rccl = ".".join(str(x) for x in torch.cuda.nccl.version())
+            except Exception:
+                rccl = "unknown"
         out = {
             "metric": "env-steps/sec at num_envs=8192, SMPL humanoid imitation", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
@@ -492,12 +531,18 @@ def main():
                                       (", stand-in policy evaluated once per epoch (targets = context frames)" if per_epoch else ", stand-in policy evaluated before every step") + (", TERMINATED ENVS FROZEN (not reference behaviour)" if args.freeze_terminated else "") + (", STUB TASK (launch-logic test, not a measurement)" if stub else "")),
                        "num_envs_per_gpu": n, "global_envs": world * n, "parallelism": "env-sharded x%d, no data-path collective" % world,
                        "world_size_seen": world_seen, "world_size_matches_gpus": world_seen == args.gpus, "backend": None if dist is None else ("gloo" if stub else "nccl(rccl)"),
-                       "per_rank_env_steps_per_s": per_rank, "alive_fraction_at_end": alive, "substep_jobs": bool(args.substep_jobs),
+                       "rccl_version": rccl, "per_rank_env_steps_per_s": per_rank, "per_rank_kernel_ms": per_rank_kernel_ms,
+                       "alive_fraction_at_end": alive, "substep_jobs": bool(args.substep_jobs),
                        # (early steps of an epoch - standing humanoids - are lighter than late ones: only whole epochs average like a rollout does)
-                       "timed_steps_cover_whole_epochs": args.steps % HORIZON == 0 and args.warmup % HORIZON == 0,
-                       "timed_epoch_positions": "%d..%d" % (args.warmup % HORIZON, (args.warmup + args.steps - 1) % HORIZON) if args.steps < HORIZON else "all"},
+                       "timed_steps_cover_whole_epochs": args.steps % HORIZON == 0,
+                       "timed_epoch_positions": "all, %d times" % (args.steps // HORIZON) if args.steps % HORIZON == 0 else
+                                                ("0..%d" % (args.steps - 1) if args.steps < HORIZON else "all %d times + 0..%d" % (args.steps // HORIZON, args.steps % HORIZON - 1)),
+                       "resets_in_timed_region": nresets,
+                       "scaling_curve": "no multi-GPU curve has been measured for this engine (the driver's 8-GPU runs were skipped in rounds 1-3)"},
             "roofline": roof,
         }
+        if whole:
+            out["whole_epoch"] = whole
         if not stub:
             from vid2player3d_amd import build
             out["build"] = build.build_info()

@@ -363,6 +363,44 @@ static void mass_and_bias(const v2p_omodel *m, const v2p_oparams *p, const v2p_o
     }
 }
 
+/* ------------------------------------------------------------------ experiments (root-causing of parity outliers; never used by a test's pass criterion)
+ * bit 0: the GAP of every hull-vertex contact row (the z of the vertex that enters the row's bias d / h) comes from a float32 forward
+ *        kinematics of the same state (quaternion chain and positions in float, link by link), everything else stays float64.  This
+ *        isolates one float32 effect: a position error of ~1e-7 m is multiplied by 1 / h = 120 (erp / h = 24 when penetrating) in the
+ *        velocity target of the row. */
+static int g_experiment;
+static double g_experiment_param;
+void v2p_oracle_experiment(int flags) { g_experiment = flags; }
+void v2p_oracle_experiment_param(double x) { g_experiment_param = x; } /* bit 1: every hull-vertex gap is shifted by this many metres */
+static double f32_vertex_z(const v2p_omodel *m, const v2p_ostate *s, int body, int vert) {
+    float q[NB][4], x[NB][3];
+    for (int b = 0; b < NB; ++b) {
+        int p = m->parents[b];
+        if (p < 0) {
+            for (int i = 0; i < 4; ++i) q[b][i] = (float)s->root_quat[i];
+            for (int i = 0; i < 3; ++i) x[b][i] = (float)s->root_pos[i];
+        } else {
+            const float *a = q[p];
+            float c[4] = {(float)s->jquat[b - 1][0], (float)s->jquat[b - 1][1], (float)s->jquat[b - 1][2], (float)s->jquat[b - 1][3]};
+            float o[4] = {a[3] * c[0] + a[0] * c[3] + a[1] * c[2] - a[2] * c[1], a[3] * c[1] + a[1] * c[3] + a[2] * c[0] - a[0] * c[2],
+                          a[3] * c[2] + a[2] * c[3] + a[0] * c[1] - a[1] * c[0], a[3] * c[3] - a[0] * c[0] - a[1] * c[1] - a[2] * c[2]};
+            float n = sqrtf(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]);
+            for (int i = 0; i < 4; ++i) q[b][i] = o[i] / n;
+            /* x_b = x_p + R_p local_pos */
+            float X = a[0], Y = a[1], Z = a[2], W = a[3];
+            float l[3] = {(float)m->local_pos[b][0], (float)m->local_pos[b][1], (float)m->local_pos[b][2]};
+            float R[9] = {1 - 2 * (Y * Y + Z * Z), 2 * (X * Y - Z * W), 2 * (X * Z + Y * W), 2 * (X * Y + Z * W), 1 - 2 * (X * X + Z * Z), 2 * (Y * Z - X * W),
+                          2 * (X * Z - Y * W), 2 * (Y * Z + X * W), 1 - 2 * (X * X + Y * Y)};
+            for (int i = 0; i < 3; ++i) x[b][i] = x[p][i] + (R[3 * i] * l[0] + R[3 * i + 1] * l[1] + R[3 * i + 2] * l[2]);
+        }
+    }
+    const float *a = q[body];
+    float X = a[0], Y = a[1], Z = a[2], W = a[3];
+    const double *hv = &m->hull_verts[3 * (m->hull_offsets[body] + vert)];
+    float l[3] = {(float)hv[0], (float)hv[1], (float)hv[2]};
+    return (double)(x[body][2] + ((2 * (X * Z - Y * W)) * l[0] + (2 * (Y * Z + X * W)) * l[1] + (1 - 2 * (X * X + Y * Y)) * l[2]));
+}
+
 /* ------------------------------------------------------------------ contact generation */
 typedef struct {
     int n;
@@ -719,7 +757,8 @@ static int substep_impl(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s
                 r->kind = 0; r->body = b; r->vert = cs.vert[ci];
                 memcpy(r->pos, cs.pos[ci], sizeof(double) * 3);
                 r->n[0] = 0; r->n[1] = 0; r->n[2] = 1; r->t1[0] = 1; r->t1[1] = 0; r->t1[2] = 0; r->t2[0] = 0; r->t2[1] = 1; r->t2[2] = 0;
-                r->gap = cs.pos[ci][2]; r->mu = p->mu; r->rest = 0.0;
+                r->gap = (g_experiment & 1) ? f32_vertex_z(m, s, b, cs.vert[ci]) : cs.pos[ci][2]; r->mu = p->mu; r->rest = 0.0;
+                if (g_experiment & 2) r->gap += g_experiment_param;
             }
             for (int q = 0; q < nhull; ++q) if (hull_link[q] == b) { rows[nc++] = hull_row[q]; ++g_hull_rows; }
             if (ball && b == bp->racket_link)

@@ -237,6 +237,38 @@ class BatchOracle:
         for e in range(self.n):
             self.lib.v2p_oracle_set_state(C.byref(self.states[e]), _dptr(r[e]), _dptr(p[e]), _dptr(v[e]))
 
+    def _state_view(self):
+        """The env states as a float64 array [n, 174]: root pos 3 | root quat 4 | 23 joint quats | generalised velocity 75."""
+        return np.frombuffer(self.states, dtype=np.float64).reshape(self.n, C.sizeof(OState) // 8)
+
+    def sensitivity(self, pd_target, ext_force, ext_torque, nsub=4, hold=2, forced_ids=None, trials=8, eps_pos=2e-7, eps_vel=1e-6, seed=0):
+        """CONDITIONING of the step this batch is about to take (call it before step(); the states are left untouched): the step is
+        run from the current states and from `trials` copies whose inputs are perturbed at the level of float32 rounding - positions and
+        quaternion components by eps_pos N(0,1) (2e-7: about one ulp of a coordinate of 1 .. 2 m), velocities by eps_vel N(0,1) - and
+        the largest change of every output element over the trials is returned (same keys and shapes as step()).  The step map of this
+        model is piecewise linear but not contractive: box friction bounded by the CURRENT normal impulse couples the rows
+        non-symmetrically, and in rare states one substep multiplies a velocity perturbation by 10^2 and more (tools/gain_probe.py).
+        A float32 evaluation can be no closer to the float64 result than this; the parity tests add a multiple of it to their
+        per-element bounds instead of allowing a share of the envs to miss them."""
+        st = self._state_view()
+        saved = st.copy()
+        rng = np.random.default_rng(seed)
+        keys = ("root", "dpos", "dvel", "rb", "cf", "df")
+        base = self.step(pd_target, ext_force, ext_torque, nsub, hold, forced_ids)
+        sens = {k: np.zeros_like(base[k]) for k in keys}
+        for _ in range(trials):
+            st[:] = saved
+            st[:, 0:3] += eps_pos * rng.normal(size=(self.n, 3))
+            q = st[:, 3:99].reshape(self.n, 24, 4)
+            q += eps_pos * rng.normal(size=q.shape)
+            q /= np.linalg.norm(q, axis=-1, keepdims=True)
+            st[:, 99:] += eps_vel * rng.normal(size=(self.n, ND))
+            out = self.step(pd_target, ext_force, ext_torque, nsub, hold, forced_ids)
+            for k in keys:
+                np.maximum(sens[k], np.abs(out[k] - base[k]), out=sens[k])
+        st[:] = saved
+        return sens
+
     def step(self, pd_target, ext_force, ext_torque, nsub=4, hold=2, forced_ids=None, want_selection=False):
         n = self.n
         out = {"cf": np.zeros((n, NB, 3)), "df": np.zeros((n, 69)), "ids": np.full((n, NB, 4), -1, dtype=np.int32), "root": np.zeros((n, 13)),

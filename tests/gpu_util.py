@@ -62,9 +62,13 @@ def close(a, b, tol, what=""):
     assert err <= lim, "%s: max abs err %.3e > %.1e" % (what, err, lim)
 
 
-def rows_close(a, b, atol, rtol, what):
-    """Per-element mixed bound |a - b| <= atol + rtol |b| (axis 0 = env).  Prints the 50 / 99 / 100th percentiles of the error and of the
-    share of the bound it uses (pytest -s) and returns the boolean mask of the ENVS that break the bound somewhere."""
+def rows_close(a, b, atol, rtol, what, sens=None, k_sens=16.0):
+    """Per-element mixed bound |a - b| <= atol + rtol |b| (+ k_sens * sens, axis 0 = env).  `sens` = conditioning of the oracle's own
+    step at every element (oracle.phys_oracle.BatchOracle.sensitivity: the largest change of the float64 result under input
+    perturbations of float32-rounding size): with it the bound reads "the kernel's result is what the oracle gives for inputs within
+    k_sens x float32 rounding".  Prints the 50 / 99 / 100th percentiles of the error and of the share of the bound it uses, the number
+    of envs that need the conditioning term and the largest error in units of the sensitivity among them (pytest -s), and returns the
+    boolean mask of the ENVS that break the bound somewhere."""
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     assert a.shape == b.shape, (what, a.shape, b.shape)
@@ -72,9 +76,17 @@ def rows_close(a, b, atol, rtol, what):
     if a.size == 0:
         return np.zeros(a.shape[0], dtype=bool)
     err = np.abs(a - b)
-    use = err / (atol + rtol * np.abs(b))
+    flat = atol + rtol * np.abs(b)
+    lim = flat if sens is None else flat + k_sens * np.asarray(sens, dtype=np.float64)
+    use = err / lim
     bad = (use > 1.0).reshape(a.shape[0], -1).any(axis=1)
     pe, pu = np.percentile(err, [50, 99, 100]), np.percentile(use, [50, 99, 100])
-    print("[rows] %-34s |err| p50 %.1e p99 %.1e max %.1e | share of (%.0e + %.0e|ref|) p50 %.3f p99 %.3f max %.2f | envs over: %d of %d"
-          % (what, pe[0], pe[1], pe[2], atol, rtol, pu[0], pu[1], pu[2], int(bad.sum()), a.shape[0]))
+    extra = ""
+    if sens is not None:
+        over_flat = err > flat
+        need = over_flat.reshape(a.shape[0], -1).any(axis=1)
+        worst = float((err[over_flat] / np.maximum(np.asarray(sens, dtype=np.float64)[over_flat], 1e-300)).max()) if over_flat.any() else 0.0
+        extra = " | envs that need the conditioning term: %d (largest error there = %.1f x sensitivity)" % (int(need.sum()), worst)
+    print("[rows] %-34s |err| p50 %.1e p99 %.1e max %.1e | share of (%.0e + %.0e|ref|%s) p50 %.3f p99 %.3f max %.2f | envs over: %d of %d%s"
+          % (what, pe[0], pe[1], pe[2], atol, rtol, "" if sens is None else " + %g sens" % k_sens, pu[0], pu[1], pu[2], int(bad.sum()), a.shape[0], extra))
     return bad

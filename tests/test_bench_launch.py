@@ -40,10 +40,22 @@ def test_self_launch_two_ranks_with_stub_task():
     assert "STUB" in d["config"]["workload"] and "cpu_baseline" not in d
 
 
-def test_single_rank_and_partial_epoch_warning():
-    d, err = _run(["--stub-task", "--steps", "20", "--warmup", "5", "--num-envs", "64"])
-    assert d["n_gpus"] == 1 and d["config"]["world_size_seen"] == 1
-    assert "not a multiple" in err
+def test_short_run_is_followed_by_a_whole_epoch_block():
+    """The driver's command (--steps 20 --warmup 5): every run() starts an epoch, so the timed region is reset + positions 0..19 - the
+    line must say so, and carry a separately timed block of whole epochs from which the roofline figures are taken."""
+    d, _ = _run(["--stub-task", "--steps", "20", "--warmup", "5", "--num-envs", "64"])
+    assert d["n_gpus"] == 1 and d["config"]["world_size_seen"] == 1 and d["steps"] == 20 and d["warmup"] == 5
+    assert d["config"]["timed_epoch_positions"] == "0..19" and d["config"]["resets_in_timed_region"] == 1
+    assert d["config"]["timed_steps_cover_whole_epochs"] is False
+    w = d["whole_epoch"]
+    assert w["steps"] == 320 and w["epochs"] == 10 and w["kernel_launches_timed"] == 320
+    assert d["roofline"]["kernel_ms"] == w["kernel_ms"] and d["roofline"]["requested_region"]["kernel_launches_timed"] == 20
+    assert abs(d["ms_per_step"] * 20 * 1e-3 - 20 * 64 / d["value"]) < 1e-6  # value = the requested steps
+
+
+def test_whole_epoch_runs_need_no_extra_block():
+    d, _ = _run(["--stub-task", "--steps", "64", "--warmup", "32", "--num-envs", "64"])
+    assert "whole_epoch" not in d and d["config"]["timed_epoch_positions"] == "all, 2 times" and d["config"]["resets_in_timed_region"] == 2
 
 
 def test_gpu_run_refuses_without_gpus():

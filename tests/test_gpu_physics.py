@@ -17,8 +17,6 @@ from tests.gpu_util import DEV, N, T, close, make_task, rows_close, synth_tables
 
 pytestmark = pytest.mark.gpu
 
-# float32 recursion vs float64 dense solve after 4 substeps (velocities are O(1..10), positions O(1))
-TOL_POS, TOL_VEL, TOL_FORCE = 2e-5, 5e-4, 5e-3
 # a selection decision closer than this (metres) is a tie between float32 and float64 evaluation of the same state
 TIE_TOL = 5e-5
 NSUB = 4
@@ -97,11 +95,18 @@ def _run_pair(mlib, n, contact, seed, lift=0.0, vel_sigma=0.5, steps=1, hold="fi
         close(pd_tar, pd_ref, 1e-6, "pd target")
         got = {"root": N(task._humanoid_root_states), "dpos": N(task._dof_pos), "dvel": N(task._dof_vel),
                "rb": N(task._rigid_body_state).reshape(n, 24, 13), "cf": N(task._contact_forces), "df": N(task.dof_force_tensor),
-               "ids": N(task.debug_contacts()), "ids_sub": N(task.debug_contacts_substeps())}
+               "ids": N(task.debug_contacts()), "ids_sub": N(task.debug_contacts_substeps()),
+               # the inputs of the step (tools/parity_sweep.py --dump: outlier envs are re-examined offline with the CPU oracle)
+               "in_root": root if s == 0 else None, "in_dpos": dpos if s == 0 else None, "in_dvel": dvel if s == 0 else None,
+               "pd": pd_tar, "force": force, "torque": torque}
+        got = {k: v for k, v in got.items() if v is not None}
         got = {k: v[ids_o] for k, v in got.items()}
         assert np.array_equal(got["ids_sub"][:, -1], got["ids"])
-        ref = oracle.step(pd_tar[ids_o], force[ids_o], torque[ids_o], nsub=NSUB, hold=2 if hold == "first_sim" else NSUB,
+        hold_n = 2 if hold == "first_sim" else NSUB
+        sens = oracle.sensitivity(pd_tar[ids_o], force[ids_o], torque[ids_o], nsub=NSUB, hold=hold_n, forced_ids=got["ids_sub"] if contact else None, seed=seed + s)
+        ref = oracle.step(pd_tar[ids_o], force[ids_o], torque[ids_o], nsub=NSUB, hold=hold_n,
                           forced_ids=got["ids_sub"] if contact else None, want_selection=True)
+        ref["sens"] = sens
         if contact:
             selection_report(got["ids_sub"], ref["own"], ref["margin"], "%s step %d" % (what or "seed %d" % seed, s))
         out.append((got, ref))
@@ -110,50 +115,45 @@ def _run_pair(mlib, n, contact, seed, lift=0.0, vel_sigma=0.5, steps=1, hold="fi
     return out
 
 
-# velocities and forces are judged PER ELEMENT, |hip - oracle| <= atol + rtol |oracle| (a bound scaled by the largest entry of the whole array
-# would leave the small entries unchecked): float32 O(n) recursion against float64 dense solve after 4 substeps.  Measured (pytest -s prints
-# the percentiles of every comparison, profiles/r03_rows.log): median error 5e-7 .. 2e-6 rad/s, 99th percentile 1e-5 .. 3e-5, isolated
-# entries up to 9e-4 (one env in 50 .. 130, on the velocity of a distal link of a fast chain).  Envs over the bound are counted and named
-# (with the oracle's clamp margin: how far the closest row update of their sweep was from the other branch of its clamp); they must be few
-# and inside the coarse bounds.  (The round-2 explanation of the outliers - a row on its clamp in one arithmetic and off it in the other -
-# does not hold up: their clamp margins, 5e-4 .. 4e-3 m/s, are three orders of magnitude above float32 rounding.)
+# Velocities and forces are judged PER ELEMENT on EVERY env:  |hip - oracle| <= atol + rtol |oracle| + K_SENS * sens,  float32 O(n)
+# recursion against float64 dense solve after 4 substeps.  `sens` is the CONDITIONING of the oracle's own step at that element
+# (BatchOracle.sensitivity: largest change of the float64 result when its inputs are perturbed by float32 rounding - 2e-7 on positions
+# and quaternions, 1e-6 on velocities).  Why it is there (round 4, profiles/r04_parity_*.log, tools/gain_probe.py): the step map of
+# this model is piecewise linear but NOT contractive - box friction bounded by the current normal impulse couples the rows
+# non-symmetrically - and in ~1 % of the perturbed states of these fixtures one substep multiplies a velocity perturbation by 10^2 and
+# more (the float64 oracle does this to itself).  Those envs are exactly the ones that used to miss the flat bound, by the amounts the
+# oracle's sensitivity predicts (error / sens 0.1 .. 9 in every one of 78 dumped outliers), in the precise build
+# (V2P_LL_STRICT_MATH) and in the env-per-lane kernel as often as in the default build.  No share of the envs is exempt any more.
+# Measured (pytest -s prints the percentiles of every comparison): median error 5e-7 .. 2e-6, 99th percentile 1e-5 .. 5e-5.
 VEL_ATOL, VEL_RTOL = 2e-4, 5e-4
 FORCE_ATOL, FORCE_RTOL = 0.05, 1e-3
-MAX_OUTLIER_ENVS = 0.05   # contact-rich fixtures (fallen ragdolls, limit rows + contacts) have 2 such envs in 32 .. 48, the others none
+POS_ATOL = 2e-5
+K_SENS = 16.0   # the kernel's result must be what the oracle gives for inputs within K_SENS x float32 rounding
 
 
-def check_outliers(bad, ref, what, max_frac=MAX_OUTLIER_ENVS):
-    """bad: mask of the envs over the per-element bounds.  Returns the number of outliers."""
-    n, k = bad.shape[0], int(bad.sum())
-    if k:
-        cm = np.asarray(ref["clamp"])[bad]
-        print("[outliers] %s: %d of %d envs over the per-element bounds; their smallest clamp margins: %s" % (what, k, n, np.sort(cm)[:8]))
-        assert k <= max(2, int(np.ceil(max_frac * n))), "%s: %d of %d envs over the per-element bounds" % (what, k, n)
-    return k
+def assert_none_over(bad, what):
+    assert not bad.any(), "%s: %d of %d envs over the per-element bounds (envs %s)" % (what, int(bad.sum()), bad.shape[0], np.nonzero(bad)[0][:8].tolist())
 
 
-def _compare(got, ref, what, tol_force=TOL_FORCE, contact=True):
-    close(got["root"][:, :7], ref["root"][:, :7], TOL_POS, what + " root pose")
-    close(got["dpos"], ref["dpos"], 5e-5, what + " dof_pos")
-    close(got["rb"][..., :3], ref["rb"][..., :3], TOL_POS, what + " rb pos")
-    # quaternion sign is arbitrary
-    qs = np.sign(np.sum(got["rb"][..., 3:7] * ref["rb"][..., 3:7], axis=-1, keepdims=True))
-    close(got["rb"][..., 3:7] * qs, ref["rb"][..., 3:7], TOL_POS, what + " rb rot")
-    # coarse bounds on everything (every env, outliers included) ...
-    close(got["root"][:, 7:], ref["root"][:, 7:], TOL_VEL, what + " root vel")
-    close(got["dvel"], ref["dvel"], TOL_VEL, what + " dof_vel")
-    close(got["rb"][..., 7:], ref["rb"][..., 7:], TOL_VEL, what + " rb vel")
-    close(got["df"], ref["df"], TOL_FORCE, what + " dof force")
+def rows_all(got, ref, what, contact=True, k_sens=K_SENS):
+    """Every per-element comparison of one control step; returns the mask of the envs over a bound."""
+    S = ref["sens"]
+    qs = np.sign(np.sum(got["rb"][..., 3:7] * ref["rb"][..., 3:7], axis=-1, keepdims=True))  # quaternion sign is arbitrary
+    bad = rows_close(got["root"][:, :3], ref["root"][:, :3], POS_ATOL, 0.0, what + " root pos", S["root"][:, :3], k_sens)
+    bad |= rows_close(got["dpos"], ref["dpos"], 5e-5, 0.0, what + " dof_pos", S["dpos"], k_sens)
+    bad |= rows_close(got["rb"][..., :3], ref["rb"][..., :3], POS_ATOL, 0.0, what + " rb pos", S["rb"][..., :3], k_sens)
+    bad |= rows_close(got["rb"][..., 3:7] * qs, ref["rb"][..., 3:7], POS_ATOL, 0.0, what + " rb rot", S["rb"][..., 3:7], k_sens)
+    bad |= rows_close(got["root"][:, 7:], ref["root"][:, 7:], VEL_ATOL, VEL_RTOL, what + " root vel", S["root"][:, 7:], k_sens)
+    bad |= rows_close(got["dvel"], ref["dvel"], VEL_ATOL, VEL_RTOL, what + " dof_vel", S["dvel"], k_sens)
+    bad |= rows_close(got["rb"][..., 7:], ref["rb"][..., 7:], VEL_ATOL, VEL_RTOL, what + " rb vel", S["rb"][..., 7:], k_sens)
+    bad |= rows_close(got["df"], ref["df"], FORCE_ATOL, FORCE_RTOL, what + " dof force", S["df"], k_sens)
     if contact:
-        close(got["cf"], ref["cf"], tol_force, what + " contact force")
-    # ... and the per-element ones
-    bad = rows_close(got["root"][:, 7:], ref["root"][:, 7:], VEL_ATOL, VEL_RTOL, what + " root vel")
-    bad |= rows_close(got["dvel"], ref["dvel"], VEL_ATOL, VEL_RTOL, what + " dof_vel")
-    bad |= rows_close(got["rb"][..., 7:], ref["rb"][..., 7:], VEL_ATOL, VEL_RTOL, what + " rb vel")
-    bad |= rows_close(got["df"], ref["df"], FORCE_ATOL, FORCE_RTOL, what + " dof force")
-    if contact:
-        bad |= rows_close(got["cf"], ref["cf"], FORCE_ATOL, FORCE_RTOL, what + " contact force")
-    return check_outliers(bad, ref, what)
+        bad |= rows_close(got["cf"], ref["cf"], FORCE_ATOL, FORCE_RTOL, what + " contact force", S["cf"], k_sens)
+    return bad
+
+
+def _compare(got, ref, what, contact=True):
+    assert_none_over(rows_all(got, ref, what, contact), what)
 
 
 def test_pd_only_step_matches_oracle(mlib):
@@ -190,7 +190,7 @@ def test_fallen_humanoid_many_contacts_matches_oracle(mlib):
     """Low root height: most bodies touch the plane (worst case for the block Gauss-Seidel sweep); every env compared."""
     (got, ref), = _run_pair(mlib, 32, contact=True, seed=3, lift=-0.75, vel_sigma=0.2, what="fallen")
     assert ((got["ids"] >= 0).any(axis=2).sum(axis=1) >= 6).mean() > 0.5
-    _compare(got, ref, "fallen", tol_force=2e-2)
+    _compare(got, ref, "fallen")
 
 
 def test_tgs_option_matches_oracle(mlib):
@@ -211,10 +211,10 @@ def test_joint_limits_match_oracle(mlib):
 
     bm, _ = with_racket(load_baked_model())
     jw = 3 * (bm.body_index("R_Wrist") - 1)
-    for seed, lift, sig, what, tolf in ((61, 0.0, 0.5, "limits standing", TOL_FORCE), (62, -0.75, 0.2, "limits fallen", 2e-2)):
+    for seed, lift, sig, what in ((61, 0.0, 0.5, "limits standing"), (62, -0.75, 0.2, "limits fallen")):
         pairs = _run_pair(mlib, 48, contact=True, seed=seed, lift=lift, vel_sigma=sig, steps=2, limits=True, body_model=bm, act_sigma=0.5, what=what)
         for got, ref in pairs:
-            _compare(got, ref, what, tol_force=tolf)
+            _compare(got, ref, what)
         (got0, _), = _run_pair(mlib, 48, contact=True, seed=seed, lift=lift, vel_sigma=sig, limits=False, body_model=bm, act_sigma=0.5, what=what + " off")
         moved = np.abs(pairs[0][0]["dvel"][:, jw:jw + 3] - got0["dvel"][:, jw:jw + 3]).max(axis=1)
         print("[limits] %s: wrist rates differ from the run without limits in %d of 48 envs (max %.2f rad/s)" % (what, (moved > 1e-2).sum(), moved.max()))
@@ -261,7 +261,7 @@ def _epoch_against_oracles(lib, tabs, n, steps, seed, sigma, **env):
     ref.reset_all(times)
     close(N(task.obs_buf), ref.obs_buf, 5e-6, "reset obs")
     oracle = BatchOracle(bm, n, default_params())
-    died = outliers = 0
+    died = 0
     for k in range(steps):
         oracle.set_state(N(task._humanoid_root_states), N(task._dof_pos), N(task._dof_vel))
         act = np.concatenate([ref.target[2] + rng.normal(0, sigma, size=(n, 69)), rng.normal(0, sigma, size=(n, 6))], axis=1).astype(np.float32)
@@ -271,27 +271,24 @@ def _epoch_against_oracles(lib, tabs, n, steps, seed, sigma, **env):
         _, pd, _, force, torque = ref.pre_physics_step(act)
         assert np.array_equal(N(a), ref.actions), "in-place action masking of dead envs"
         ids_sub = N(task.debug_contacts_substeps())
+        sens = oracle.sensitivity(pd, force, torque, nsub=NSUB, hold=2, forced_ids=ids_sub, seed=seed + k)
         res = oracle.step(pd, force, torque, nsub=NSUB, hold=2, forced_ids=ids_sub, want_selection=True)
         selection_report(ids_sub, res["own"], res["margin"], "epoch step %d" % k, min_rate=0.985)
         ref.set_sim_state(res["dpos"].astype(np.float32), res["dvel"].astype(np.float32), res["rb"].astype(np.float32))
         ref.post_physics_step()
         rb = N(task._rigid_body_state).reshape(n, 24, 13)
-        # coarse bounds on every env (x3 the one-step ones: the flailing ragdolls of this fixture reach joint rates of tens of rad/s) ...
-        close(rb[..., :3], res["rb"][..., :3], 1e-4, "rb pos, step %d" % k)
-        close(rb[..., 7:], res["rb"][..., 7:], 3 * TOL_VEL, "rb vel, step %d" % k)
-        close(N(task._dof_vel), res["dvel"], 3 * TOL_VEL, "dof vel, step %d" % k)
-        # ... the per-element bounds on all but a few, and those few named and counted
-        bad = rows_close(rb[..., 7:], res["rb"][..., 7:], VEL_ATOL, VEL_RTOL, "epoch step %d rb vel" % k)
-        bad |= rows_close(N(task._dof_vel), res["dvel"], VEL_ATOL, VEL_RTOL, "epoch step %d dof vel" % k)
-        outliers += check_outliers(bad, res, "epoch step %d" % k, max_frac=0.05)
+        # the per-element, conditioning-aware bounds of the one-step tests on EVERY env at every step (flailing ragdolls included)
+        bad = rows_close(rb[..., :3], res["rb"][..., :3], POS_ATOL, 0.0, "epoch step %d rb pos" % k, sens["rb"][..., :3], K_SENS)
+        bad |= rows_close(rb[..., 7:], res["rb"][..., 7:], VEL_ATOL, VEL_RTOL, "epoch step %d rb vel" % k, sens["rb"][..., 7:], K_SENS)
+        bad |= rows_close(N(task._dof_vel), res["dvel"], VEL_ATOL, VEL_RTOL, "epoch step %d dof vel" % k, sens["dvel"], K_SENS)
+        bad |= rows_close(N(task._contact_forces), res["cf"], FORCE_ATOL, FORCE_RTOL, "epoch step %d contact force" % k, sens["cf"], K_SENS)
+        assert_none_over(bad, "epoch step %d" % k)
         assert np.array_equal(N(task.progress_buf), ref.progress_buf), "progress, step %d" % k
         assert np.array_equal(N(task.reset_buf), ref.reset_buf), "reset flags, step %d: %d differ" % (k, (N(task.reset_buf) != ref.reset_buf).sum())
         assert np.array_equal(N(task._terminate_buf), ref.terminate_buf), "terminate flags, step %d" % k
         close(N(task.rew_buf), ref.rew_buf, 1e-3, "reward, step %d" % k)
         died = int(ref.reset_buf.sum())
     task.close()
-    print("[outliers] epoch: %d (env, step) pairs of %d over the per-element bounds" % (outliers, n * steps))
-    assert outliers <= 0.02 * n * steps, "%d of %d (env, step) pairs over the per-element bounds" % (outliers, n * steps)
     return died
 
 
@@ -607,7 +604,7 @@ def test_non_uniform_body_shapes_match_oracle():
     lib = MotionLib.from_clips(synth.make_clips(6, 8, 60, 120), shapes, DEV)
     for contact, lift, seed in ((False, 0.0, 51), (True, -0.05, 52), (True, -0.7, 53)):
         (got, ref), = _run_pair(lib, 48, contact, seed, lift=lift, shapes=shapes, what="non-uniform shapes")
-        _compare(got, ref, "non-uniform shapes contact=%s lift=%.2f" % (contact, lift), contact=contact, tol_force=2e-2 if lift < -0.5 else TOL_FORCE)
+        _compare(got, ref, "non-uniform shapes contact=%s lift=%.2f" % (contact, lift), contact=contact)
 
 
 def test_fused_step_equals_staged_step(mlib):

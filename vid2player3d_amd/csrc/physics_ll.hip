@@ -38,10 +38,17 @@
 // reference in the pre-physics prologue must round like task_ops.hip).  The physics model is this engine's own specification and
 // is checked against the float64 oracle at fixed tolerances; its transcendental / division shortcuts are written out below
 // (hardware sin, cos, sqrt, rcp).  V2P_LL_STRICT_MATH builds everything precise.
+// (V2P_LL_PRECISE_SINCOS / _SQRT / _RCP switch one shortcut back at a time: tools/parity_ab.sh bisects a parity difference with them)
 #if !defined(V2P_LL_STRICT_MATH)
+#if !defined(V2P_LL_PRECISE_SINCOS)
 #define PHYS_SINCOS(x, s, c) do { (s) = __sinf(x); (c) = __cosf(x); } while (0)
+#endif
+#if !defined(V2P_LL_PRECISE_SQRT)
 #define PHYS_SQRT(x) __builtin_amdgcn_sqrtf(x)
+#endif
+#if !defined(V2P_LL_PRECISE_RCP)
 #define PHYS_RCP(x) __builtin_amdgcn_rcpf(x)
+#endif
 #endif
 #include "phys_common.hpp"
 #include "hull_gjk.hpp"
