@@ -34,7 +34,7 @@ extern "C" {
 #define V2P_NUM_OBS 461
 #define V2P_MOTION_STATE_DIM 331  /* root_pos3 root_rot4 dof_pos69 root_vel3 root_ang_vel3 dof_vel69 key_pos12 rb_pos72 rb_rot96 */
 #define V2P_CONTEXT_DIM 378       /* body_pos72 body_rot96 dof_pos69 body_pos_gt72 dof_pos_gt69 (humanoid_smpl_im.py:202) */
-#define V2P_ABI_VERSION 10
+#define V2P_ABI_VERSION 11
 
 typedef enum {
     V2P_OK = 0,
@@ -211,6 +211,15 @@ typedef struct {
                                  * vertices, the closing distance of a substep for the ball), PhysX's `contactDistance` of a joint limit.
                                  * A joint far from its limits costs nothing; one that is pushed across by an impulse of the same substep
                                  * is caught in the next (C < 0 is always active) and corrected with erp.  1e9 = rows always on (ABI 8). */
+    /* ---- ABI 11: the rest of the reference's sim.physx block (cfg/amass_im.yaml:39-48, utils/config.py:190-222) reaches the engine
+     * instead of being parsed and dropped on the Python side */
+    float rest_offset;          /* 0.0 (amass_im.yaml:45): distance at which a hull vertex rests on the plane - the gap of a hull-vertex row
+                                 * is z - rest_offset (PhysX: contacts exist below contact_offset and come to rest at rest_offset) */
+    float bounce_threshold_velocity; /* 0.2 (amass_im.yaml:46): approach speed below which a contact does not bounce.  The humanoid's
+                                 * contacts have restitution 0 (plane.restitution 0.0), so nothing bounces at any speed; the ball rows take
+                                 * their own copy (v2p_ball_cfg.bounce_threshold_velocity).  Must be >= 0. */
+    int32_t num_velocity_iterations; /* 0 (amass_im.yaml:43).  The engine's solvers have no separate velocity pass: any other value is
+                                 * REFUSED (V2P_ERR_UNSUPPORTED) rather than ignored. */
 } v2p_sim_cfg;
 
 /* Caller-owned DEVICE buffers the engine reads/writes; these are the tensors the reference

@@ -73,6 +73,7 @@ typedef struct {
     int solver_type;       /* 0 = PGS (default), 1 = TGS (see the substep) */
     int joint_limits;      /* 1: DOFs whose range is narrower than a full turn get a limit row (see the substep) */
     double limit_margin;   /* 0.05 rad: the row exists only while C < limit_margin + h max(0, approach rate of v*) */
+    double rest_offset;    /* 0.0 (sim.physx.rest_offset): the gap of a hull-vertex row is z - rest_offset */
 } v2p_oparams;
 
 /* ---- racket + ball (vid2player/env/tasks/humanoid_smpl_im_mvae.py:367-442, 711-783; data/assets/tennis_ball.urdf,
@@ -758,6 +759,7 @@ static int substep_impl(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s
                 memcpy(r->pos, cs.pos[ci], sizeof(double) * 3);
                 r->n[0] = 0; r->n[1] = 0; r->n[2] = 1; r->t1[0] = 1; r->t1[1] = 0; r->t1[2] = 0; r->t2[0] = 0; r->t2[1] = 1; r->t2[2] = 0;
                 r->gap = (g_experiment & 1) ? f32_vertex_z(m, s, b, cs.vert[ci]) : cs.pos[ci][2]; r->mu = p->mu; r->rest = 0.0;
+                r->gap -= p->rest_offset;
                 if (g_experiment & 2) r->gap += g_experiment_param;
             }
             for (int q = 0; q < nhull; ++q) if (hull_link[q] == b) { rows[nc++] = hull_row[q]; ++g_hull_rows; }

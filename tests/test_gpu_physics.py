@@ -64,17 +64,21 @@ def _perturbed_task(mlib, n, contact, rng, lift, vel_sigma, hold, shapes, **env)
 
 
 def _run_pair(mlib, n, contact, seed, lift=0.0, vel_sigma=0.5, steps=1, hold="first_sim", shapes=None, subset=None, solver="pgs", what="", limits=False,
-              act_sigma=0.17, **env):
+              act_sigma=0.17, oracle_solver=None, **env):
     """subset: env indices that get an oracle (all by default); the returned arrays are restricted to them.  Returns one
     (got, ref) per control step; ref carries the oracle's own selection ("own") and its margins next to the forced one."""
     rng = np.random.default_rng(seed)
-    task, root, dpos, dvel = _perturbed_task(mlib, n, contact, rng, lift, vel_sigma, hold, shapes, contact_solver=solver, joint_limits=limits, **env)
+    # (solver=None: env.contact_solver is not given - the sim block decides - and the oracle runs `oracle_solver`)
+    if solver is not None:
+        env = dict(env, contact_solver=solver)
+    task, root, dpos, dvel = _perturbed_task(mlib, n, contact, rng, lift, vel_sigma, hold, shapes, joint_limits=limits, **env)
     ids_o = np.arange(n) if subset is None else np.asarray([int(i) for i in subset])
     par = default_params(enable_contact=contact)
-    par.solver_type = {"pgs": 0, "tgs": 1}[solver]
+    par.solver_type = {"pgs": 0, "tgs": 1}[solver or oracle_solver]
     par.joint_limits = int(limits)
     if "limit_margin" in env:
         par.limit_margin = float(env["limit_margin"])
+    par.rest_offset = float(((env.get("sim_overrides") or {}).get("physx") or {}).get("rest_offset", 0.0))
     if shapes is None:
         oracle = BatchOracle(task.body_model, len(ids_o), par)
     else:  # the oracle of env e simulates the body shape of its clip
@@ -202,6 +206,28 @@ def test_tgs_option_matches_oracle(mlib):
     assert np.abs(got["rb"][..., 7:] - got_p["rb"][..., 7:]).max() > 1e-3
 
 
+PHYSX_AMASS_IM = {"num_threads": 4, "solver_type": 1, "num_position_iterations": 4, "num_velocity_iterations": 0, "contact_offset": 0.02, "rest_offset": 0.0,
+                  "bounce_threshold_velocity": 0.2, "max_depenetration_velocity": 10.0, "default_buffer_size_multiplier": 10.0}  # cfg/amass_im.yaml:39-48
+
+
+def test_the_references_sim_block_runs_tgs_and_other_values_reach_the_engine(mlib):
+    """The sim.physx block of the reference's yaml at the boundary: solver_type 1 makes the engine run TGS (same numbers as
+    env.contact_solver='tgs', different from PGS); rest_offset moves the rest height of the hull vertices in kernel and oracle alike;
+    num_velocity_iterations != 0 is refused by the library."""
+    task = make_task(8, mlib, sim_overrides={"physx": dict(PHYSX_AMASS_IM)})
+    assert task.contact_solver == "tgs" and task.contact_solver_source == "sim.physx.solver_type"
+    task.close()
+    (got_y, _), = _run_pair(mlib, 24, contact=True, seed=2, lift=-0.1, what="yaml tgs", sim_overrides={"physx": dict(PHYSX_AMASS_IM)}, solver=None, oracle_solver="tgs")
+    (got_e, _), = _run_pair(mlib, 24, contact=True, seed=2, lift=-0.1, what="env tgs", solver="tgs")
+    assert np.array_equal(got_y["rb"], got_e["rb"]) and np.array_equal(got_y["cf"], got_e["cf"])
+    (got, ref), = _run_pair(mlib, 32, contact=True, seed=2, lift=0.0, what="rest offset", sim_overrides={"physx": dict(PHYSX_AMASS_IM, solver_type=0, rest_offset=0.005)})
+    _compare(got, ref, "rest_offset 5 mm")
+    (got0, _), = _run_pair(mlib, 32, contact=True, seed=2, lift=0.0, what="rest offset 0", sim_overrides={"physx": dict(PHYSX_AMASS_IM, solver_type=0)})
+    assert np.abs(got["rb"][..., 7:] - got0["rb"][..., 7:]).max() > 1e-3, "rest_offset must change the result"
+    with pytest.raises(RuntimeError, match="num_velocity_iterations"):
+        make_task(8, mlib, sim_overrides={"physx": dict(PHYSX_AMASS_IM, num_velocity_iterations=1)})
+
+
 def test_joint_limits_match_oracle(mlib):
     """v2p_sim_cfg.joint_limits with the player MJCF's racket-arm ranges (R_Wrist +-10 / +-45 / +-90 deg, R_Elbow_x <= 90 deg): the
     reference poses put the wrist beyond +-10 deg in most envs, so the rows work against violated limits (erp) and against approached
@@ -244,6 +270,20 @@ def test_config4_settings_match_oracle():
     lib = MotionLib(tabs, DEV)
     n = 64
     _epoch_against_oracles(lib, tabs, n, steps=4, seed=21, sigma=0.17, terminationHeadHeight=-0.5)
+
+
+def test_config1_four_envs_one_clip_whole_epoch():
+    """BASELINE config 1 (embodied_pose amass_im cfg, num_envs=4, ONE clip; the reference runs it on the CPU PhysX path - this engine has
+    no CPU path, so the same configuration runs on the GPU): 4 envs bound to one 300-frame clip, contacts on, a whole
+    32-step epoch against TaskOracle + the C oracle: physics per element on every env, rewards, reset / terminate / progress flags."""
+    from vid2player3d_amd import motion_tables, synth
+    from vid2player3d_amd.model import load_baked_model
+    from vid2player3d_amd.motion_lib import MotionLib
+
+    bm = load_baked_model()
+    tabs = motion_tables.build_tables(synth.make_clips(7, 1, 300, 300), bm.parents, bm.local_pos)
+    assert len(tabs["motion_num_frames"]) == 1 and int(tabs["motion_num_frames"][0]) == 300
+    _epoch_against_oracles(MotionLib(tabs, DEV), tabs, 4, steps=32, seed=7, sigma=0.17)
 
 
 def _epoch_against_oracles(lib, tabs, n, steps, seed, sigma, **env):

@@ -45,6 +45,13 @@ def _launch(task, rng, mode):
         ball[:, 2] = rng.uniform(0.03, 0.25, n)
         ball[:, 7:10] = np.stack([rng.normal(0, 6, n), rng.normal(0, 6, n), rng.uniform(-12, 1, n)], 1)
         ball[:, 10:13] = rng.normal(0, 60, (n, 3))
+    elif mode == "serve":
+        # bench.py's serve (a ball flying at the player at ~22 m/s with top spin), started 0.6 .. 2 m in front of the root so that it
+        # arrives within the steps of the test: racket, link hulls, ground - whatever is in the way
+        dist = rng.uniform(0.6, 2.0, n)
+        ball[:, 0:3] = rb[:, 0, 0:3] + np.stack([dist, rng.uniform(-0.3, 0.3, n), rng.uniform(-0.2, 0.5, n)], 1)
+        ball[:, 7:10] = np.array([-22.0, 0.0, 4.0]) + (rng.uniform(size=(n, 3)) - 0.5) * np.array([6.0, 3.0, 3.0])
+        ball[:, 10:13] = np.array([0.0, -150.0, 0.0])
     elif mode == "joint":
         # aimed at a JOINT of each env (knee, elbow, neck ...): the hulls of the two links that meet there are both within reach of a
         # fast ball, so two hull points are active at once (one per overlapping link)
@@ -117,9 +124,10 @@ def test_ball_step_with_six_substeps_per_simulate_call(mlib, mode):
     _ball_step_vs_oracle(mlib, mode, 0.0, True, "djokovic", substeps=6)
 
 
-def _ball_step_vs_oracle(mlib, mode, lift, limits, player, shapes=None, substeps=2):
-    n = 32
-    rng = np.random.default_rng({"flight": 1, "ground": 2, "hit": 3, "body": 4, "joint": 5}[mode] + int(10 * lift))
+def _ball_step_vs_oracle(mlib, mode, lift, limits, player, shapes=None, substeps=2, n=32, subset=None, steps=2):
+    """subset: the envs that get an oracle (all by default); every comparison is restricted to them."""
+    sub = np.arange(n) if subset is None else np.asarray(sorted(int(i) for i in subset))
+    rng = np.random.default_rng({"flight": 1, "ground": 2, "hit": 3, "body": 4, "joint": 5, "serve": 6}[mode] + int(10 * lift))
     extra = {} if shapes is None else {"body_model": shapes, "motion_shape_ids": np.arange(8) % len(shapes)}
     task = make_rb_task(n, mlib, joint_limits=limits, player=player, sim_overrides={"substeps": substeps}, **extra)
     rl = task.racket_geometry["racket_link"]
@@ -137,19 +145,23 @@ def _ball_step_vs_oracle(mlib, mode, lift, limits, player, shapes=None, substeps
     # one physics-free refresh of the rigid-body state for the launch geometry: FK of the pushed state through the oracle
     bm = task.body_model
     oracles = []
-    for e in range(n):
+    for e in sub:
         if shapes is not None:
             bm = task.body_shapes[task._env_shape_ids[e]]
         o = PhysOracle(bm, default_params(h=1.0 / (60.0 * substeps), joint_limits=int(limits)), kp=bm.kp.astype(np.float32), kd=bm.kd.astype(np.float32))
         o.set_state(root[e], dpos[e], dvel[e])
         o.attach_ball(task.racket_geometry)
         oracles.append(o)
-    task._rigid_body_state[:] = T(np.stack([o.get_state()[3] for o in oracles]).reshape(n * 24, 13))
+    if subset is None:
+        task._rigid_body_state[:] = T(np.stack([o.get_state()[3] for o in oracles]).reshape(n * 24, 13))
+    else:  # (the launch geometry of the other envs: the rigid-body state the reset left, i.e. the unperturbed reference pose)
+        rbv = task._rigid_body_state.view(n, 24, 13)
+        rbv[T(sub, torch.long)] = T(np.stack([o.get_state()[3] for o in oracles]))
     ball = _launch(task, rng, mode)
     task._ball_root_states[:] = T(ball)
     hits_total, ground_total, body_total, multi_total = 0, 0, 0, 0
-    has_hit = np.zeros(n, dtype=bool)
-    for step in range(2):
+    has_hit = np.zeros(len(sub), dtype=bool)
+    for step in range(steps):
         act = np.concatenate([N(task._target_dof_pos) + rng.normal(0, 0.17, (n, 69)), rng.normal(0, 0.17, (n, 6))], axis=1).astype(np.float32)
         rb0 = N(task._rigid_body_state).reshape(n, 24, 13).copy()
         dpos_before = N(task._dof_pos).copy()
@@ -160,39 +172,40 @@ def _ball_step_vs_oracle(mlib, mode, lift, limits, player, shapes=None, substeps
         torch.cuda.synchronize()
         _, pd, _, force, torque = O.pre_physics(act, N(task.reset_buf), dpos_before, rb0[:, 0, 3:7], bm.kp.astype(np.float32))
         per_sim, hit, bc, rbs, ids, cf, bbf, cfs = [], [], [], [], [], [], [], []
-        for e in range(n):
-            oracles[e].set_ball(ball_before[e])
-            c, _, i, ps, h, b = oracles[e].step_ball(pd_target=pd[e], ext_force=force[e], ext_torque=torque[e], nsub=2 * substeps, hold=substeps, sub_per_sim=substeps)
-            per_sim.append(ps); hit.append(h); bc.append(b); rbs.append(oracles[e].get_state()[3]); ids.append(i); cf.append(c); bbf.append(oracles[e].ball_body_force); cfs.append(oracles[e].contact_force_sum)
+        for k, e in enumerate(sub):
+            oracles[k].set_ball(ball_before[e])
+            c, _, i, ps, h, b = oracles[k].step_ball(pd_target=pd[e], ext_force=force[e], ext_torque=torque[e], nsub=2 * substeps, hold=substeps, sub_per_sim=substeps)
+            per_sim.append(ps); hit.append(h); bc.append(b); rbs.append(oracles[k].get_state()[3]); ids.append(i); cf.append(c); bbf.append(oracles[k].ball_body_force); cfs.append(oracles[k].contact_force_sum)
         per_sim, hit, bc, rbs, ids, cf, bbf, cfs = map(np.stack, (per_sim, hit, bc, rbs, ids, cf, bbf, cfs))
-        assert np.array_equal(N(task.debug_contacts()), ids), "hull contact vertices differ"
-        got_ps = N(task._ball_states_per_sim)
+        assert np.array_equal(N(task.debug_contacts())[sub], ids), "hull contact vertices differ"
+        got_ps = N(task._ball_states_per_sim)[sub]
+        ball_before = ball_before[sub]
         close(got_ps[..., 0:3], per_sim[..., 0:3], 2e-5, "%s ball pos (step %d)" % (mode, step))
         qs = np.sign(np.sum(got_ps[..., 3:7] * per_sim[..., 3:7], -1, keepdims=True))
         close(got_ps[..., 3:7] * qs, per_sim[..., 3:7], 1e-4, "ball quat")
         close(got_ps[..., 7:10], per_sim[..., 7:10], 5e-4, "%s ball vel (step %d)" % (mode, step))
         close(got_ps[..., 10:13], per_sim[..., 10:13], 5e-4, "%s ball spin (step %d)" % (mode, step))
-        assert np.array_equal(N(task._ball_root_states), got_ps[:, -1])
-        assert np.array_equal(N(task._racket_ball_contact_per_sim), hit), "racket hit flags"
+        assert np.array_equal(N(task._ball_root_states)[sub], got_ps[:, -1])
+        assert np.array_equal(N(task._racket_ball_contact_per_sim)[sub], hit), "racket hit flags"
         # the reference's sticky flag and its per-step edge (humanoid_smpl_im_mvae.py:773-779), kept by the physics launch itself
         # (only with sim.substeps <= 2, :769)
-        now = (hit.any(axis=1) & ~has_hit) if substeps <= 2 else np.zeros(n, dtype=bool)
+        now = (hit.any(axis=1) & ~has_hit) if substeps <= 2 else np.zeros(len(sub), dtype=bool)
         has_hit |= now
-        assert np.array_equal(N(task._has_racket_ball_contact_now), now) and np.array_equal(N(task._has_racket_ball_contact), has_hit)
-        close(N(task._ball_contact_forces), bc, 2e-2, "contact forces on the ball")
-        close(N(task._ball_body_contact_force), bbf, 2e-2, "contact force on the ball from the humanoid's links")
-        rb = N(task._rigid_body_state).reshape(n, 24, 13)
+        assert np.array_equal(N(task._has_racket_ball_contact_now)[sub], now) and np.array_equal(N(task._has_racket_ball_contact)[sub], has_hit)
+        close(N(task._ball_contact_forces)[sub], bc, 2e-2, "contact forces on the ball")
+        close(N(task._ball_body_contact_force)[sub], bbf, 2e-2, "contact force on the ball from the humanoid's links")
+        rb = N(task._rigid_body_state).reshape(n, 24, 13)[sub]
         close(rb[..., 0:3], rbs[..., 0:3], 2e-5, "rb pos")
         close(rb[..., 7:13], rbs[..., 7:13], 1e-3, "rb vel")
-        close(N(task._contact_forces), cf, 2e-2, "net contact forces (the racket's link carries the reaction of the ball)")
-        close(N(task._contact_forces_sum), cfs, 2e-2, "_contact_forces_sum: net contact forces summed over the two simulate() calls")
+        close(N(task._contact_forces)[sub], cf, 2e-2, "net contact forces (the racket's link carries the reaction of the ball)")
+        close(N(task._contact_forces_sum)[sub], cfs, 2e-2, "_contact_forces_sum: net contact forces summed over the two simulate() calls")
         if lift == 0.0:  # standing on the ground: the feet carry the weight in both simulate() calls
             assert np.abs(cfs - cf).max() > 1.0, "the first simulate() call contributes"
         # the racket rigid body = the wrist frame moved by the weld offset
         Rw = Rotation.from_quat(rbs[:, rl, 3:7]).as_matrix()
         off = np.einsum("nij,j->ni", Rw, task.racket_geometry["racket_offset"])
-        close(N(task._racket_rb_state)[:, 0:3], rbs[:, rl, 0:3] + off, 2e-5, "racket pos")
-        close(N(task._racket_rb_state)[:, 7:10], rbs[:, rl, 7:10] + np.cross(rbs[:, rl, 10:13], off), 1e-3, "racket vel")
+        close(N(task._racket_rb_state)[sub][:, 0:3], rbs[:, rl, 0:3] + off, 2e-5, "racket pos")
+        close(N(task._racket_rb_state)[sub][:, 7:10], rbs[:, rl, 7:10] + np.cross(rbs[:, rl, 10:13], off), 1e-3, "racket vel")
         multi_total += sum(int(o.max_hull_points >= 2) for o in oracles)  # envs whose ball touched two links' hulls in one substep
         hits_total += int(hit.sum())
         ground_total += int(((ball_before[:, 9] < -0.5) & (got_ps[:, -1, 9] > 0)).sum())  # balls that bounced within this control step
@@ -208,6 +221,18 @@ def _ball_step_vs_oracle(mlib, mode, lift, limits, player, shapes=None, substeps
     if mode == "body":
         assert body_total >= n // 4, "the fixture must produce ball x hull hits (%d)" % body_total
     task.close()
+    return {"hits": hits_total, "ground": ground_total, "body": body_total, "multi": multi_total}
+
+
+def test_racket_ball_full_size_sample_matches_oracle(mlib):
+    """BASELINE config 4 as worded, at its size: 8192 envs with racket + ball, joint limits on, a ball served at every player (bench.py's
+    serve, started close enough to arrive within the test); 64 of the envs - first, last and a spread - against their own oracles over
+    three control steps: substep jobs, pairing by load and the tail of a full-size launch with the ball kernel."""
+    n = 8192
+    subset = sorted(set([0, 1, 2, n - 2, n - 1] + list(np.random.default_rng(9).integers(0, n, size=59))))
+    got = _ball_step_vs_oracle(mlib, "serve", 0.0, True, "djokovic", n=n, subset=subset, steps=3)
+    print("[racket-ball 8192] sampled envs: racket hits %d, ground bounces %d, deflections by a link's hull %d, balls on two hulls at once %d" % (got["hits"], got["ground"], got["body"], got["multi"]))
+    assert got["hits"] + got["body"] + got["ground"] >= 8, "the serve must reach something in the sampled envs: %s" % got
 
 
 def test_bounce_and_hit_flags(mlib):

@@ -325,6 +325,16 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
     if (c->schedule != 0 && c->schedule != 1) { set_error("v2p_env_create: schedule must be 0 or 1"); delete e; return V2P_ERR_INVALID; }
     if (c->solver_type != 0 && c->solver_type != 1) { set_error("v2p_env_create: solver_type must be 0 (PGS) or 1 (TGS)"); delete e; return V2P_ERR_INVALID; }
     if (c->solver_type == 1 && c->schedule == 1) { set_error("v2p_env_create: the env-per-lane cross-check kernel solves PGS only"); delete e; return V2P_ERR_UNSUPPORTED; }
+    if (c->num_velocity_iterations != 0) {
+        set_error("v2p_env_create: sim.physx.num_velocity_iterations = %d: the engine's contact solvers have no separate velocity pass (the reference's configs use 0)", c->num_velocity_iterations);
+        delete e;
+        return V2P_ERR_UNSUPPORTED;
+    }
+    if (!(c->bounce_threshold_velocity >= 0.f) || !(c->rest_offset < c->contact_offset)) {
+        set_error("v2p_env_create: bounce_threshold_velocity must be >= 0 and rest_offset below contact_offset");
+        delete e;
+        return V2P_ERR_INVALID;
+    }
     if (c->joint_limits && (c->schedule == 1 || c->solver_type != 0 || !c->enable_contact)) {
         set_error("v2p_env_create: joint_limits needs the link-per-lane schedule, the PGS solver and contacts on");
         delete e;
@@ -347,6 +357,8 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
     p.solver_type = c->solver_type;
     p.joint_limits = c->joint_limits ? 1 : 0;
     p.limit_margin = c->limit_margin <= 0.f ? 0.05f : c->limit_margin;  // (a zero-initialised cfg gets the default)
+    p.rest_offset = c->rest_offset;
+    p.bounce_threshold = c->bounce_threshold_velocity;
     p.context_length = c->context_length; p.context_padding = c->context_padding;
     p.dt = (float)c->control_freq_inv * c->sim_dt;
     memcpy(p.term_heights, c->term_heights, sizeof(p.term_heights));
@@ -557,6 +569,10 @@ int v2p_env_attach_ball(v2p_env* e, const v2p_ball_cfg* c, const v2p_ball_buffer
     }
     if (e->schedule != 0 || !e->p.enable_contact || e->p.solver_type != 0) {
         set_error("v2p_env_attach_ball: racket + ball needs the link-per-lane schedule, contacts on and the PGS solver");
+        return V2P_ERR_UNSUPPORTED;
+    }
+    if (e->p.rest_offset != 0.f) {
+        set_error("v2p_env_attach_ball: sim.physx.rest_offset != 0 is modelled for the hull x plane rows only, not for the ball's rows");
         return V2P_ERR_UNSUPPORTED;
     }
     if (!e->ball) e->ball = new (std::nothrow) BallDev();

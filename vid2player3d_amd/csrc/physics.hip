@@ -445,7 +445,7 @@ __global__ __launch_bounds__(L) void physics_kernel(PhysArgs a) {
                         int vi = sel[c] < 0 ? 0 : sel[c];
                         V3 rr = mul(R, V3{M.shape.hull_verts[v0 + vi][0], M.shape.hull_verts[v0 + vi][1], M.shape.hull_verts[v0 + vi][2]});
                         G(b, GCR + 3 * c) = rr.x; G(b, GCR + 3 * c + 1) = rr.y; G(b, GCR + 3 * c + 2) = rr.z;
-                        float d = x.z + rr.z;
+                        float d = x.z + rr.z - P.rest_offset;
                         G(b, GCB + c) = d >= 0.f ? d / h : fmaxf(P.erp * d / h, -P.max_depen);
                         G(b, GCL + 3 * c) = 0.f; G(b, GCL + 3 * c + 1) = 0.f; G(b, GCL + 3 * c + 2) = 0.f;
                         if (a.contact_ids) a.contact_ids[(e * NB + b) * 4 + c] = c < cnt ? b * 64 + sel[c] : -1;

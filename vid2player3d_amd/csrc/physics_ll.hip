@@ -1229,7 +1229,7 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                     const float4 uu = hullv(v0 + (sel4[c] < 0 ? 0 : sel4[c]));
                     const V3 crc = mul(R, V3{uu.x, uu.y, uu.z});
                     CS.set_cr(c, crc);
-                    float dz = x.z + crc.z;
+                    float dz = x.z + crc.z - P.rest_offset;
                     CS.set_bias(c, TGS ? dz : (dz >= 0.f ? dz * ih : fmaxf(P.erp * dz * ih, -P.max_depen)));
                 }
             }

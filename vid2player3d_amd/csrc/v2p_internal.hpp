@@ -98,6 +98,8 @@ struct EnvParams {
     int solver_type;        // 0 PGS, 1 TGS (frozen Jacobians)
     int joint_limits;       // 1: limit rows for DOFs with a range narrower than a full turn
     float limit_margin;     // ... that exist only while C < limit_margin + h max(0, approach rate of v*)
+    float rest_offset;      // gap of a hull-vertex row = z - rest_offset (sim.physx.rest_offset)
+    float bounce_threshold; // sim.physx.bounce_threshold_velocity (the humanoid's rows have restitution 0: kept for the record)
     int context_length, context_padding;
     float dt;              // control step
     float term_heights[NB];

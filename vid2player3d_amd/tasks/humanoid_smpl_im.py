@@ -47,9 +47,12 @@ class SimParams:
     substeps: int = 2
     gravity: tuple = (0.0, 0.0, -9.81)
     physx: PhysxParams = field(default_factory=PhysxParams)
+    given: set = field(default_factory=set)   # sim.physx keys the yaml block names itself (from_cfg)
 
     @classmethod
     def from_cfg(cls, sim_cfg):
+        """The `sim` block of a task yaml (cfg/amass_im.yaml:37-52).  `given` records which sim.physx keys the block names itself, so
+        that a choice the file states (solver_type: 1) is told apart from a default of this class."""
         sp = cls()
         sim_cfg = sim_cfg or {}
         sp.dt = float(sim_cfg.get("dt", sp.dt))
@@ -57,7 +60,55 @@ class SimParams:
         for k, v in (sim_cfg.get("physx") or {}).items():
             if hasattr(sp.physx, k):
                 setattr(sp.physx, k, type(getattr(sp.physx, k))(v))
+                sp.given.add(k)
         return sp
+
+
+SOLVER_NAMES = {0: "pgs", 1: "tgs"}   # gymapi: sim.physx.solver_type 0 = PGS, 1 = TGS (amass_im.yaml:41, config.py:203)
+
+
+def resolve_contact_solver(env, sim_params, log=None):
+    """Which contact solver the engine runs: (name, source).
+
+    The reference's files decide: `sim.physx.solver_type` (cfg/amass_im.yaml:41 says 1 = TGS; `parse_sim_params`, utils/config.py:203,
+    sets 1 before the yaml is read) -> 1 = "tgs", 0 = "pgs".  `env.contact_solver` ("pgs" | "tgs"), a key of THIS engine, overrides it
+    - and says so through `log` when the two disagree.  With neither stated (this package's `default_cfg()`, which names no solver
+    type) the engine's default is PGS, the solver BASELINE.json's config 3 is worded on."""
+    physx = getattr(sim_params, "physx", None)
+    given = getattr(sim_params, "given", None)   # None: a foreign SimParams object (e.g. gymapi's): what it holds was stated by its maker
+    stated = physx is not None and hasattr(physx, "solver_type") and (given is None or "solver_type" in given)
+    from_sim = None
+    if stated:
+        st = int(physx.solver_type)
+        if st not in SOLVER_NAMES:
+            raise ValueError("sim.physx.solver_type = %r: 0 (PGS) or 1 (TGS)" % (physx.solver_type,))
+        from_sim = SOLVER_NAMES[st]
+    if "contact_solver" in env:
+        name = env["contact_solver"]
+        if name not in ("pgs", "tgs"):
+            raise ValueError("env.contact_solver = %r: 'pgs' or 'tgs'" % (name,))
+        if from_sim is not None and from_sim != name and log is not None:
+            log("vid2player3d_amd: env.contact_solver = %r overrides sim.physx.solver_type = %d (%s)" % (name, int(physx.solver_type), from_sim))
+        return name, "env.contact_solver"
+    if from_sim is not None:
+        return from_sim, "sim.physx.solver_type"
+    return "pgs", "engine default"
+
+
+def fill_physx(c, sim_params, env, log=None):
+    """The sim.physx block (cfg/amass_im.yaml:39-48) -> v2p_sim_cfg; every key either reaches the engine or is refused there
+    (num_threads and default_buffer_size_multiplier size PhysX's own host threads / GPU buffers and have no counterpart).  Returns the
+    (solver name, source) pair."""
+    px = sim_params.physx
+    c.num_solver_iterations = int(px.num_position_iterations)
+    c.num_velocity_iterations = int(getattr(px, "num_velocity_iterations", 0))
+    c.contact_offset = float(px.contact_offset)
+    c.rest_offset = float(getattr(px, "rest_offset", 0.0))
+    c.bounce_threshold_velocity = float(getattr(px, "bounce_threshold_velocity", 0.2))
+    c.max_depenetration_velocity = float(px.max_depenetration_velocity)
+    name, source = resolve_contact_solver(env, sim_params, log)
+    c.solver_type = {"pgs": 0, "tgs": 1}[name]
+    return name, source
 
 
 def default_cfg(num_envs=8192, **env_overrides):
@@ -395,14 +446,13 @@ class HumanoidSMPLIM:
         c.sim_dt = sp.dt
         c.substeps = sp.substeps
         c.control_freq_inv = self.control_freq_inv
-        c.num_solver_iterations = sp.physx.num_position_iterations
         c.enable_contact = int(env.get("enable_contact", True))
         c.freeze_terminated_envs = int(env.get("freeze_terminated_envs", False))  # not the reference's behaviour: see v2p_rollout.h
         c.schedule = {"link_per_lane": 0, "env_per_lane": 1}[env.get("kernel_schedule", "link_per_lane")]
         c.pair_envs_by_load = int(env.get("pair_envs_by_load", True))
-        # contact solver of the engine's own physics model: "pgs" (default) or "tgs" (sim.physx.solver_type 1 of amass_im.yaml:41 names
-        # PhysX's TGS; the engine's TGS restates the published algorithm with frozen Jacobians, see oracle/phys/v2p_phys_oracle.c)
-        c.solver_type = {"pgs": 0, "tgs": 1}[env.get("contact_solver", "pgs")]
+        # the sim.physx block, solver choice included (sim.physx.solver_type 1 of amass_im.yaml:41 = TGS; env.contact_solver overrides;
+        # the engine's TGS restates the published algorithm with frozen Jacobians, see oracle/phys/v2p_phys_oracle.c)
+        self.contact_solver, self.contact_solver_source = fill_physx(c, sp, env, log=lambda m: print(m, flush=True))
         # physics launch cut into (substep, env pair) jobs: finer load balancing, bit-identical results (tests); on by default
         # (True / 1: the engine cuts launches that do not fit the wave slots in one round; 2: always; every solver / contact setting)
         c.substep_jobs = int(env.get("substep_jobs", True)) if c.schedule == 0 else 0
@@ -417,8 +467,6 @@ class HumanoidSMPLIM:
         c.residual_hold_sims = 1 if hold == "first_sim" else self.control_freq_inv
         c.gravity_z = sp.gravity[2]
         c.friction = 0.5 * (env["plane"]["staticFriction"] + env["plane"]["dynamicFriction"]) if "plane" in env else 1.0
-        c.contact_offset = sp.physx.contact_offset
-        c.max_depenetration_velocity = sp.physx.max_depenetration_velocity
         c.erp = env.get("contact_erp", 0.2)
         c.angular_damping = 0.01
         c.max_angular_velocity = 100.0
