@@ -139,6 +139,29 @@ class StubTask:
         return 0.001 * self._launches, self._launches
 
 
+class StubAgent:
+    """Stand-in for PPOAgent when the launch / aggregation logic of `--ppo` is tested without GPUs: an epoch of it moves a few CPU
+    tensors and all-reduces one of them like the update does.  Never part of a measured number."""
+
+    def __init__(self, task):
+        self.task, self.epoch = task, 0
+
+    def train_epoch(self):
+        t0 = time.perf_counter()
+        for _ in range(HORIZON):
+            self.task.step_fused(torch.zeros(self.task.num_envs, 75))
+        t1 = time.perf_counter()
+        g = torch.ones(16)
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.all_reduce(g)
+        self.epoch += 1
+        return {"play_time": t1 - t0, "total_time": time.perf_counter() - t0, "frames": self.task.num_envs * HORIZON, "step_rewards": 0.0,
+                "step_sub_rewards": [0.0] * 4, "alive_ratio": 1.0, "world": float(g[0])}
+
+    def format_epoch_line(self, r):
+        return "stub epoch %d: world %d" % (self.epoch, int(r["world"]))
+
+
 def print_last(line, dist):
     """The JSON line as the LAST thing on stdout: RCCL writes its version banner through C stdio, which a redirected stdout holds back
     until the process exits - after anything Python printed.  Every rank drains its C buffers, the ranks meet, rank 0 prints."""
@@ -182,44 +205,59 @@ def make_epoch_actions(task, noise_all, out):
     return out
 
 
-def cpu_baseline(budget_s=12.0, max_steps=HORIZON, sigma=0.17):
-    """The oracle on the host cores, same workload (contacts on, sigma-noise actions around the target pose): per control step ONE
-    batched C call for the physics of all sample envs (OpenMP over envs, float64 dense restatement) and the numpy task ops
-    (single-threaded restatement of the reference's torch ops), timed separately."""
+def host_cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(sizes=((4, 32, 3.0), (1024, 8, 5.0), (8192, 3, 12.0)), sigma=0.17):
+    """The oracle on the host cores, same workload (contacts on, sigma-noise actions around the target pose) at the env counts BASELINE.md
+    section 3 names (4, 1024, 8192): per control step ONE batched C call for the physics of all envs (OpenMP over envs; the float64 dense
+    restatement built with -O3 -mavx2 -mfma, oracle/phys/Makefile `fast`) and the numpy task ops (single-threaded restatement of the
+    reference's torch ops), timed separately.  sizes: (envs, most steps, seconds budget) - a bounded sample each; `value` is the 8192-env
+    figure (the size the metric is quoted on)."""
     from oracle import task_oracle as O
-    from oracle.phys_oracle import BatchOracle, default_params, lib
+    from oracle.phys_oracle import FAST_FLAGS, BatchOracle, default_params, lib_fast
     from vid2player3d_amd import motion_tables, synth
     from vid2player3d_amd.model import load_baked_model
 
     cores = os.cpu_count() or 1
-    threads = min(cores, lib().v2p_oracle_max_threads())
+    threads = min(cores, lib_fast().v2p_oracle_max_threads())
     bm = load_baked_model()
     clips = synth.make_clips(7, 8, 90, 300)
     tabs = motion_tables.build_tables(clips, bm.parents, bm.local_pos)
-    rng = np.random.default_rng(7)
-    n = max(64, 4 * threads)
-    ids = np.arange(n) % 8
-    task = O.TaskOracle(tabs, ids, bm.kp.astype(np.float32))
-    task.reset_all(rng.uniform(0.1, 1.0, size=n).astype(np.float32))
-    oracle = BatchOracle(bm, n, default_params(), threads=threads)
-    oracle.set_state(task.root_states, task.dof_pos, task.dof_vel)
-    t_phys = t_task = 0.0
-    steps = 0
-    t0 = time.perf_counter()
-    while steps < max_steps and time.perf_counter() - t0 < budget_s:
-        steps += 1
-        ta = time.perf_counter()
-        act = np.concatenate([task.target[2] + rng.normal(0, sigma, size=(n, 69)), rng.normal(0, sigma, size=(n, 6))], axis=1).astype(np.float32)
-        _, pd, _, force, torque = task.pre_physics_step(act)
-        tb = time.perf_counter()
-        res = oracle.step(pd, force, torque, nsub=4, hold=2)
-        tc = time.perf_counter()
-        task.set_sim_state(res["dpos"].astype(np.float32), res["dvel"].astype(np.float32), res["rb"].astype(np.float32))
-        task.post_physics_step()
-        td = time.perf_counter()
-        t_phys += tc - tb
-        t_task += (tb - ta) + (td - tc)
-    dt = t_phys + t_task
+    by_n = {}
+    for n, max_steps, budget_s in sizes:
+        rng = np.random.default_rng(7)
+        task = O.TaskOracle(tabs, np.arange(n) % 8, bm.kp.astype(np.float32))
+        task.reset_all(rng.uniform(0.1, 1.0, size=n).astype(np.float32))
+        th = min(threads, n)
+        oracle = BatchOracle(bm, n, default_params(), threads=th, fast=True)
+        oracle.set_state(task.root_states, task.dof_pos, task.dof_vel)
+        t_phys = t_task = 0.0
+        steps = 0
+        t0 = time.perf_counter()
+        while steps < max_steps and (steps == 0 or time.perf_counter() - t0 < budget_s):
+            steps += 1
+            ta = time.perf_counter()
+            act = np.concatenate([task.target[2] + rng.normal(0, sigma, size=(n, 69)), rng.normal(0, sigma, size=(n, 6))], axis=1).astype(np.float32)
+            _, pd, _, force, torque = task.pre_physics_step(act)
+            tb = time.perf_counter()
+            res = oracle.step(pd, force, torque, nsub=4, hold=2)
+            tc = time.perf_counter()
+            task.set_sim_state(res["dpos"].astype(np.float32), res["dvel"].astype(np.float32), res["rb"].astype(np.float32))
+            task.post_physics_step()
+            td = time.perf_counter()
+            t_phys += tc - tb
+            t_task += (tb - ta) + (td - tc)
+        by_n[str(n)] = {"value": n * steps / (t_phys + t_task), "physics_env_steps_per_s": n * steps / t_phys, "task_ops_env_steps_per_s": n * steps / t_task,
+                        "physics_threads": th, "physics_env_steps_per_s_per_thread": n * steps / t_phys / th, "steps": steps,
+                        "seconds": {"physics": t_phys, "task_ops": t_task}}
     ref_ops = None
     try:  # the reference's OWN task code timed in the build container (tools/ref_cpu_baseline.py; the reference tree does not travel)
         r = json.load(open(os.path.join(REPO, "profiles", "r03_ref_cpu_task_ops.json")))
@@ -228,11 +266,14 @@ def cpu_baseline(budget_s=12.0, max_steps=HORIZON, sigma=0.17):
                    "envs": r["envs"], "ms_per_step": r["ms_per_step"], "source": "from_profiles: profiles/r03_ref_cpu_task_ops.json"}
     except Exception:
         pass
-    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port", "reference_task_ops": ref_ops,
-            "physics_env_steps_per_s": n * steps / t_phys, "physics_env_steps_per_s_per_core": n * steps / t_phys / threads,
-            "task_ops_env_steps_per_s": n * steps / t_task, "task_ops_threads": 1,
-            "sample": "%d envs x %d control steps (4 substeps each, contacts on): C float64 dense oracle, one batched OpenMP call per step on %d threads "
-                      "(%.2f s) + numpy task ops on 1 thread (%.2f s); host has %d logical cores" % (n, steps, threads, t_phys, t_task, cores)}
+    big = by_n[str(sizes[-1][0])]
+    return {"value": big["value"], "unit": "env-steps/s", "cores": threads, "kind": "port", "host": "%s, %d logical cores" % (host_cpu_model(), cores),
+            "by_num_envs": by_n, "reference_task_ops": ref_ops, "oracle_build_flags": FAST_FLAGS,
+            "physics_env_steps_per_s": big["physics_env_steps_per_s"], "physics_env_steps_per_s_per_core": big["physics_env_steps_per_s_per_thread"],
+            "task_ops_env_steps_per_s": big["task_ops_env_steps_per_s"], "task_ops_threads": 1,
+            "sample": "num_envs %s: %s control steps each (4 substeps, contacts on): C float64 dense oracle (%s), one batched OpenMP call per step on up to %d threads "
+                      "+ numpy task ops on 1 thread; value = the %d-env figure; NOT the reference's PhysX-CPU path (closed, absent)"
+                      % ("/".join(str(x[0]) for x in sizes), "/".join(str(by_n[str(x[0])]["steps"]) for x in sizes), FAST_FLAGS, threads, sizes[-1][0])}
 
 
 def profiles_view():
@@ -268,11 +309,14 @@ def run_ppo(args, task, dist, world, rank):
     """BASELINE config 5 (per GPU: --num-envs envs, horizon 32, the amass_im.yaml MLP and PPO hyper-parameters): epochs of
     play_steps + update; the reference's meters `fps step` = frames / T_play and `fps total` = frames / (T_play + T_update)
     (im_agent.py:204-214), whole job = sum over ranks of frames over the slowest rank's time."""
-    from vid2player3d_amd.ppo import PPOAgent
-
     tasks = task if isinstance(task, list) else [task]
     task = tasks[0]
-    agent = PPOAgent(tasks if len(tasks) > 1 else task, seed=7, reuse_next_values=not args.ppo_reference_critic_passes, overlap_critic=not args.ppo_no_overlap, mixed_precision=args.ppo_mixed_precision)
+    if args.stub_task:
+        agent = StubAgent(task)
+    else:
+        from vid2player3d_amd.ppo import PPOAgent
+
+        agent = PPOAgent(tasks if len(tasks) > 1 else task, seed=7, reuse_next_values=not args.ppo_reference_critic_passes, overlap_critic=not args.ppo_no_overlap, mixed_precision=args.ppo_mixed_precision)
     agent.train_epoch()  # warm-up epoch (allocator, rocBLAS heuristics, running statistics)
     rows = []
     for _ in range(args.ppo_epochs):
@@ -287,8 +331,14 @@ def run_ppo(args, task, dist, world, rank):
         t = torch.tensor([play, total], device=task.device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         play, total = float(t[0]), float(t[1])
+    world_seen = 1 if dist is None else dist.get_world_size()
+    rccl = None
+    if dist is not None and not args.stub_task:
+        try:
+            rccl = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:
+            rccl = "unknown"
     if rank == 0:
-        from vid2player3d_amd import build
         out = {"metric": "env-steps/sec at num_envs=8192, SMPL humanoid imitation", "value": world * frames / total, "unit": "env-steps/s", "n_gpus": world,
                "steps": args.ppo_epochs * HORIZON, "warmup": HORIZON, "ms_per_step": 1e3 * total / (args.ppo_epochs * HORIZON), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f16 autocast (update) / f32" if args.ppo_mixed_precision else "f32", "data": "synthetic",
@@ -299,12 +349,20 @@ def run_ppo(args, task, dist, world, rank):
                                          ", UPDATE IN MIXED PRECISION (fp16 autocast: the reference's non-default cfg option)" if args.ppo_mixed_precision else ""),
                           "num_envs_per_gpu": args.num_envs, "global_envs": world * args.num_envs,
                           "parallelism": "env-sharded x%d; advantage statistics, running norms and gradients all-reduced over RCCL at the update" % world,
+                          "world_size_seen": world_seen, "world_size_matches_gpus": world_seen == args.gpus, "rccl_version": rccl,
+                          "backend": None if dist is None else ("gloo" if args.stub_task else "nccl(rccl)"),
+                          "scaling_curve": "no multi-GPU curve has been measured for this engine (the driver's 8-GPU runs were skipped in rounds 1-3)",
                           "fps_step": world * frames / play, "fps_total": world * frames / total,
                           "T_play_s_per_epoch": play / args.ppo_epochs, "T_update_s_per_epoch": (total - play) / args.ppo_epochs,
                           "rollout_groups": len(tasks),
                           "step_rewards_by_epoch": [r["step_rewards"] for r in rows], "step_sub_rewards_last_epoch": rows[-1]["step_sub_rewards"],
                           "step_rewards_last_epoch": rows[-1]["step_rewards"], "alive_ratio_last_epoch": rows[-1]["alive_ratio"]},
-               "build": build.build_info()}
+               }
+        if args.stub_task:
+            out["config"]["workload"] += ", STUB TASK AND AGENT (launch-logic test, not a measurement)"
+        else:
+            from vid2player3d_amd import build
+            out["build"] = build.build_info()
         line = json.dumps(out)
     else:
         line = None

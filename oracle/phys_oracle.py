@@ -7,6 +7,8 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "phys", "libv2p_phys_oracle.so")
+LIB_FAST = os.path.join(HERE, "phys", "libv2p_phys_oracle_fast.so")   # same source, -O3 -mavx2 -mfma: bench.py's cpu_baseline only
+FAST_FLAGS = "-O3 -mavx2 -mfma -ffp-contract=fast -funroll-loops -fopenmp"
 NB, NJ, ND = 24, 23, 75
 
 
@@ -62,6 +64,21 @@ def lib():
         assert _lib.v2p_oracle_sizeof_params() == C.sizeof(OParams)
         assert _lib.v2p_oracle_sizeof_ball_params() == C.sizeof(OBallParams) and _lib.v2p_oracle_sizeof_ball() == C.sizeof(OBall)
     return _lib
+
+
+_lib_fast = None
+
+
+def lib_fast():
+    """The same C source built with FAST_FLAGS (oracle/phys/Makefile): the cpu_baseline leg of bench.py times this one; no test's pass
+    criterion uses it."""
+    global _lib_fast
+    if _lib_fast is None:
+        if not os.path.exists(LIB_FAST):
+            build()
+        _lib_fast = C.CDLL(LIB_FAST)
+        assert _lib_fast.v2p_oracle_sizeof_state() == C.sizeof(OState) and _lib_fast.v2p_oracle_sizeof_params() == C.sizeof(OParams)
+    return _lib_fast
 
 
 def default_params(h=1.0 / 120.0, enable_contact=True, **kw):
@@ -218,8 +235,8 @@ class BatchOracle:
     """n independent humanoids stepped by one C call (OpenMP over envs).  `models` is one BodyModel or a list of them with
     `model_of` [n] naming each env's; gains default to the models' own."""
 
-    def __init__(self, models, n, params=None, model_of=None, gains_f32=True, threads=0):
-        self.lib = lib()
+    def __init__(self, models, n, params=None, model_of=None, gains_f32=True, threads=0, fast=False):
+        self.lib = lib_fast() if fast else lib()
         models = list(models) if isinstance(models, (list, tuple)) else [models]
         cast = (lambda x: x.astype(np.float32)) if gains_f32 else (lambda x: x)
         self._m = [_omodel(bm, cast(bm.kp), cast(bm.kd)) for bm in models]

@@ -40,6 +40,14 @@ def test_self_launch_two_ranks_with_stub_task():
     assert "STUB" in d["config"]["workload"] and "cpu_baseline" not in d
 
 
+def test_ppo_loop_line_with_two_ranks_and_stub_task():
+    """`bench.py --gpus 2 --ppo` (BASELINE config 5's launch shape): rank spawn, per-epoch time aggregation (MAX over ranks) and the line."""
+    d, err = _run(["--gpus", "2", "--ppo", "--ppo-epochs", "2", "--stub-task", "--num-envs", "128"])
+    assert d["n_gpus"] == 2 and d["config"]["world_size_seen"] == 2 and d["config"]["world_size_matches_gpus"] and d["config"]["backend"] == "gloo"
+    assert d["steps"] == 64 and d["config"]["global_envs"] == 256 and d["config"]["fps_total"] <= d["config"]["fps_step"]
+    assert "world 2" in err and "no multi-GPU curve" in d["config"]["scaling_curve"]
+
+
 def test_short_run_is_followed_by_a_whole_epoch_block():
     """The driver's command (--steps 20 --warmup 5): every run() starts an epoch, so the timed region is reset + positions 0..19 - the
     line must say so, and carry a separately timed block of whole epochs from which the roofline figures are taken."""

@@ -3,7 +3,14 @@ tests/golden/ppo_trace.npz): `_calc_advs`, `prepare_dataset` (value normaliser i
 masked KL, clip fraction, per-minibatch RunningNorm update, residual action in the training-mode forward, gradient-norm clip, Adam) on a
 real recorded rollout of 6 envs x 32 steps.  Pure torch on the CPU: the one HIP op of the update (the raw 734-d features) is supplied by
 the numpy oracle here and compared with the kernel in tests/test_gpu_ppo_reference.py.  Plus: two data-parallel ranks (gloo) == one
-process on the concatenated batch."""
+process on the concatenated batch.
+
+WHAT IS PINNED TO THE REFERENCE AND WHAT IS NOT.  The generator ran the reference's own methods, but rl_games (1.1.4, third-party, absent)
+was stood in for by oracle/ref_shim/rl_games_restated.py, written from its published source by the author of the product code.  Golden
+keys whose VALUE passes through one of those helpers are therefore compared with a restatement of the same provenance - SELF-REFERENTIAL
+as far as that helper's conventions go (SELF_REFERENTIAL_KEYS below; the helpers' mathematics is pinned separately, against independent
+closed forms, in tests/test_rl_games_helpers.py).  Everything else in the file - buffer contents, returns, advantages, the RunningNorm
+of the observations, the reference's loss formulas, Adam - is the reference's own arithmetic."""
 import os
 import types
 
@@ -16,6 +23,25 @@ from oracle import task_oracle as O
 G = np.load(os.path.join(os.path.dirname(__file__), "golden", "ppo_trace.npz"))
 TR = np.load(os.path.join(os.path.dirname(__file__), "golden", "env_trace.npz"))
 N_ENV, T, PAD = 6, 32, 8
+
+# golden key (prefix) -> the restated rl_games helper its value went through when it was recorded
+SELF_REFERENTIAL_KEYS = {
+    "vms1": "RunningMeanStd (value normaliser after prepare_dataset: prior count 1, unbiased batch variance, population merge)",
+    "data/old_values": "RunningMeanStd.forward (normalised with the statistics above, epsilon inside the square root, clamp +-5)",
+    "data/returns": "RunningMeanStd.forward",
+    "grad/*/kl": "policy_kl(reduce=False) with its 1e-5 guards, averaged by the masked mean (divisor = mask.numel(): the reference's own form, im_agent.py:573)",
+    "grad/*/actor_loss": "apply_masks (divisor = number of elements of the mask)", "grad/*/critic_loss": "apply_masks", "grad/*/entropy": "apply_masks",
+    "grad/*/w/*": "the weights after Adam depend on the three masked losses above",
+    "play/neglogpacs": "ModelA2CContinuousLogStd.neglogp", "data/old_logp_actions": "ModelA2CContinuousLogStd.neglogp",
+}
+
+
+def test_self_referential_keys_exist_in_the_fixture():
+    """(the table above names real keys: a renamed fixture entry must not silently drop out of it)"""
+    import fnmatch
+
+    for pat in SELF_REFERENTIAL_KEYS:
+        assert any(fnmatch.fnmatch(k, pat) for k in G.files), pat
 
 
 def stub_task(n=N_ENV, device="cpu"):

@@ -168,7 +168,7 @@ int v2p_model_create(const v2p_model_desc* d, int device, v2p_model** out) {
         for (int k = 0; k < 4; ++k) {
             int a = b, steps = 1 << k;
             while (steps > 0 && a > 0) { a = h.parents[a]; --steps; }
-            h.anc_jump[b] |= ((steps == 0 && b != 0) ? a : 255) << (8 * k);
+            h.anc_jump[b] = (int32_t)((uint32_t)h.anc_jump[b] | ((uint32_t)((steps == 0 && b != 0) ? a : 255) << (8 * k)));
         }
     }
     h.side_depths[0] = 0;
@@ -614,7 +614,12 @@ int v2p_env_check_async(v2p_env* e, void* stream) {
     int rc = V2P_OK;
     if (!e->err_host) {
         rc = check_hip(hipHostMalloc((void**)&e->err_host, sizeof(int32_t), hipHostMallocDefault), "hipHostMalloc(job recovery counter)");
-        if (rc == V2P_OK) rc = check_hip(hipEventCreateWithFlags(&e->err_event, hipEventDisableTiming), "hipEventCreate(job recovery counter)");
+        if (rc == V2P_OK) {
+            rc = check_hip(hipEventCreateWithFlags(&e->err_event, hipEventDisableTiming), "hipEventCreate(job recovery counter)");
+            if (rc != V2P_OK) { (void)hipHostFree(e->err_host); e->err_host = nullptr; }  // (no half-built pair: a later call starts over)
+        } else {
+            e->err_host = nullptr;
+        }
         if (rc != V2P_OK) return rc;
         *e->err_host = 0;
     } else if (e->err_pending && hipEventQuery(e->err_event) == hipSuccess) {

@@ -81,8 +81,9 @@ class RunningNorm:
         self.var.copy_((m2 / tot).float())
         self.std.copy_(torch.sqrt(self.var))
         self.n += m.long()
-        if x.shape[0] > 0:
-            self._seen = True
+        # (from the REDUCED count, like the reference's `n > 0` test: a rank whose own batch was empty must normalise like its peers;
+        # None = re-read from n at the next normalize(), no host sync here)
+        self._seen = True if x.shape[0] > 0 else None
 
     def normalize(self, x):
         if self._seen is None:

@@ -332,16 +332,17 @@ class PPOAgent(PolicyInference):
         self.current_lengths.zero_()
         # the epoch's action noise in one draw, so that the env -> noise assignment does not depend on how the envs are grouped
         noise_all = None if self.noise_fn else torch.randn((T, self.num_actors, A), device=self.device, generator=self.action_gen)
-        start = torch.cuda.Event() if multi else None
-        if multi:
-            start.record(main)
         st = []
         for gi, g in enumerate(self.groups):
+            # (built BEFORE the start event is recorded: the zero fills run on the main stream, the group streams wait for the event)
             s = dict(prev_dones=torch.zeros(g.task.num_envs, device=self.device),
                      # device accumulators of what the reference collects through .nonzero() / AverageMeter on the host:
                      # finished episodes: n, sum reward, sum length | steps of envs not done before: n, sum reward
                      acc=torch.zeros(8, dtype=torch.float64, device=self.device), sub=None, feat=None, value=None)
             st.append(s)
+        start = torch.cuda.Event() if multi else None
+        if multi:
+            start.record(main)
         cuda = self.device.type == "cuda"
         overlap = self.overlap_critic and self.reuse_next_values and cuda
 
@@ -512,10 +513,10 @@ class PPOAgent(PolicyInference):
         for p in params:
             p.grad = None
         (self.scaler.scale(loss) if self.mixed_precision else loss).backward()
-        if self.mixed_precision:
-            self.scaler.unscale_(self.optimizer)
         world = _world(self.group)
         if world > 1:  # data parallel over env shards: one flat all-reduce of the gradients over RCCL, averaged (Horovod's DistributedOptimizer)
+            # (the SCALED gradients are reduced, unscale_ comes after - the order of the reference's Horovod path, optimizer.synchronize()
+            # before scaler.unscale_(): every rank then sees the same inf / NaN verdict and takes the same step-or-skip decision)
             flat = torch.cat([p.grad.reshape(-1) for p in params])
             vdist.dist.all_reduce(flat, group=self.group)
             flat /= world
@@ -523,6 +524,8 @@ class PPOAgent(PolicyInference):
             for p in params:
                 p.grad.copy_(flat[o:o + p.numel()].view_as(p))
                 o += p.numel()
+        if self.mixed_precision:
+            self.scaler.unscale_(self.optimizer)
         if self.truncate_grads:
             nn.utils.clip_grad_norm_(params, self.grad_norm)
         if self.mixed_precision:
