@@ -1,10 +1,14 @@
 #!/usr/bin/env python
 """Summarise the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into profiles/pmc_summary.json.
 
-Units: rocprofv3 reports both counters in KiB per dispatch.  Per MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950
-reads exactly 1/2 of the bytes of a WIDE coalesced stream (16 B/lane); this kernel's accesses are 4 B/lane, a width the
-guide calls uncalibrated, so the raw value is reported together with the x2 upper bound.
+Units: rocprofv3 reports both counters in KiB per dispatch.  Calibrated on known byte counts in this kernel's own access widths
+(tools/ubench/hbm_calib.hip, tools/hbm_calib.sh -> profiles/r04_hbm_calib.txt, 1 GiB streams, larger than the Infinity Cache):
+FETCH_SIZE reports exactly 0.500 of the bytes read, for 4 B / lane loads as for 16 B / lane ones; WRITE_SIZE reports 1.000 of the bytes
+of full-line stores (4 B / lane and 16 B / lane alike) and 32 B for every isolated 4-byte store (partial lines are written back in
+32-byte sectors).  A second anchor inside the engine: env_context_kernel writes 594.5 MB (N x 48 x 378 floats + N x 48 mask bytes at
+8192 envs) and WRITE_SIZE shows 598.2 MB (1.006).  Hence: bytes = 2 x FETCH_SIZE + WRITE_SIZE.
 """
+FETCH_FACTOR, WRITE_FACTOR = 2.0, 1.0
 import json
 import sqlite3
 import sys
@@ -25,6 +29,10 @@ def main(fetch_db, write_db, out_path):
            "physics_kernel": kern, "fetch_KiB_per_launch": f[kern]["avg_KiB"], "write_KiB_per_launch": w[kern]["avg_KiB"],
            "physics_kernel_hbm_bytes_per_launch": (f[kern]["avg_KiB"] + w[kern]["avg_KiB"]) * 1024.0,
            "physics_kernel_hbm_bytes_per_launch_fetch_x2": (2 * f[kern]["avg_KiB"] + w[kern]["avg_KiB"]) * 1024.0,
+           "physics_kernel_hbm_bytes_calibrated": (FETCH_FACTOR * f[kern]["avg_KiB"] + WRITE_FACTOR * w[kern]["avg_KiB"]) * 1024.0,
+           "calibration_note": "bytes = 2.0 x FETCH_SIZE + 1.0 x WRITE_SIZE: calibrated on 1 GiB streams of 4 B / lane and 16 B / lane accesses (profiles/r04_hbm_calib.txt: "
+                               "FETCH_SIZE = 0.500 x bytes read at both widths, WRITE_SIZE = 1.000 x bytes of full-line stores, 32 B per isolated 4-byte store) and on "
+                               "env_context_kernel's known 594.5 MB of output (WRITE_SIZE 1.006 x); `traffic` is the calibrated figure, the raw sum stays in the summary",
            "all_kernels": {k: {"fetch_KiB": f.get(k, {}).get("avg_KiB"), "write_KiB": w.get(k, {}).get("avg_KiB")} for k in sorted(set(f) | set(w)) if "v2p" in k}}
     json.dump(res, open(out_path, "w"), indent=1)
     print(json.dumps(res, indent=1))

@@ -115,6 +115,13 @@ __device__ __forceinline__ void cload4x2(const float* p0, const float* p1, f4& a
     asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dwordx4 %1, %3, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(a), "=&v"(b) : "v"(p0), "v"(p1) : "memory");
 }
 
+// five chunks in one block (one wait for all of them): the whole hand-over of a lane
+__device__ __forceinline__ void cload4x5(const float* p0, const float* p1, const float* p2, const float* p3, const float* p4, f4& a, f4& b, f4& c, f4& d, f4& e) {
+    asm volatile("global_load_dwordx4 %0, %5, off sc0 sc1\n\tglobal_load_dwordx4 %1, %6, off sc0 sc1\n\tglobal_load_dwordx4 %2, %7, off sc0 sc1\n\t"
+                 "global_load_dwordx4 %3, %8, off sc0 sc1\n\tglobal_load_dwordx4 %4, %9, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "=&v"(e) : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4) : "memory");
+}
+
 __device__ __forceinline__ float pull(float v, int src_lane) {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
 }
@@ -255,6 +262,23 @@ constexpr bool PARK3 = V2P_LL_PARK3 != 0;
 #ifndef V2P_LL_PREFETCH_ROWS
 #define V2P_LL_PREFETCH_ROWS 1
 #endif
+#ifndef V2P_LL_FAST_HANDOVER
+#define V2P_LL_FAST_HANDOVER 0  // prologue of a job that takes a hand-over: hand-over slots indexed by WAVE SLOT (not by env), every chunk of a lane in ONE
+                                // load block, the env looked up from the pairing tables while the first poll of the progress word is in flight
+                                // (0, the default: progress word -> env index -> chunks 0,1 -> chunks 48,49 -> chunk 54, up to five dependent round
+                                // trips.  Measured round 4, profiles/r04_ab_handover_targethead.txt: no difference at 8192 / 32768 envs, racket + ball,
+                                // TGS - with three waves per SIMD a job's prologue latency is covered by the other waves; the shorter chain is kept
+                                // as a build switch, bit-identical to the default in the substep-job tests)
+#endif
+#ifndef V2P_LL_WAIT_SLEEP
+#define V2P_LL_WAIT_SLEEP 16  // s_sleep argument (x 64 clocks) between two polls of a job that waits for its predecessor's hand-over
+#endif
+#ifndef V2P_LL_TARGET_HEAD
+#define V2P_LL_TARGET_HEAD 0  // 1: fused step, the next target is sampled by the job of an env's FIRST substep (it depends on the clip and the time
+                              // only) instead of by its last one, so that the jobs that end a launch get shorter.  Measured round 4 (same file):
+                              // 19.89 vs 19.92 M at 8192 envs, 12.74 vs 12.86 M racket + ball, 24.48 vs 24.35 M at 32768: nothing - the tail of a
+                              // launch is set by when the last jobs START, not by the ~8 us they lose
+#endif
 #ifndef V2P_LL_WALK
 #define V2P_LL_WALK 1  // 0: the sweep with a leaf -> root -> leaves propagation after every touched group (A/B; the ball / joint-limit kernels use it)
 #endif
@@ -273,8 +297,12 @@ constexpr int BL_POS = 0, BL_QUAT = 3, BL_VEL = 7, BL_ANG = 10, BL_F = 13, BL_GA
 constexpr int LDS_FLOATS_PER_WAVE = PARK_SLOTS * 64 + 2 * BL_SLOTS + ROOTLAM_FLOATS;
 // ball x hull narrow phase, out of line: it runs on the few substeps in which a ball is within reach of a link, and inlined its
 // registers would be spilled around on every substep
-__device__ __noinline__ float ball_hull_distance(ConstShape* S, int v0, int nv, V3 c, V3& p) {
-    return hull_closest([&](int k) { return V3{S->hull_verts[v0 + k][0], S->hull_verts[v0 + k][1], S->hull_verts[v0 + k][2]}; }, nv, c, p);
+// (the closest point comes back BY VALUE, xyz = point, w = distance: an out-parameter by reference is a stack slot of the caller that the
+// callee writes through a pointer)
+__device__ __noinline__ f4 ball_hull_distance(ConstShape* S, int v0, int nv, V3 c) {
+    V3 p;
+    const float d = hull_closest([&](int k) { return V3{S->hull_verts[v0 + k][0], S->hull_verts[v0 + k][1], S->hull_verts[v0 + k][2]}; }, nv, c, p);
+    return f4{p.x, p.y, p.z, d};
 }
 // contact records of this lane's link: registers, or (PARK3) the lane's LDS column
 template <bool LDS>
@@ -361,6 +389,11 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
     // the inputs of this job were written by another workgroup of this launch - unless that one did not show up in time (below)
     bool handed = !mono && sjob > 0;
     int* const progress = JOBS ? a.job_progress + (bid * LL_WPB + (threadIdx.x >> 6)) : nullptr;
+    // (FAST_HANDOVER: the first poll of the progress word is issued HERE and looked at behind the env lookup below - the two round trips
+    // of a job's prologue that do not depend on each other overlap)
+    int poll0 = 0;
+    if constexpr (JOBS && V2P_LL_FAST_HANDOVER != 0) if (handed && lane == 0) poll0 = __hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    auto wait_for_predecessor = [&]() {
     if constexpr (JOBS) if (handed) {
         // wait for the previous substep of this env pair
         // progress word of a pair = launch number x (nsub + 1) + substeps handed over: the last hand-over of launch E stores
@@ -370,7 +403,7 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
         int ok = 1;
         if (lane == 0) {
             long spins = 0;
-            while (__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+            while ((V2P_LL_FAST_HANDOVER != 0 && spins == 0 ? poll0 : __hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) < want) {
                 if (spins >= a.job_timeout_spins) {
                     // The predecessor is late beyond reason (jobs are dispatched in index order as far as observed, but nothing promises
                     // it).  This job then runs the pair's EARLIER substeps itself, from the inputs of the step, before its own: every job
@@ -381,15 +414,17 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                     __hip_atomic_fetch_add(a.job_progress + a.job_blocks * LL_WPB, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     break;
                 }
-                __builtin_amdgcn_s_sleep(16);
+                __builtin_amdgcn_s_sleep(V2P_LL_WAIT_SLEEP);
                 ++spins;
             }
         }
         handed = __builtin_amdgcn_readfirstlane(ok) != 0;
         __builtin_amdgcn_wave_barrier();
     }
+    };
+    if constexpr (V2P_LL_FAST_HANDOVER == 0) wait_for_predecessor();
     int64_t e = live_env ? slot : N - 1;
-    if (a.pl_start && handed) {
+    if (V2P_LL_FAST_HANDOVER == 0 && a.pl_start && handed) {
         // (looked up by the job of the pair's first substep, which has handed it over with everything else)
         e = __hip_atomic_load(&a.pl_slot_env[live_env ? slot : N - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     } else if (a.pl_start) {
@@ -407,8 +442,9 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
         const int c1 = __popcll(__ballot(st.x <= r1)) + __popcll(__ballot(st.y <= r1)) + __popcll(__ballot(st.z <= r1)) + __popcll(__ballot(st.w <= r1));
         const int bin = half ? c1 - 1 : c0 - 1, rk = half ? r1 : r0;
         e = a.pl_list[(int64_t)bin * N + (rk - a.pl_start[bin])];
-        if (JOBS && !mono && lb == 0 && live_env) __hip_atomic_store(&a.pl_slot_env[slot], (int32_t)e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (V2P_LL_FAST_HANDOVER == 0 && JOBS && !mono && lb == 0 && live_env) __hip_atomic_store(&a.pl_slot_env[slot], (int32_t)e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    if constexpr (V2P_LL_FAST_HANDOVER != 0) wait_for_predecessor();
     // the env index behind an opaque move: addresses formed from it inside the substep loop are computed where they are used instead of
     // being hoisted in front of the loop and kept (spilled: 64-bit pointers, 8 bytes of scratch per lane each) across all of it
     auto env_here = [&]() -> int64_t { int64_t v = e; asm volatile("" : "+v"(v)); return v; };
@@ -545,9 +581,41 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
     // (JOBS: the job of an env's first substep reads the engine's state, the others what the job before them handed over: 16-byte chunks,
     // chunk 2b, 2b+1 = joint b (quaternion | rate), chunks 0, 1, 48, 49 = the root (quat | pos, vx | vy, vz, wx, wy | wz))
     // (one hand-over slot per substep: slot s holds the state after substep s)
-    float* const hand = JOBS && handed ? a.job_hand + ((int64_t)(sjob - 1) * N + e) * HAND_FLOATS : nullptr;
+    // (FAST_HANDOVER: the slot of a hand-over is the WAVE SLOT of the pair - known from the workgroup index alone - not the env)
+    const int64_t hidx = V2P_LL_FAST_HANDOVER != 0 ? (live_env ? slot : N - 1) : e;
+    float* const hand = JOBS && handed ? a.job_hand + ((int64_t)(sjob - 1) * N + hidx) * HAND_FLOATS : nullptr;
     bool got = false;
-    if constexpr (JOBS) if (handed) {
+    bool bgot = false;  // (BALL) the ball lane has its state from the hand-over
+    if constexpr (JOBS && V2P_LL_FAST_HANDOVER != 0) if (handed) {
+        // every chunk of this lane in one block of five loads and ONE wait: a link lane its two chunks (the other three addresses repeat
+        // the first), the root lane chunks 0, 1, 48, 49, 54, the ball lane chunks 50 .. 53
+        const bool isball = BALL && lb == NB;
+        const int k0 = isball ? 50 : 2 * b, k1 = isball ? 51 : 2 * b + 1, k2 = isball ? 52 : (b == 0 ? 48 : 2 * b), k3 = isball ? 53 : (b == 0 ? 49 : 2 * b),
+                  k4 = (!isball && b == 0) ? 54 : k0;
+        f4 c0, c1, c2, c3, c4;
+        cload4x5(hand + 4 * k0, hand + 4 * k1, hand + 4 * k2, hand + 4 * k3, hand + 4 * k4, c0, c1, c2, c3, c4);
+        if (isball) {
+            lds_vfloat* const blh = (lds_vfloat*)(park_all + (threadIdx.x >> 6) * LDS_FLOATS_PER_WAVE + PARK_SLOTS * 64 + half * BL_SLOTS);
+            blh[0] = c0.x; blh[1] = c0.y; blh[2] = c0.z; blh[3] = c0.w; blh[4] = c1.x; blh[5] = c1.y; blh[6] = c1.z; blh[7] = c1.w;
+            blh[8] = c2.x; blh[9] = c2.y; blh[10] = c2.z; blh[11] = c2.w; blh[12] = c3.x; blh[13] = c3.y; blh[14] = c3.z; blh[15] = c3.w;
+            bgot = true;
+        } else if (b == 0) {
+            q = Q4{c0.x, c0.y, c0.z, c0.w};
+            x = V3{c1.x, c1.y, c1.z};
+            xd = V3{c1.w, c2.x, c2.y};
+            w = V3{c2.z, c2.w, c3.x};
+            if (a.actions && valid && sjob * jlen < a.p.hold_sub) {
+                float* const wp = park_all + (threadIdx.x >> 6) * LDS_FLOATS_PER_WAVE + base;
+                wp[PARK_TAR * 64] = c3.y; wp[(PARK_TAR + 1) * 64] = c3.z; wp[(PARK_TAR + 2) * 64] = c3.w;
+                wp[25 + PARK_TAR * 64] = c4.x; wp[25 + (PARK_TAR + 1) * 64] = c4.y; wp[25 + (PARK_TAR + 2) * 64] = c4.z;
+            }
+        } else {
+            jq = Q4{c0.x, c0.y, c0.z, c0.w};
+            wt = V3{c1.x, c1.y, c1.z};
+        }
+        got = true;
+    }
+    if constexpr (JOBS && V2P_LL_FAST_HANDOVER == 0) if (handed) {
         f4 c0, c1;
         cload4x2(hand + 8 * b, hand + 8 * b + 4, c0, c1);
         if (b == 0) {
@@ -632,13 +700,21 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
         }
     }
 
+    if constexpr (JOBS && !DIAG && V2P_LL_TARGET_HEAD != 0) {
+        // ---- the NEXT target (reference state one step ahead of the new time), sampled here, in the job of the env's first substep: it
+        // depends on the clip and the time only.  Same function, same arguments as the staged post-physics: the same bits.  (target[cur] -
+        // what the reward of this step compares with - is not touched; the buffer written here held the target before it.)
+        if (a.post.on && first_job && valid && live_env) {
+            const PostArgs& Z = a.post;
+            strict::post_sample_target(Z.b, Z.t, P, Z.motion_id[e], Z.b.cur_time[e] + P.dt, Z.cur, e, b);
+        }
+    }
     if (valid && b != 0) park_put3(PARK_TAR, tar);  // constant for the whole launch (the columns of lanes 0 and 25 hold the wrench there)
     const BallDev& BP = a.ball;
     const bool ball_lane = BALL && lb == NB;  // the first idle lane of the env carries the ball
     if (ball_lane) {
         // (JOBS: state and aerodynamic force - held over a simulate() call - come from the job of the substep before: chunks 50 .. 53)
-        bool bgot = false;
-        if constexpr (JOBS) if (handed) {
+        if constexpr (JOBS && V2P_LL_FAST_HANDOVER == 0) if (handed) {
             f4 c0, c1, c2, c3;
             cload4x2(hand + 4 * 50, hand + 4 * 51, c0, c1);
             cload4x2(hand + 4 * 52, hand + 4 * 53, c2, c3);
@@ -820,8 +896,9 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                     V3 rlw{0.f, 0.f, 0.f}, nw{0.f, 0.f, 1.f};
                     if (near) {
                         const int hv0 = S->hull_offsets[bo], hnv = S->hull_count[bo];
-                        V3 pb;
-                        float dist = ball_hull_distance(S, hv0, hnv, cb, pb);
+                        const f4 hc = ball_hull_distance(S, hv0, hnv, cb);
+                        V3 pb{hc.x, hc.y, hc.z};
+                        float dist = hc.w;
                         V3 nb;
                         if (dist > 1e-6f) nb = PHYS_RCP(dist) * (cb - pb);
                         else {  // centre inside the hull: out along the direction from the centre of the bounding box
@@ -2286,7 +2363,7 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
             const bool root = b == 0;
             const float A0 = root ? q.x : jq.x, A1 = root ? q.y : jq.y, A2 = root ? q.z : jq.z, A3 = root ? q.w : jq.w;
             const float B0 = root ? x.x : wt.x, B1 = root ? x.y : wt.y, B2 = root ? x.z : wt.z, B3 = root ? xd.x : 0.f;
-            float* const ho = a.job_hand + ((int64_t)sjob * N + e) * HAND_FLOATS;
+            float* const ho = a.job_hand + ((int64_t)sjob * N + (V2P_LL_FAST_HANDOVER != 0 ? slot : e)) * HAND_FLOATS;
             const bool second = lb & 1;
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
@@ -2307,7 +2384,7 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
             }
         }
         if (BALL && ball_lane && live_env) {
-            float* const ho = a.job_hand + ((int64_t)sjob * N + e) * HAND_FLOATS;
+            float* const ho = a.job_hand + ((int64_t)sjob * N + (V2P_LL_FAST_HANDOVER != 0 ? slot : e)) * HAND_FLOATS;
             cstore4(ho + 4 * 50, bl[0], bl[1], bl[2], bl[3]);
             cstore4(ho + 4 * 51, bl[4], bl[5], bl[6], bl[7]);
             cstore4(ho + 4 * 52, bl[8], bl[9], bl[10], bl[11]);
@@ -2395,7 +2472,7 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                 mid = Z.motion_id[e];
                 t_new = Z.b.cur_time[e] + P.dt;  // _cur_ref_motion_times += dt
                 rp = strict::post_body(Z.b, Z.t, P, mid, t_new, Z.cur, e, b, strict::V3{x.x, x.y, x.z}, strict::Q4{q.x, q.y, q.z, q.w}, strict::V3{xd.x, xd.y, xd.z},
-                                       strict::V3{w.x, w.y, w.z}, strict::V3{qe.x, qe.y, qe.z}, strict::V3{wt.x, wt.y, wt.z}, fl);
+                                       strict::V3{w.x, w.y, w.z}, strict::V3{qe.x, qe.y, qe.z}, strict::V3{wt.x, wt.y, wt.z}, fl, V2P_LL_TARGET_HEAD == 0);
             }
             // reward sums over the bodies, bodies ascending like env_post_kernel: the terms go through this lane's LDS column (the parking
             // area is idle by now; a wave's LDS accesses execute in order), lanes 0..3 of each env add one term each
