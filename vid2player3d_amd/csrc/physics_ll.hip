@@ -139,7 +139,13 @@ __device__ __forceinline__ M3 pull(const M3& a, int s) {
 // lane i <- lane i+1 through the DPP network (wave_shl:1, VALU speed, no LDS round trip): links are in depth-first order, so the
 // first child of any link is the next lane.  (The mirror image for parents, wave_shr:1 + a select against the non-chain links,
 // measured slower than a plain ds_bpermute and is not used.)
-__device__ __forceinline__ float from_next(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false)); }
+// (bound_ctrl: the lane without a source - lane 63 - gets 0 from the hardware; with bound_ctrl off it KEEPS the `old` operand, which the
+// compiler then has to materialise with a v_mov 0 in front of every one of these moves, and which keeps it from folding the move into the
+// add that consumes it)
+#ifndef V2P_LL_DPP_BOUND_CTRL
+#define V2P_LL_DPP_BOUND_CTRL 1
+#endif
+__device__ __forceinline__ float from_next(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, V2P_LL_DPP_BOUND_CTRL != 0)); }
 __device__ __forceinline__ V3 from_next(V3 v) { return V3{from_next(v.x), from_next(v.y), from_next(v.z)}; }
 __device__ __forceinline__ Sym3 from_next(const Sym3& a) {
     return Sym3{from_next(a.xx), from_next(a.xy), from_next(a.xz), from_next(a.yy), from_next(a.yz), from_next(a.zz)};
@@ -1580,7 +1586,12 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                     const unsigned longb = sideb | (ul0 < 15 ? 2u << ul0 : 0u) | (ul1 < 15 ? 2u << ul1 : 0u);
                     // ---- up  (levels in a gap between the two envs' ranges run idle: a range test here makes the compiler run the whole
                     // loop with per-lane exits and d in a VGPR)
-                    for (int d = du0 > du1 ? du0 : du1; d > ulmin; --d) {
+                    for (int dctr = du0 > du1 ? du0 : du1; dctr > ulmin; --dctr) {
+                        // (an opaque SCALAR copy of the level for everything the body compares with per-lane depths: where the body tests
+                        // `turndep == d - 1`, value numbering rewrites the loop counter itself with the per-lane value it was found equal to, and
+                        // the whole loop runs with its counter in a VGPR and per-lane exits - +20 VALU instructions per level)
+                        int d = dctr;
+                        asm volatile("" : "+s"(d));
                         V3 cn{0.f, 0.f, 0.f}, cf{0.f, 0.f, 0.f};
                         if (updep == d) {
                             const V3 na = aug * mul(Di, un_new);
