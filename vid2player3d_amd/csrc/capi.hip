@@ -481,6 +481,7 @@ void v2p_env_destroy(v2p_env* e) {
     if (e->contact_ids_sub) (void)hipFree(e->contact_ids_sub);
     if (e->job_progress) (void)hipFree(e->job_progress);
     if (e->job_hand) (void)hipFree(e->job_hand);
+    if (e->ball && e->ball->contact_part) (void)hipFree(e->ball->contact_part);
     delete e->ball;
     if (e->err_host) { (void)hipHostFree(e->err_host); (void)hipEventDestroy(e->err_event); }
     profile_free(e);
@@ -592,6 +593,11 @@ int v2p_env_attach_ball(v2p_env* e, const v2p_ball_cfg* c, const v2p_ball_buffer
     d.has_bounce = b->has_bounce; d.has_bounce_now = b->has_bounce_now; d.bounce_pos = b->bounce_pos;
     d.has_hit = b->has_racket_contact; d.has_hit_now = b->has_racket_contact_now;
     d.contact_sum = b->contact_force_sum;
+    if (d.contact_sum && !d.contact_part) {
+        const size_t nsim = (size_t)(e->p.nsub / e->substeps_per_sim);
+        int rc = check_hip(hipMalloc((void**)&d.contact_part, sizeof(float) * (size_t)e->n * nsim * NB * 3), "hipMalloc(contact_part)");
+        if (rc != V2P_OK) return rc;
+    }
     if (e->pair_mix_default) e->pair_mix_permille = 0;
     return V2P_OK;
 }

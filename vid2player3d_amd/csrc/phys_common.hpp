@@ -34,6 +34,7 @@ struct BallDev {
     uint8_t *has_bounce, *has_bounce_now, *has_hit, *has_hit_now;  // the reference's flags (all or none)
     float* bounce_pos;     // [N,3]
     float* contact_sum;    // [N,24,3] or NULL: net contact forces of the links summed over the simulate() calls of the control step
+    float* contact_part;   // [N,nsim,24,3] engine-owned (with contact_sum): the net contact forces after each simulate() call, one slot per call
 };
 
 // post-physics fused into the physics launch (v2p_env_step, link-per-lane schedule): what env_post_kernel takes

@@ -399,6 +399,16 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
     // of a job's prologue that do not depend on each other overlap)
     int poll0 = 0;
     if constexpr (JOBS && V2P_LL_FAST_HANDOVER != 0) if (handed && lane == 0) poll0 = __hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // A job of a cut pair that starts after the pair's step is COMPLETE - its successors gave up waiting, replayed its substeps and the
+    // last of them has written the results - must not run: the inputs of the step (state, actions, reset flags) are already those of the
+    // next one.  The job of an env's last substep leaves the word at launch x (nsub + 1) + nsub when it ends; every other job looks before
+    // it touches anything.  (Forward progress never needs this; it keeps a pathologically late job from writing the exposed PD targets,
+    // per-call ball records or hand-overs from the wrong inputs.)
+    if constexpr (JOBS) if (!mono) {
+        int done = 0;
+        if (lane == 0) done = (handed && V2P_LL_FAST_HANDOVER != 0 ? poll0 : __hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) >= a.job_epoch * (a.p.nsub + 1) + a.p.nsub;
+        if (__builtin_amdgcn_readfirstlane(done)) return;
+    }
     auto wait_for_predecessor = [&]() {
     if constexpr (JOBS) if (handed) {
         // wait for the previous substep of this env pair
@@ -2243,7 +2253,7 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                     if (BP.body_contact) { float* ob = BP.body_contact + e * 3; ob[0] = fbd.x; ob[1] = fbd.y; ob[2] = fbd.z; }
                 }
             }
-            if ((last || (BP.contact_sum && !replay && sub % BP.sub_per_sim == BP.sub_per_sim - 1)) && valid && live_env && !frozen) {
+            if ((last || (BP.contact_sum && sub % BP.sub_per_sim == BP.sub_per_sim - 1)) && valid && live_env && !frozen) {
                 // the reaction on the touched link enters its net contact force below
                 const V3 fr = mask(lb == BP.racket_link, frk) + fmine;
                 park[PARK_W0 * 64] = fr.x; park[(PARK_W0 + 1) * 64] = fr.y; park[(PARK_W0 + 2) * 64] = fr.z;
@@ -2251,7 +2261,12 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
         }
         // (racket + ball, opt-in: `_contact_forces_sum`, the net contact forces summed over the simulate() calls of a control step,
         // humanoid_smpl_im_mvae.py:781 - what refresh_net_contact_force_tensor shows after EVERY call is needed then, not only after the last)
-        const bool sum_now = BALL && BP.contact_sum && !replay && sub % BP.sub_per_sim == BP.sub_per_sim - 1;
+        // One slot per simulate() call (`contact_part`, engine-owned), written by whoever runs the call's last substep - a replaying job
+        // included: the same bits whoever writes them, so the order in which a pair's jobs run cannot matter - and added up by the job of the
+        // env's LAST substep, which either waited for the jobs before it (their stores were drained in front of the progress word) or has
+        // just replayed them itself.  (Round 3 accumulated in place, load + add + store per call: a job that ran ahead of a late predecessor
+        // added onto a stale value, and the predecessor's own store then dropped what had been added.)
+        const bool sum_now = BALL && BP.contact_sum && sub % BP.sub_per_sim == BP.sub_per_sim - 1;
         if ((last || sum_now) && valid && live_env && !frozen) {
             // net contact force per body = sum of impulses / h  (refresh_net_contact_force_tensor)
             V3 cforce{0.f, 0.f, 0.f};
@@ -2267,11 +2282,21 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                 oc[0] = cforce.x; oc[1] = cforce.y; oc[2] = cforce.z;
             }
             if (sum_now) {  // (system-scope accesses: the calls of one step may run in different workgroups)
-                float* os = BP.contact_sum + (env_here() * NB + b) * 3;
-                const bool first = sub < BP.sub_per_sim;
-                cstore(os, (first ? 0.f : cload(os)) + cforce.x);
-                cstore(os + 1, (first ? 0.f : cload(os + 1)) + cforce.y);
-                cstore(os + 2, (first ? 0.f : cload(os + 2)) + cforce.z);
+                const int ks = sub / BP.sub_per_sim, nsim = nsub / BP.sub_per_sim;
+                float* const part = BP.contact_part + ((env_here() * nsim) * NB + b) * 3;
+                if (!last) {
+                    float* op = part + (int64_t)ks * NB * 3;
+                    cstore(op, cforce.x); cstore(op + 1, cforce.y); cstore(op + 2, cforce.z);
+                } else {
+                    V3 tot{0.f, 0.f, 0.f};
+                    for (int k = 0; k < ks; ++k) {
+                        const float* ip = part + (int64_t)k * NB * 3;
+                        tot = tot + V3{cload(ip), cload(ip + 1), cload(ip + 2)};
+                    }
+                    tot = tot + cforce;
+                    float* os = BP.contact_sum + (env_here() * NB + b) * 3;
+                    os[0] = tot.x; os[1] = tot.y; os[2] = tot.z;
+                }
             }
         }
     }
@@ -2405,7 +2430,9 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
         if (lane == 0) {
             int bid_here = bid;  // (the address of the progress word is formed here: kept from the prologue it is a spilled 64-bit pointer)
             asm volatile("" : "+s"(bid_here));
-            __hip_atomic_store(a.job_progress + (bid_here * LL_WPB + (threadIdx.x >> 6)), a.job_epoch * (a.p.nsub + 1) + sjob + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            // (max, not store: a job that is overtaken - its successor gave up waiting and has already handed over further - must not turn
+            // the word back)
+            __hip_atomic_fetch_max(a.job_progress + (bid_here * LL_WPB + (threadIdx.x >> 6)), a.job_epoch * (a.p.nsub + 1) + sjob + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         timeline();
         return;
@@ -2496,6 +2523,15 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
             if (lb == 0 && live_env) strict::post_env(Z.b, Z.t, P, mid, t_new, e, s4, fell);
         }
     }
+    }
+    if constexpr (JOBS) if (!mono) {
+        // the step of this pair is complete: jobs of it that have not started yet must not (see the look at the word in the prologue)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            int bid_here = bid;
+            asm volatile("" : "+s"(bid_here));
+            __hip_atomic_fetch_max(a.job_progress + (bid_here * LL_WPB + (threadIdx.x >> 6)), a.job_epoch * (a.p.nsub + 1) + a.p.nsub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     timeline();
 }
