@@ -409,8 +409,13 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
     // ~4 env pairs per wave slot; beyond that the launch is throughput bound and pairs of equals are cheaper)
     // (the kernels with joint-limit rows or a ball run 2 waves per SIMD: there pairs of equals measured best, profiles/r02g_racket_ball_sweep.txt)
     e->pair_mix_default = c->pair_mix_permille < 0 ? 1 : 0;
-    e->pair_mix_permille = c->pair_mix_permille < 0 ? ((n <= 12288 && !c->joint_limits) ? 250 : 0) : c->pair_mix_permille;
-    e->job_mono_permille = c->job_mono_permille < 0 ? 250 : c->job_mono_permille;  // defaults: measured best (profiles/r02_job_mono_sweep.txt)
+    // defaults: measured best.  Round 2 (profiles/r02_job_mono_sweep.txt): 250 / 250; re-swept on the round-4 kernel (profiles/r04_mono_mix_sweep.txt:
+    // 5 x 4 grid at 8192 envs, then across TGS / djokovic / per-clip shapes / 4096 and 12288 envs): 60 / 150 is +1 .. 2 % everywhere - with the
+    // walk the heaviest chains are shorter, fewer pairs need to keep their substeps in one workgroup
+    e->pair_mix_permille = c->pair_mix_permille < 0 ? ((n <= 12288 && !c->joint_limits) ? 150 : 0) : c->pair_mix_permille;
+    // (above 12288 envs, with joint limits or with a ball - where the heavy x light mix is off - 250 stays 0.2 .. 1 % better)
+    e->job_mono_default = c->job_mono_permille < 0 ? 1 : 0;
+    e->job_mono_permille = c->job_mono_permille < 0 ? ((n <= 12288 && !c->joint_limits) ? 60 : 250) : c->job_mono_permille;
     if (e->pair_mix_permille > 500 || e->job_mono_permille > 1000) { set_error("v2p_env_create: pair_mix_permille <= 500, job_mono_permille <= 1000"); v2p_env_destroy(e); return V2P_ERR_INVALID; }
     if (rc == V2P_OK && e->substep_jobs) {
         const size_t words = (size_t)v2p::job_wave_slots(N) + 2;
@@ -599,6 +604,7 @@ int v2p_env_attach_ball(v2p_env* e, const v2p_ball_cfg* c, const v2p_ball_buffer
         if (rc != V2P_OK) return rc;
     }
     if (e->pair_mix_default) e->pair_mix_permille = 0;
+    if (e->job_mono_default) e->job_mono_permille = 250;
     return V2P_OK;
 }
 

@@ -144,6 +144,7 @@ struct v2p_env {
     int32_t* pair_list[2];    // [256][N] envs of each load bin in arrival order: what the NEXT launch looks its envs up in (double
     int32_t* pair_starts[2];  // [256]    first rank of each bin                  buffered: a launch reads one set and fills the other)
     int pair_buf;             // the set the next launch reads
+    int job_mono_default;     // job_mono_permille was left at its default (v2p_env_attach_ball moves it)
     int32_t* pair_slot_env;   // [N] env of each wave slot of the running launch: looked up by the job of the first substep, read by the later ones
     int pair_period;          // 0 = pairing off (v2p_sim_cfg.pair_envs_by_load = 0), else on
     int substeps_per_sim;     // substeps of one simulate() call
