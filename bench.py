@@ -289,6 +289,12 @@ def profiles_view():
             valu = {"flops_per_launch": wave_ops * lanes, "lanes_active_per_valu_op": lanes,
                     "valu_insts_per_wave": g("SQ_INSTS_VALU") / g("SQ_WAVES"),
                     "wave_time_issuing_valu": g("SQ_ACTIVE_INST_VALU") / g("SQ_WAVE_CYCLES"),
+                    # what bounds the kernel while its wave slots are full: cycles between two VALU instructions of a SIMD that holds three
+                    # waves (SQ_WAVE_CYCLES counts quad-cycles of wave residency) against the issue ceiling of a saturated SIMD measured by
+                    # tools/ubench/valu_issue.hip (profiles/r04_valu_issue.txt: 2.67 .. 2.88 nominal cycles per v_fma_f32, 2 .. 8 waves per SIMD)
+                    "valu_issue": {"cycles_per_inst_per_simd_at_3_waves": 4.0 * g("SQ_WAVE_CYCLES") / 3.0 / g("SQ_INSTS_VALU"), "ceiling_cycles_per_inst": 2.7,
+                                   "frac": 2.7 / (4.0 * g("SQ_WAVE_CYCLES") / 3.0 / g("SQ_INSTS_VALU")),
+                                   "float_math_share_of_valu": (g("SQ_INSTS_VALU_FMA_F32") + g("SQ_INSTS_VALU_MUL_F32") + g("SQ_INSTS_VALU_ADD_F32") + g("SQ_INSTS_VALU_TRANS_F32")) / g("SQ_INSTS_VALU")},
                     "source": "from_profiles: " + c.get("source", "profiles/valu_counters.json")}
         except Exception:
             valu = None
