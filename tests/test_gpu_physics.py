@@ -286,7 +286,19 @@ def test_config1_four_envs_one_clip_whole_epoch():
     _epoch_against_oracles(MotionLib(tabs, DEV), tabs, 4, steps=32, seed=7, sigma=0.17)
 
 
-def _epoch_against_oracles(lib, tabs, n, steps, seed, sigma, **env):
+def test_epoch_under_the_references_solver_choice():
+    """The reference's yaml names TGS (cfg/amass_im.yaml:41, solver_type 1): the same epoch comparison - physics per element on every
+    env, rewards, flags - with the engine's TGS selected the way the reference selects it, through the sim block."""
+    from vid2player3d_amd import motion_tables, synth
+    from vid2player3d_amd.model import load_baked_model
+    from vid2player3d_amd.motion_lib import MotionLib
+
+    bm = load_baked_model()
+    tabs = motion_tables.build_tables(synth.make_clips(11, 8, 90, 160), bm.parents, bm.local_pos)
+    _epoch_against_oracles(MotionLib(tabs, DEV), tabs, 32, steps=12, seed=41, sigma=0.4, oracle_solver=1, sim_overrides={"physx": dict(PHYSX_AMASS_IM)})
+
+
+def _epoch_against_oracles(lib, tabs, n, steps, seed, sigma, oracle_solver=0, **env):
     """`steps` control steps after one reset, teacher-forced per control step: before every step the C oracle is set to
     the engine's state, both take the step (the oracle with the kernel's contact vertices), the physics results are compared at
     the one-step tolerances on EVERY env, and the task oracle continues from the ORACLE's result with its own sticky buffers:
@@ -300,7 +312,8 @@ def _epoch_against_oracles(lib, tabs, n, steps, seed, sigma, **env):
     ref = O.TaskOracle(tabs, N(task._reset_ref_motion_ids), bm.kp.astype(np.float32), term_heights=th)
     ref.reset_all(times)
     close(N(task.obs_buf), ref.obs_buf, 5e-6, "reset obs")
-    oracle = BatchOracle(bm, n, default_params())
+    oracle = BatchOracle(bm, n, default_params(solver_type=oracle_solver))
+    assert task.contact_solver == ("tgs" if oracle_solver else "pgs")
     died = 0
     for k in range(steps):
         oracle.set_state(N(task._humanoid_root_states), N(task._dof_pos), N(task._dof_vel))

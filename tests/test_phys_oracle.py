@@ -133,3 +133,38 @@ def test_contact_manifold_is_bounded_and_deterministic(model):
         sel = ids[b][ids[b] >= 0]
         assert len(set(sel.tolist())) == len(sel)
         assert all(v // 64 == b for v in sel)
+
+
+def test_sensitivity_leaves_the_states_alone_and_finds_the_ill_conditioned_envs():
+    """BatchOracle.sensitivity (the conditioning term of the GPU parity bounds): the batch's states are untouched (the step that follows
+    equals the step without it, bit for bit), the result is reproducible, and on contact-rich states it spreads over orders of magnitude -
+    the step map of the model amplifies float32-rounding perturbations 10 x in the median env and 1000 x in a few (tools/gain_probe.py)."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from oracle.phys_oracle import BatchOracle, default_params
+    from tools.gain_probe import fixture
+
+    n = 96
+    bm, root, dpos, dvel, pd, force, torque = fixture(n, seed=3, lift=-0.75, vel_sigma=0.2)   # fallen: ~8 touched links per env
+    a = BatchOracle(bm, n, default_params())
+    a.set_state(root, dpos, dvel)
+    s1 = a.sensitivity(pd, force, torque, seed=5)
+    ra = a.step(pd, force, torque)
+    b = BatchOracle(bm, n, default_params())
+    b.set_state(root, dpos, dvel)
+    rb = b.step(pd, force, torque)
+    for k in ("dvel", "rb", "cf", "root", "dpos"):
+        assert np.array_equal(ra[k], rb[k]), k
+    c = BatchOracle(bm, n, default_params())
+    c.set_state(root, dpos, dvel)
+    s2 = c.sensitivity(pd, force, torque, seed=5)
+    assert np.array_equal(s1["dvel"], s2["dvel"]) and (s1["dvel"] >= 0).all() and np.isfinite(s1["cf"]).all()
+    gain = s1["dvel"].max(axis=1) / 1e-6
+    assert np.median(gain) > 3.0 and gain.max() > 20.0 * np.median(gain), (np.median(gain), gain.max())
+    # without contacts the step is well conditioned everywhere
+    d = BatchOracle(bm, n, default_params(enable_contact=0))
+    d.set_state(root + np.array([0, 0, 2.0] + [0] * 10), dpos, dvel)
+    g0 = d.sensitivity(pd, force, torque, seed=5)["dvel"].max(axis=1) / 1e-6
+    assert g0.max() < 40.0, g0.max()
