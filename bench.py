@@ -555,8 +555,9 @@ def main():
         # the fractions describe the rollout average: from the whole-epoch block when the requested region is not whole epochs
         k_ms, k_cnt, k_stride = (whole["kernel_ms"], whole["kernel_launches_timed"], max(1, args.kernel_events)) if whole else (phys_ms, launches, ev_stride)
         achieved = ALGO_BYTES_PER_ENV_STEP * ng / (k_ms * 1e-3) / 1e9
-        roof = {"bound": "valu-latency", "bound_note": "the contract's choices are hbm | mfma; this kernel is bound by neither: its waves wait on dependent VALU / LDS chains "
-                "(DESIGN.md 4-5).  achieved / peak / frac are the HBM figures BASELINE.json asks for; valu_frac is the fraction that says how good the kernel is",
+        roof = {"bound": "valu-issue", "bound_note": "the contract's choices are hbm | mfma; this kernel is bound by neither: while its wave slots are full its SIMDs issue one VALU "
+                "instruction per ~3.4 cycles against a measured ceiling of ~2.7 (valu.valu_issue), at ~24 of 64 lanes active; late in an epoch a launch is as long as "
+                "its heaviest env pair (DESIGN.md 4-5).  achieved / peak / frac are the HBM figures BASELINE.json asks for; valu_frac says how good the kernel is",
                 "kernel": "physics_ll_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "frac_of": "hbm",
                 "traffic": None if traffic is None else traffic["bytes_per_launch"],
                 "traffic_fetch_x2": None if traffic is None else traffic.get("bytes_per_launch_fetch_x2"),
