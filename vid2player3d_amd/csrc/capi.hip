@@ -428,6 +428,7 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
         // substeps per job: 1 while the launch is short of jobs, 2 once there are plenty (>= CUs x 32 env pairs: measured crossover at
         // 16384 envs - a job's prologue / hand-over is ~8 % of a one-substep job); V2P_JOB_LEN: A/B switch
         e->job_len = getenv("V2P_JOB_LEN") ? atoi(getenv("V2P_JOB_LEN")) : 0;
+        e->job_lead = getenv("V2P_JOB_LEAD") ? atoi(getenv("V2P_JOB_LEAD")) : -1;  // -1: the engine decides (see launch_env_physics_ll)
         e->job_interleave = getenv("V2P_JOB_INTERLEAVE") ? atoi(getenv("V2P_JOB_INTERLEAVE")) : 1;  // (A/B switch)
     }
     if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->pair_key, sizeof(int32_t) * N), "hipMalloc(pair_key)");

@@ -92,6 +92,7 @@ struct PhysArgs {
     int32_t* job_progress;
     float* job_hand;  // [nsub - 1][N][HAND_FLOATS] state hand-off between the substep jobs of an env pair: slot s = the state after substep s
     int32_t job_len;         // substeps per job
+    int32_t job_lead;        // ... of the first job of a cut pair (>= 1)
     int32_t job_interleave;  // 1: heavy x light slots and pairs of equals are dispatched alternately (see the kernel)
     long job_timeout_spins;  // polls (of ~0.4 us) after which a job stops waiting for its predecessor and recomputes the earlier substeps
     PostArgs post;

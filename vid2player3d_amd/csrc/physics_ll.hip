@@ -391,7 +391,11 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
     const int64_t slot = ((int64_t)bid * LL_WPB + (threadIdx.x >> 6)) * 2 + half;
     const bool live_env = slot < N;
     const int jlen = JOBS ? a.job_len : 1;  // substeps per job (v2p_env: job_len; 1 = one job per substep)
-    const bool first_job = mono || sjob == 0, last_job = mono || (sjob + 1) * jlen >= a.p.nsub;
+    // first substep of job j of a cut pair: the FIRST job may be longer than the others (job_lead substeps: one hand-over less per pair,
+    // while the jobs that end a launch keep the fine granularity)
+    const int jlead = JOBS ? a.job_lead : 1;
+    auto jstart = [&](int j) -> int { return j <= 0 ? 0 : jlead + (j - 1) * jlen; };
+    const bool first_job = mono || sjob == 0, last_job = mono || jstart(sjob + 1) >= a.p.nsub;
     // the inputs of this job were written by another workgroup of this launch - unless that one did not show up in time (below)
     bool handed = !mono && sjob > 0;
     int* const progress = JOBS ? a.job_progress + (bid * LL_WPB + (threadIdx.x >> 6)) : nullptr;
@@ -574,7 +578,7 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
     }
 #endif
     // substeps of this job (a job that gave up waiting replays the earlier ones)
-    const int sub0 = handed ? sjob * jlen : 0, sub1 = mono ? nsub : (nsub ? ((sjob + 1) * jlen < nsub ? (sjob + 1) * jlen : nsub) : 0);
+    const int sub0 = handed ? jstart(sjob) : 0, sub1 = mono ? nsub : (nsub ? (jstart(sjob + 1) < nsub ? jstart(sjob + 1) : nsub) : 0);
     auto ldin = [&](const float* p) -> float { return handed ? cload(p) : *p; };
 
     // inputs of the fused pre-physics, REQUESTED here, in front of the hand-over loads (inline asm that waits for its own loads), and used
@@ -620,7 +624,7 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
             x = V3{c1.x, c1.y, c1.z};
             xd = V3{c1.w, c2.x, c2.y};
             w = V3{c2.z, c2.w, c3.x};
-            if (a.actions && valid && sjob * jlen < a.p.hold_sub) {
+            if (a.actions && valid && jstart(sjob) < a.p.hold_sub) {
                 float* const wp = park_all + (threadIdx.x >> 6) * LDS_FLOATS_PER_WAVE + base;
                 wp[PARK_TAR * 64] = c3.y; wp[(PARK_TAR + 1) * 64] = c3.z; wp[(PARK_TAR + 2) * 64] = c3.w;
                 wp[25 + PARK_TAR * 64] = c4.x; wp[25 + (PARK_TAR + 1) * 64] = c4.y; wp[25 + (PARK_TAR + 2) * 64] = c4.z;
@@ -641,7 +645,7 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
             x = V3{c1.x, c1.y, c1.z};
             xd = V3{c1.w, c2.x, c2.y};
             w = V3{c2.z, c2.w, c3.x};
-            if (a.actions && valid && sjob * jlen < a.p.hold_sub) {
+            if (a.actions && valid && jstart(sjob) < a.p.hold_sub) {
                 // the residual wrench of the fused step travels with the root's chunks while a later job still needs it (it is held for the
                 // first hold_sub substeps only): force behind w.z, torque in chunk 54
                 f4 c4, c5;
@@ -771,7 +775,7 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
         const bool wrench_on = sub < P.hold_sub;
         const bool last = sub == nsub - 1;
         // a substep that is being recomputed by a job that gave up waiting for its predecessor: it publishes nothing (the predecessor does)
-        const bool replay = JOBS && !mono && sub < sjob * jlen;
+        const bool replay = JOBS && !mono && sub < jstart(sjob);
         LLPH(0);
         // per-link model constants are (re)loaded where they are used (L1/K$ hits) instead of pinning ~20 registers for the whole
         // kernel; the opaque index keeps the compiler from hoisting the loads back out of the substep loop
@@ -2410,7 +2414,7 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
             }
             if (root && valid && live_env) {
                 cstore4(ho + 4 * 48, xd.y, xd.z, w.x, w.y);
-                if (a.actions && (sjob + 1) * jlen < a.p.hold_sub) {  // the next job still applies the residual wrench: it travels along
+                if (a.actions && jstart(sjob + 1) < a.p.hold_sub) {  // the next job still applies the residual wrench: it travels along
                     const float* wp = park_all + (threadIdx.x >> 6) * LDS_FLOATS_PER_WAVE + base;
                     cstore4(ho + 4 * 49, w.z, wp[PARK_TAR * 64], wp[(PARK_TAR + 1) * 64], wp[(PARK_TAR + 2) * 64]);
                     cstore4(ho + 4 * 54, wp[25 + PARK_TAR * 64], wp[25 + (PARK_TAR + 1) * 64], wp[25 + (PARK_TAR + 2) * 64], 0.f);
@@ -2663,6 +2667,7 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s, float* actions, int* fuse
     a.job_timeout_spins = env->job_timeout_spins;
     a.job_interleave = env->job_interleave;
     a.job_len = 1;
+    a.job_lead = 1;
     a.job_mono = (int)blocks;
     auto job_grid = [&](int& rc) -> dim3 {
         rc = V2P_OK;
@@ -2678,7 +2683,14 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s, float* actions, int* fuse
             a.job_mono = (int)(blocks * (unsigned)env->job_mono_permille / 1000u);
         }
         a.job_len = !cut ? 1 : (env->job_len >= 1 ? env->job_len : (((int)blocks >= env->job_len2_blocks && env->p.nsub % 2 == 0) ? 2 : 1));
-        const unsigned njobs = (unsigned)((env->p.nsub + a.job_len - 1) / a.job_len);
+        // (job_lead: substeps of the first job of a cut pair; 0 / out of range = job_len, i.e. jobs of equal length; -1 = the engine's
+        // choice: with one-substep jobs the first job takes two substeps - one hand-over less per pair (a third of the hand-over traffic
+        // at four substeps) while the jobs that END a launch stay one substep long; measured +0.3 % at 8192 envs, +1.3 % at 12288, three
+        // substeps in the first job -4.7 %: profiles/r04_job_lead.txt)
+        // (not with a ball: 12.68 vs 12.79 M)
+        const int lead_req = env->job_lead >= 0 ? env->job_lead : ((a.job_len == 1 && env->p.nsub >= 4 && !env->ball) ? 2 : 0);
+        a.job_lead = (cut && lead_req >= 1 && lead_req < env->p.nsub) ? lead_req : a.job_len;
+        const unsigned njobs = 1u + (unsigned)((env->p.nsub - a.job_lead + a.job_len - 1) / a.job_len);
         return dim3((unsigned)a.job_mono + (blocks - (unsigned)a.job_mono) * njobs);
     };
     // every production instantiation is cut into substep jobs and runs post-physics in the epilogue of an env's last job (v2p_env_step);
