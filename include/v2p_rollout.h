@@ -34,7 +34,7 @@ extern "C" {
 #define V2P_NUM_OBS 461
 #define V2P_MOTION_STATE_DIM 331  /* root_pos3 root_rot4 dof_pos69 root_vel3 root_ang_vel3 dof_vel69 key_pos12 rb_pos72 rb_rot96 */
 #define V2P_CONTEXT_DIM 378       /* body_pos72 body_rot96 dof_pos69 body_pos_gt72 dof_pos_gt69 (humanoid_smpl_im.py:202) */
-#define V2P_ABI_VERSION 11
+#define V2P_ABI_VERSION 12
 
 typedef enum {
     V2P_OK = 0,
@@ -220,6 +220,13 @@ typedef struct {
                                  * their own copy (v2p_ball_cfg.bounce_threshold_velocity).  Must be >= 0. */
     int32_t num_velocity_iterations; /* 0 (amass_im.yaml:43).  The engine's solvers have no separate velocity pass: any other value is
                                  * REFUSED (V2P_ERR_UNSUPPORTED) rather than ignored. */
+    /* ---- ABI 12 */
+    int32_t kernel_build;       /* the library holds two builds of the link-per-lane physics kernel (same source, same results to float32
+                                 * rounding): 1 = three waves per SIMD with the contact records parked in LDS (fastest where the launch is
+                                 * bound by instruction issue: BASELINE's 8192 envs), 2 = two waves per SIMD with everything in registers
+                                 * (5 - 7 % faster where a launch is as long as its heaviest env pair: small batches).  0 = the engine
+                                 * chooses by env count (2 at <= 5120 envs: measured, profiles/r04e_dual_build.txt).  v2p_env_kernel_build
+                                 * tells which one a batch runs. */
 } v2p_sim_cfg;
 
 /* Caller-owned DEVICE buffers the engine reads/writes; these are the tensors the reference
@@ -291,6 +298,9 @@ int v2p_env_set_schedule(v2p_env* e, int schedule);
 
 /* index (0/1) of the CURRENT target inside v2p_env_buffers.target; the other one is the previous target */
 int v2p_env_target_index(const v2p_env* e);
+
+/* which build of the link-per-lane kernel the batch runs (v2p_sim_cfg.kernel_build): 1 = LDS-parked / 3 waves per SIMD, 2 = registers / 2 */
+int v2p_env_kernel_build(const v2p_env* e);
 
 /* diagnostics for tests: contact vertex ids chosen in the last substep, [N,24,4] int32, body*64+vertex or -1
  * (needs v2p_sim_cfg.debug_contacts >= 1) */

@@ -225,6 +225,42 @@ class PhysOracle:
         self.ball_body_force = bc[6:9].copy()  # force on the ball from the humanoid's links, last substep
         return cf, df, ids.reshape(NB, 4), per_sim, hit, bc[:6].reshape(2, 3)
 
+    def ball_sensitivity(self, pd_target=None, ext_force=None, ext_torque=None, nsub=4, hold=2, sub_per_sim=2, trials=8, eps_pos=2e-7, eps_vel=1e-6, seed=0):
+        """CONDITIONING of the control step with the ball this instance is about to take (call it before step_ball(); humanoid and ball
+        states are left untouched) - BatchOracle.sensitivity for one env with a ball: the largest change, over `trials` runs whose
+        humanoid and ball states are perturbed at float32-rounding size, of the rigid-body state [24,13], the net contact forces of the
+        last substep / summed over the simulate() calls [24,3], the ball after each simulate() [nsim,13] and the forces on the ball [3,3]."""
+        nst, nbl = C.sizeof(OState), C.sizeof(OBall)
+        s0, b0 = C.string_at(C.addressof(self.state), nst), C.string_at(C.addressof(self.ball), nbl)
+        st = np.frombuffer((C.c_char * nst).from_address(C.addressof(self.state)), dtype=np.float64)  # pos 3 | quats 96 | velocity 75
+        rng = np.random.default_rng(seed)
+
+        def run():
+            cf, _, _, ps, _, bc = self.step_ball(pd_target, ext_force, ext_torque, nsub, hold, sub_per_sim)
+            return {"rb": self.get_state()[3], "cf": cf.copy(), "cfs": self.contact_force_sum.copy(), "ball": ps.copy(),
+                    "bc": np.concatenate([bc.reshape(-1), self.ball_body_force]).reshape(3, 3)}
+
+        base = run()
+        sens = {k: np.zeros_like(v) for k, v in base.items()}
+        for _ in range(trials):
+            C.memmove(C.addressof(self.state), s0, nst)
+            C.memmove(C.addressof(self.ball), b0, nbl)
+            st[0:3] += eps_pos * rng.normal(size=3)
+            q = st[3:99].reshape(24, 4)
+            q += eps_pos * rng.normal(size=q.shape)
+            q /= np.linalg.norm(q, axis=-1, keepdims=True)
+            st[99:] += eps_vel * rng.normal(size=st.size - 99)
+            b = self.get_ball()
+            b[0:3] += eps_pos * rng.normal(size=3)
+            b[7:13] += eps_vel * rng.normal(size=6) * np.array([1, 1, 1, 30, 30, 30])  # (spins are tens of rad/s: one float32 ulp is larger there)
+            self.set_ball(b)
+            out = run()
+            for k in sens:
+                np.maximum(sens[k], np.abs(out[k] - base[k]), out=sens[k])
+        C.memmove(C.addressof(self.state), s0, nst)
+        C.memmove(C.addressof(self.ball), b0, nbl)
+        return sens
+
     def diagnostics(self):
         out = np.zeros(8)
         self.lib.v2p_oracle_diagnostics(C.byref(self.model), C.byref(self.params), C.byref(self.state), _dptr(out))

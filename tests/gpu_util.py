@@ -47,19 +47,27 @@ def make_task(num_envs, motion_lib, motion_ids=None, sim_overrides=None, **env_o
     return task
 
 
-def close(a, b, tol, what=""):
+def close(a, b, tol, what="", sens=None, k_sens=16.0):
+    """|a - b| <= tol * max(1, max|b|) everywhere (+ k_sens * sens per element: the conditioning of the oracle's own step there, see
+    rows_close)."""
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     assert a.shape == b.shape, (what, a.shape, b.shape)
     if a.size == 0:
         return
-    err = np.abs(a - b).max()
-    lim = tol * max(1.0, np.abs(b).max())
+    flat = tol * max(1.0, np.abs(b).max())
+    err = np.abs(a - b)
+    lim = flat if sens is None else flat + k_sens * np.asarray(sens, dtype=np.float64)
+    over = err > lim
+    use = float((err / np.maximum(lim, 1e-300)).max())
     assert np.isfinite(a).all(), what + ": non-finite values"
+    if sens is not None and (err > flat).any():
+        print("[close] %s: %d of %d elements need the conditioning term (largest error there = %.1f x sensitivity)"
+              % (what, int((err > flat).sum()), err.size, float((err[err > flat] / np.maximum(np.asarray(sens, dtype=np.float64)[err > flat], 1e-300)).max())))
     if os.environ.get("V2P_CLOSE_REPORT"):  # A/B of kernel variants: print how much of each tolerance is used instead of asserting
-        print("[close] %-40s err %.3e  limit %.3e  used %.3f" % (what, err, lim, err / lim))
+        print("[close] %-40s err %.3e  limit %.3e  used %.3f" % (what, err.max(), flat, use))
         return
-    assert err <= lim, "%s: max abs err %.3e > %.1e" % (what, err, lim)
+    assert not over.any(), "%s: max abs err %.3e, %.2f x its bound (%.1e%s)" % (what, err.max(), use, flat, "" if sens is None else " + %g x sensitivity" % k_sens)
 
 
 def rows_close(a, b, atol, rtol, what, sens=None, k_sens=16.0):

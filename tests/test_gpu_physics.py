@@ -206,6 +206,34 @@ def test_tgs_option_matches_oracle(mlib):
     assert np.abs(got["rb"][..., 7:] - got_p["rb"][..., 7:]).max() > 1e-3
 
 
+@pytest.mark.parametrize("build", [1, 2])
+def test_both_builds_of_the_kernel_match_oracle(mlib, build):
+    """The library holds two builds of the link-per-lane kernel (v2p_sim_cfg.kernel_build: 1 = contact records parked in LDS, three waves
+    per SIMD; 2 = registers only, two waves) and picks by env count - the small fixtures of this file would otherwise only ever see
+    build 2.  Each build on its own against the oracle: PGS standing, TGS, joint limits on a fallen fixture, PD only; a wrong value is refused."""
+    from vid2player3d_amd.model import load_baked_model
+    from vid2player3d_amd.racket import with_racket
+
+    name = {1: "lds-parked, 3 waves per SIMD", 2: "registers, 2 waves per SIMD"}[build]
+    task = make_task(8, mlib, kernel_build=build)
+    assert task.kernel_build() == name
+    task.close()
+    for kw in (dict(contact=True, seed=2, lift=0.0), dict(contact=True, seed=2, lift=-0.1, solver="tgs"), dict(contact=False, seed=1),
+               dict(contact=True, seed=62, lift=-0.75, vel_sigma=0.2, limits=True, body_model=with_racket(load_baked_model())[0], act_sigma=0.5)):
+        what = "build %d %s" % (build, " ".join("%s=%s" % (k, v) for k, v in kw.items() if k in ("contact", "solver", "limits", "lift")))
+        (got, ref), = _run_pair(mlib, 48, what=what, kernel_build=build, **kw)
+        _compare(got, ref, what, contact=kw["contact"])
+    with pytest.raises(RuntimeError, match="kernel_build"):
+        make_task(8, mlib, kernel_build=3)
+
+
+def test_engine_picks_the_build_by_env_count(mlib):
+    small, large = make_task(64, mlib), make_task(8192, mlib)
+    assert small.kernel_build().startswith("registers") and large.kernel_build().startswith("lds-parked")
+    small.close()
+    large.close()
+
+
 PHYSX_AMASS_IM = {"num_threads": 4, "solver_type": 1, "num_position_iterations": 4, "num_velocity_iterations": 0, "contact_offset": 0.02, "rest_offset": 0.0,
                   "bounce_threshold_velocity": 0.2, "max_depenetration_velocity": 10.0, "default_buffer_size_multiplier": 10.0}  # cfg/amass_im.yaml:39-48
 
@@ -480,11 +508,14 @@ def test_substep_jobs_are_invisible(mlib, n):
             assert np.array_equal(x, y), "step %d, tensor %d: %d of %d values differ (max %.3e)" % (k, j, int((x != y).sum()), x.size, float(np.abs(x.astype(np.float64) - y).max()))
 
 
+@pytest.mark.parametrize("build", [1, 2])
 @pytest.mark.parametrize("what,env", [("tgs", dict(contact_solver="tgs")), ("pd only", dict(enable_contact=False)), ("limits", dict(joint_limits=True))])
-def test_substep_jobs_are_invisible_in_every_instantiation(mlib, what, env):
+def test_substep_jobs_are_invisible_in_every_instantiation(mlib, what, env, build):
     """TGS, the contact-free kernel and the joint-limit kernel cut into substep jobs (forced: at this size the engine would keep whole
-    control steps per workgroup) == one workgroup per env pair, bit for bit, over several steps incl. the fused post-physics."""
+    control steps per workgroup) == one workgroup per env pair, bit for bit, over several steps incl. the fused post-physics; in either
+    build of the kernel (v2p_sim_cfg.kernel_build)."""
     n = 1500
+    env = dict(env, kernel_build=build)
     if what == "limits":
         from vid2player3d_amd.model import load_baked_model
         from vid2player3d_amd.racket import with_racket

@@ -107,6 +107,13 @@ def test_ball_step_matches_oracle(mlib, mode, lift, limits, player):
     _ball_step_vs_oracle(mlib, mode, lift, limits, player)
 
 
+@pytest.mark.parametrize("mode,limits", [("hit", True), ("body", False), ("ground", False)])
+def test_ball_step_with_the_lds_parked_build(mlib, mode, limits):
+    """kernel_build=1: the build that full-size batches run (the engine gives 32-env fixtures the register build, which is what every
+    other small test of this file sees)."""
+    _ball_step_vs_oracle(mlib, mode, 0.0, limits, "djokovic", kernel_build=1)
+
+
 @pytest.mark.parametrize("mode", ["hit", "body"])
 def test_ball_step_with_one_body_shape_per_clip(mlib, mode):
     """racket + ball on per-clip body shapes (three differently scaled bodies, each with the racket folded into its wrist): every env
@@ -124,11 +131,11 @@ def test_ball_step_with_six_substeps_per_simulate_call(mlib, mode):
     _ball_step_vs_oracle(mlib, mode, 0.0, True, "djokovic", substeps=6)
 
 
-def _ball_step_vs_oracle(mlib, mode, lift, limits, player, shapes=None, substeps=2, n=32, subset=None, steps=2):
+def _ball_step_vs_oracle(mlib, mode, lift, limits, player, shapes=None, substeps=2, n=32, subset=None, steps=2, **env):
     """subset: the envs that get an oracle (all by default); every comparison is restricted to them."""
     sub = np.arange(n) if subset is None else np.asarray(sorted(int(i) for i in subset))
     rng = np.random.default_rng({"flight": 1, "ground": 2, "hit": 3, "body": 4, "joint": 5, "serve": 6}[mode] + int(10 * lift))
-    extra = {} if shapes is None else {"body_model": shapes, "motion_shape_ids": np.arange(8) % len(shapes)}
+    extra = dict(env, **({} if shapes is None else {"body_model": shapes, "motion_shape_ids": np.arange(8) % len(shapes)}))
     task = make_rb_task(n, mlib, joint_limits=limits, player=player, sim_overrides={"substeps": substeps}, **extra)
     rl = task.racket_geometry["racket_link"]
     assert rl == (17 if player == "nadal" else 22)
@@ -171,20 +178,23 @@ def _ball_step_vs_oracle(mlib, mode, lift, limits, player, shapes=None, substeps
         task._physics_step()
         torch.cuda.synchronize()
         _, pd, _, force, torque = O.pre_physics(act, N(task.reset_buf), dpos_before, rb0[:, 0, 3:7], bm.kp.astype(np.float32))
-        per_sim, hit, bc, rbs, ids, cf, bbf, cfs = [], [], [], [], [], [], [], []
+        per_sim, hit, bc, rbs, ids, cf, bbf, cfs, sens = [], [], [], [], [], [], [], [], []
         for k, e in enumerate(sub):
             oracles[k].set_ball(ball_before[e])
+            # conditioning of the oracle's own step (float32-rounding perturbations of its inputs): see test_gpu_physics.py
+            sens.append(oracles[k].ball_sensitivity(pd_target=pd[e], ext_force=force[e], ext_torque=torque[e], nsub=2 * substeps, hold=substeps, sub_per_sim=substeps, seed=step))
             c, _, i, ps, h, b = oracles[k].step_ball(pd_target=pd[e], ext_force=force[e], ext_torque=torque[e], nsub=2 * substeps, hold=substeps, sub_per_sim=substeps)
             per_sim.append(ps); hit.append(h); bc.append(b); rbs.append(oracles[k].get_state()[3]); ids.append(i); cf.append(c); bbf.append(oracles[k].ball_body_force); cfs.append(oracles[k].contact_force_sum)
         per_sim, hit, bc, rbs, ids, cf, bbf, cfs = map(np.stack, (per_sim, hit, bc, rbs, ids, cf, bbf, cfs))
+        sens = {k: np.stack([s[k] for s in sens]) for k in sens[0]}
         assert np.array_equal(N(task.debug_contacts())[sub], ids), "hull contact vertices differ"
         got_ps = N(task._ball_states_per_sim)[sub]
         ball_before = ball_before[sub]
         close(got_ps[..., 0:3], per_sim[..., 0:3], 2e-5, "%s ball pos (step %d)" % (mode, step))
         qs = np.sign(np.sum(got_ps[..., 3:7] * per_sim[..., 3:7], -1, keepdims=True))
         close(got_ps[..., 3:7] * qs, per_sim[..., 3:7], 1e-4, "ball quat")
-        close(got_ps[..., 7:10], per_sim[..., 7:10], 5e-4, "%s ball vel (step %d)" % (mode, step))
-        close(got_ps[..., 10:13], per_sim[..., 10:13], 5e-4, "%s ball spin (step %d)" % (mode, step))
+        close(got_ps[..., 7:10], per_sim[..., 7:10], 5e-4, "%s ball vel (step %d)" % (mode, step), sens=sens["ball"][..., 7:10])
+        close(got_ps[..., 10:13], per_sim[..., 10:13], 5e-4, "%s ball spin (step %d)" % (mode, step), sens=sens["ball"][..., 10:13])
         assert np.array_equal(N(task._ball_root_states)[sub], got_ps[:, -1])
         assert np.array_equal(N(task._racket_ball_contact_per_sim)[sub], hit), "racket hit flags"
         # the reference's sticky flag and its per-step edge (humanoid_smpl_im_mvae.py:773-779), kept by the physics launch itself
@@ -192,13 +202,13 @@ def _ball_step_vs_oracle(mlib, mode, lift, limits, player, shapes=None, substeps
         now = (hit.any(axis=1) & ~has_hit) if substeps <= 2 else np.zeros(len(sub), dtype=bool)
         has_hit |= now
         assert np.array_equal(N(task._has_racket_ball_contact_now)[sub], now) and np.array_equal(N(task._has_racket_ball_contact)[sub], has_hit)
-        close(N(task._ball_contact_forces)[sub], bc, 2e-2, "contact forces on the ball")
-        close(N(task._ball_body_contact_force)[sub], bbf, 2e-2, "contact force on the ball from the humanoid's links")
+        close(N(task._ball_contact_forces)[sub], bc, 2e-2, "contact forces on the ball", sens=sens["bc"][:, 0:2])
+        close(N(task._ball_body_contact_force)[sub], bbf, 2e-2, "contact force on the ball from the humanoid's links", sens=sens["bc"][:, 2])
         rb = N(task._rigid_body_state).reshape(n, 24, 13)[sub]
         close(rb[..., 0:3], rbs[..., 0:3], 2e-5, "rb pos")
-        close(rb[..., 7:13], rbs[..., 7:13], 1e-3, "rb vel")
-        close(N(task._contact_forces)[sub], cf, 2e-2, "net contact forces (the racket's link carries the reaction of the ball)")
-        close(N(task._contact_forces_sum)[sub], cfs, 2e-2, "_contact_forces_sum: net contact forces summed over the two simulate() calls")
+        close(rb[..., 7:13], rbs[..., 7:13], 1e-3, "rb vel", sens=sens["rb"][..., 7:13])
+        close(N(task._contact_forces)[sub], cf, 2e-2, "net contact forces (the racket's link carries the reaction of the ball)", sens=sens["cf"])
+        close(N(task._contact_forces_sum)[sub], cfs, 2e-2, "_contact_forces_sum: net contact forces summed over the two simulate() calls", sens=sens["cfs"])
         if lift == 0.0:  # standing on the ground: the feet carry the weight in both simulate() calls
             assert np.abs(cfs - cf).max() > 1.0, "the first simulate() call contributes"
         # the racket rigid body = the wrist frame moved by the weld offset

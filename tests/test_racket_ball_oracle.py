@@ -206,3 +206,32 @@ def test_racket_model_inherits_gain_scales_and_refuses_a_second_racket():
     with pytest.raises(ValueError):
         R.with_racket(m1)
     assert np.allclose(scaled.scaled(1.1).kp / plain.scaled(1.1).kp, 1.5 * 90.0 / 75.0)
+
+
+def test_ball_sensitivity_leaves_the_states_alone(models):
+    """PhysOracle.ball_sensitivity (the conditioning term of the GPU parity bounds with a ball): humanoid and ball states are restored
+    bit for bit, the step taken afterwards is the unperturbed one, and a standing humanoid with a ball in flight is well conditioned
+    in the ball (free flight) and has a finite, positive figure on the links in contact."""
+    _, (m, geom) = models
+    o = PhysOracle(m, default_params(), kp=m.kp.astype(np.float32), kd=m.kd.astype(np.float32))
+    root = np.zeros(13); root[2] = 0.93; root[3:7] = BASE
+    o.set_state(root, np.zeros(69), np.zeros(69))
+    o.attach_ball(geom)
+    ball = np.zeros(13); ball[0:3] = [2.0, 0, 1.5]; ball[6] = 1; ball[7:10] = [-10.0, 0, 1.0]
+    o.set_ball(ball)
+    for _ in range(6):  # settle onto the feet
+        o.step_ball(pd_target=np.zeros(69), nsub=4, hold=0, sub_per_sim=2)
+    s0, b0 = o.get_state(), o.get_ball()
+    sens = o.ball_sensitivity(pd_target=np.zeros(69), nsub=4, hold=0, sub_per_sim=2)
+    for x, y in zip(s0, o.get_state()):
+        assert np.array_equal(x, y)
+    assert np.array_equal(b0, o.get_ball())
+    twin = PhysOracle(m, default_params(), kp=m.kp.astype(np.float32), kd=m.kd.astype(np.float32))
+    twin.set_state(s0[0], s0[1], s0[2])
+    twin.attach_ball(geom)
+    twin.set_ball(b0)
+    a = o.step_ball(pd_target=np.zeros(69), nsub=4, hold=0, sub_per_sim=2)
+    b = twin.step_ball(pd_target=np.zeros(69), nsub=4, hold=0, sub_per_sim=2)
+    assert np.allclose(a[0], b[0], atol=1e-9) and np.allclose(a[3], b[3], atol=1e-12)
+    assert sens["rb"].shape == (24, 13) and sens["ball"].shape == (2, 13) and sens["bc"].shape == (3, 3)
+    assert 0 < sens["ball"][:, 7:10].max() < 1e-4 and 0 < sens["rb"][:, 7:13].max() < 1.0 and np.isfinite(sens["cf"]).all()

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "libv2p_rollout.so")
 
 NUM_BODIES, NUM_DOF, NUM_ACTIONS, NUM_OBS = 24, 69, 75, 461
 MOTION_STATE_DIM, CONTEXT_DIM = 331, 378
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 c_f = C.POINTER(C.c_float)
 c_i32 = C.POINTER(C.c_int32)
@@ -43,7 +43,7 @@ class SimCfg(C.Structure):
                 ("reward_specs", C.c_float * 8), ("freeze_terminated_envs", C.c_int32), ("schedule", C.c_int32), ("pair_envs_by_load", C.c_int32),
                 ("solver_type", C.c_int32), ("substep_jobs", C.c_int32), ("job_mono_permille", C.c_int32), ("pair_mix_permille", C.c_int32), ("debug_contacts", C.c_int32),
                 ("joint_limits", C.c_int32), ("limit_margin", C.c_float),
-                ("rest_offset", C.c_float), ("bounce_threshold_velocity", C.c_float), ("num_velocity_iterations", C.c_int32)]
+                ("rest_offset", C.c_float), ("bounce_threshold_velocity", C.c_float), ("num_velocity_iterations", C.c_int32), ("kernel_build", C.c_int32)]
 
 
 class EnvBuffers(C.Structure):
@@ -109,6 +109,7 @@ def load():
         "v2p_env_post_physics": [vp, vp],
         "v2p_env_push_state": [vp, vp, C.c_int64, C.c_int, vp],
         "v2p_env_target_index": [vp],
+        "v2p_env_kernel_build": [vp],
         "v2p_env_set_schedule": [vp, C.c_int],
         "v2p_env_debug_contacts": [vp, vp, vp],
         "v2p_env_debug_contacts_substeps": [vp, vp, vp],
@@ -136,7 +137,7 @@ def load():
 EXPORTED_SYMBOLS = (
     "v2p_model_create", "v2p_model_destroy", "v2p_mlib_create", "v2p_mlib_destroy", "v2p_motion_state", "v2p_reward", "v2p_reset_flags",
     "v2p_obs_imitation", "v2p_obs_imitation_packed", "v2p_policy_head", "v2p_gae", "v2p_env_create", "v2p_env_create_shapes", "v2p_env_destroy", "v2p_env_reset", "v2p_env_context", "v2p_env_step", "v2p_env_pre_physics", "v2p_env_physics", "v2p_env_export",
-    "v2p_env_post_physics", "v2p_env_push_state", "v2p_env_target_index", "v2p_env_set_schedule", "v2p_env_debug_contacts", "v2p_env_debug_contacts_substeps", "v2p_env_debug_pairing", "v2p_env_attach_ball", "v2p_env_check", "v2p_env_check_async", "v2p_env_job_recoveries", "v2p_env_profile_begin", "v2p_env_profile_begin_sampled", "v2p_env_profile_end", "v2p_last_error", "v2p_abi_version",
+    "v2p_env_post_physics", "v2p_env_push_state", "v2p_env_target_index", "v2p_env_kernel_build", "v2p_env_set_schedule", "v2p_env_debug_contacts", "v2p_env_debug_contacts_substeps", "v2p_env_debug_pairing", "v2p_env_attach_ball", "v2p_env_check", "v2p_env_check_async", "v2p_env_job_recoveries", "v2p_env_profile_begin", "v2p_env_profile_begin_sampled", "v2p_env_profile_end", "v2p_last_error", "v2p_abi_version",
 )
 
 

@@ -50,9 +50,14 @@ def build(force=False, verbose=False, lib_out=None, tag=""):
     flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-fno-vectorize", "-fno-slp-vectorize", "-Wall",
              "-Wno-unused-function"]
     procs = []
-    for s in SOURCES:
-        obj = os.path.join(CSRC, s.replace(".hip", tag + ".o"))
+    # (physics_ll.hip is compiled twice: the default object and the register build, in its own namespace - see csrc/capi.hip)
+    for s in SOURCES + ["physics_ll.hip:regs"]:
+        regs = s.endswith(":regs")
+        s = s.split(":")[0]
+        obj = os.path.join(CSRC, s.replace(".hip", ("_regs" if regs else "") + tag + ".o"))
         fl = list(flags)
+        if regs:
+            fl += ["-Dv2p=v2p_regs", "-DV2P_LL_WPS=2", "-DV2P_LL_WPS_BALL=2", "-DV2P_LL_WPS_LIMITS=2", "-DV2P_LL_PARK2=0", "-DV2P_LL_PARK3=0"]
         if s in ("motion_state.hip", "task_ops.hip"):
             # the task-side kernels restate torch elementwise code: no FMA contraction, so that ill-conditioned spots of the
             # reference itself (acos of a dot product next to 1 in slerp / angle-axis) round the way torch rounds them

@@ -42,6 +42,25 @@ struct DeviceGuard {
 
 }  // namespace v2p
 
+// The link-per-lane physics kernel is built TWICE from the same source (build.py): the default object (168 VGPRs, three waves per SIMD,
+// contact records and phase-dead values parked in LDS) and `physics_ll_regs.o` (-Dv2p=v2p_regs -DV2P_LL_WPS=2 -DV2P_LL_PARK2=0
+// -DV2P_LL_PARK3=0: 256 VGPRs, two waves per SIMD, everything in registers).  Where a launch is as long as its heaviest env pair - up to
+// ~5000 envs on one GPU - the register build is 5 - 7 % faster (no LDS round trips in the heaviest wave's chain), where the wave slots
+// are full the LDS build is 15 % faster (profiles/r04_env_count_sweep.txt).  The second object lives in its own namespace;
+// what it calls from this file is forwarded here.
+namespace v2p_regs {
+void set_error(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    v2p::set_error("%s", buf);
+}
+int check_hip(hipError_t e, const char* what) { return v2p::check_hip(e, what); }
+int launch_env_physics_ll(v2p_env* e, hipStream_t s, float* actions, int* fused_post);
+}  // namespace v2p_regs
+
 using namespace v2p;
 
 namespace v2p {
@@ -325,6 +344,7 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
     if (c->schedule != 0 && c->schedule != 1) { set_error("v2p_env_create: schedule must be 0 or 1"); delete e; return V2P_ERR_INVALID; }
     if (c->solver_type != 0 && c->solver_type != 1) { set_error("v2p_env_create: solver_type must be 0 (PGS) or 1 (TGS)"); delete e; return V2P_ERR_INVALID; }
     if (c->solver_type == 1 && c->schedule == 1) { set_error("v2p_env_create: the env-per-lane cross-check kernel solves PGS only"); delete e; return V2P_ERR_UNSUPPORTED; }
+    if (c->kernel_build < 0 || c->kernel_build > 2) { set_error("v2p_env_create: kernel_build must be 0 (engine's choice), 1 (LDS-parked) or 2 (registers)"); delete e; return V2P_ERR_INVALID; }
     if (c->num_velocity_iterations != 0) {
         set_error("v2p_env_create: sim.physx.num_velocity_iterations = %d: the engine's contact solvers have no separate velocity pass (the reference's configs use 0)", c->num_velocity_iterations);
         delete e;
@@ -429,6 +449,10 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
         // 16384 envs - a job's prologue / hand-over is ~8 % of a one-substep job); V2P_JOB_LEN: A/B switch
         e->job_len = getenv("V2P_JOB_LEN") ? atoi(getenv("V2P_JOB_LEN")) : 0;
         e->job_lead = getenv("V2P_JOB_LEAD") ? atoi(getenv("V2P_JOB_LEAD")) : -1;  // -1: the engine decides (see launch_env_physics_ll)
+    }
+    {   // which build of the link-per-lane kernel this batch runs (see the head of this file): by env count, V2P_LL_BUILD=regs|lds overrides (A/B)
+        const char* lb = getenv("V2P_LL_BUILD");
+        e->ll_regs_build = lb ? (strcmp(lb, "regs") == 0) : c->kernel_build ? (c->kernel_build == 2) : (n <= 5120);
         e->job_interleave = getenv("V2P_JOB_INTERLEAVE") ? atoi(getenv("V2P_JOB_INTERLEAVE")) : 1;  // (A/B switch)
     }
     if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->pair_key, sizeof(int32_t) * N), "hipMalloc(pair_key)");
@@ -551,7 +575,8 @@ static int physics_launch(v2p_env* e, hipStream_t s, float* actions, int* fused_
         if (e->prof_stride > 1) rec = rec && (L % e->prof_stride) == (L / e->prof_period) % e->prof_stride;
     }
     if (rec) (void)hipEventRecord(e->prof_ev[2 * e->prof_n], s);
-    int rc = e->schedule != 0 ? launch_env_physics(e, s) : launch_env_physics_ll(e, s, actions, fused_post);
+    int rc = e->schedule != 0 ? launch_env_physics(e, s)
+                              : (e->ll_regs_build ? v2p_regs::launch_env_physics_ll(e, s, actions, fused_post) : launch_env_physics_ll(e, s, actions, fused_post));
     if (rec) { (void)hipEventRecord(e->prof_ev[2 * e->prof_n + 1], s); ++e->prof_n; }
     return rc;
 }
@@ -752,6 +777,7 @@ int v2p_env_set_schedule(v2p_env* e, int schedule) {
 }
 
 int v2p_env_target_index(const v2p_env* e) { return e ? e->cur_target : V2P_ERR_INVALID; }
+int v2p_env_kernel_build(const v2p_env* e) { return e ? (e->ll_regs_build ? 2 : 1) : V2P_ERR_INVALID; }
 
 int v2p_env_debug_contacts(v2p_env* e, int32_t* out, void* stream) {
     if (!e || !out) { set_error("v2p_env_debug_contacts: bad argument"); return V2P_ERR_INVALID; }

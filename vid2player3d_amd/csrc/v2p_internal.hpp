@@ -156,6 +156,7 @@ struct v2p_env {
     int job_interleave;
     int job_len;              // substeps per job; 0 = the engine decides (2 for launches of >= job_len2_blocks env pairs, else 1)
     int job_len2_blocks;
+    int ll_regs_build;        // 1: this batch runs the register build of the link-per-lane kernel (two waves per SIMD), chosen by env count
     int job_lead;             // substeps of the FIRST job of a cut pair (0 = like the others, -1 = the engine decides)
     int64_t job_recoveries;   // jobs that gave up waiting and recomputed, as last fetched (v2p_env_check / _check_async)
     int job_epoch;

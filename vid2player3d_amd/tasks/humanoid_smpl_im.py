@@ -458,6 +458,7 @@ class HumanoidSMPLIM:
         c.substep_jobs = int(env.get("substep_jobs", True)) if c.schedule == 0 else 0
         c.job_mono_permille = int(env.get("job_mono_permille", -1))  # -1: the engine's defaults
         c.pair_mix_permille = int(env.get("pair_mix_permille", -1))
+        c.kernel_build = int(env.get("kernel_build", 0))  # 0: the engine chooses by env count
         # joint ranges of the MJCF enforced as limit rows (Isaac Gym always enforces them; only the racket arm of the player MJCFs has
         # DOFs narrower than a full turn, the amass MJCF has none)
         c.joint_limits = int(env.get("joint_limits", False))
@@ -727,6 +728,10 @@ class HumanoidSMPLIM:
         """Synchronise (v2p_env_check: raises on a HIP error) and fetch the substep jobs' recovery counter."""
         _lib.check(self._lib.v2p_env_check(self._h_env, self._stream()), "v2p_env_check")
         self._warn_job_recoveries()
+
+    def kernel_build(self):
+        """Which of the library's two builds of the physics kernel this batch runs (v2p_sim_cfg.kernel_build)."""
+        return {1: "lds-parked, 3 waves per SIMD", 2: "registers, 2 waves per SIMD"}[int(self._lib.v2p_env_kernel_build(self._h_env))]
 
     def job_recoveries(self):
         """Substep jobs that gave up waiting for their predecessor and recomputed the earlier substeps themselves (as last fetched by
