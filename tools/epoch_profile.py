@@ -23,10 +23,11 @@ def main():
     ap.add_argument("--num-envs", type=int, default=8192)
     ap.add_argument("--action-noise", type=float, default=0.17)
     ap.add_argument("--job-mono", type=int, default=None, help="v2p_sim_cfg.job_mono_permille")
+    ap.add_argument("--kernel-build", type=int, default=None, help="v2p_sim_cfg.kernel_build (1 = LDS-parked, 2 = registers)")
     ap.add_argument("--brief", action="store_true", help="one line: ms of every 4th step")
     args = ap.parse_args()
     n = args.num_envs
-    task = bench.build_task(n, 0, seed=7, substep_jobs=True, env_extra={} if args.job_mono is None else {"job_mono_permille": args.job_mono})
+    task = bench.build_task(n, 0, seed=7, substep_jobs=True, env_extra={k: v for k, v in (("job_mono_permille", args.job_mono), ("kernel_build", args.kernel_build)) if v is not None})
     from vid2player3d_amd.model import load_baked_model
     parents = np.asarray(load_baked_model().parents)
     dev = task.device
