@@ -57,7 +57,10 @@ def build(force=False, verbose=False, lib_out=None, tag=""):
         obj = os.path.join(CSRC, s.replace(".hip", ("_regs" if regs else "") + tag + ".o"))
         fl = list(flags)
         if regs:
-            fl += ["-Dv2p=v2p_regs", "-DV2P_LL_WPS=2", "-DV2P_LL_WPS_BALL=2", "-DV2P_LL_WPS_LIMITS=2", "-DV2P_LL_PARK2=0", "-DV2P_LL_PARK3=0"]
+            # (the ILP scheduler: this build runs where a launch is as long as its heaviest wave's chain, +1.6 % at 4096 envs, +2.1 % at 1024;
+            # for the default build, bound by instruction issue at three waves per SIMD, the same switch costs 0.3 %: profiles/r04e_dual_build.txt)
+            fl += ["-Dv2p=v2p_regs", "-DV2P_LL_WPS=2", "-DV2P_LL_WPS_BALL=2", "-DV2P_LL_WPS_LIMITS=2", "-DV2P_LL_PARK2=0", "-DV2P_LL_PARK3=0",
+                   "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
         if s in ("motion_state.hip", "task_ops.hip"):
             # the task-side kernels restate torch elementwise code: no FMA contraction, so that ill-conditioned spots of the
             # reference itself (acos of a dot product next to 1 in slerp / angle-axis) round the way torch rounds them
@@ -67,7 +70,7 @@ def build(force=False, verbose=False, lib_out=None, tag=""):
             # of the file for why the flags are spelled out instead of -ffast-math); V2P_LL_STRICT_MATH=1 builds it precise (A/B, bisecting)
             fl = [f if f != "-ffp-contract=fast" else "-ffp-contract=fast-honor-pragmas" for f in fl]
             fl = fl + (["-DV2P_LL_STRICT_MATH"] if os.environ.get("V2P_LL_STRICT_MATH") else LL_MATH_FLAGS)
-        extra = os.environ.get("V2P_FLAGS_" + s.split(".")[0].upper())  # experiments: per-file flag override, e.g. V2P_FLAGS_PHYSICS_LL="-O1"
+        extra = os.environ.get("V2P_FLAGS_" + s.split(".")[0].upper() + ("_REGS" if regs else ""))  # experiments: per-object flag override, e.g. V2P_FLAGS_PHYSICS_LL="-O1" (V2P_FLAGS_PHYSICS_LL_REGS: the register build)
         if extra:
             fl = [f for f in fl if f != "-O3"] + extra.split()
         cmd = [_hipcc()] + fl + ["-c", os.path.join(CSRC, s), "-o", obj]
