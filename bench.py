@@ -435,6 +435,11 @@ def main():
 
     n = args.num_envs
     G = max(1, args.groups)
+    if G > 1 and args.kernel_build is None:
+        # the engine picks the build of its physics kernel by a batch's env count (register build <= 5120 envs: the launch of a lone small batch
+        # is as long as its heaviest wave); G batches that SHARE the GPU are bound by instruction issue together: the three-wave build
+        # (8192 envs as 2 x 4096: 20.9 M against 19.4 M with the engine's per-batch choice, profiles/r04e_dual_build.txt)
+        args.kernel_build = 1
     if n % G:
         raise SystemExit("--num-envs %d is not a multiple of --groups %d" % (n, G))
     if stub:

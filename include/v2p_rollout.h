@@ -195,7 +195,7 @@ typedef struct {
     int32_t job_mono_permille;  /* substep_jobs: share of the env pairs (the heaviest) whose substeps stay in one workgroup; -1 = default (60) */
     int32_t pair_mix_permille;  /* pair_envs_by_load: share of the envs (the heaviest) that share their wave with one of the lightest envs
                                  * instead of with an equally heavy one (a wave costs the union of its two envs' contact structure, and the
-                                 * heaviest envs are the critical path of the launch); 0 = pairs of equals only; -1 = default (150; 0 above 12288 envs,
+                                 * heaviest envs are the critical path of the launch); 0 = pairs of equals only; -1 = default (150, 500 with the register build - kernel_build; 0 above 12288 envs,
                                  * with joint limits or with a ball: measured) */
     int32_t debug_contacts;     /* diagnostics, off (0) by default: 1 = keep the contact vertex ids of the last substep
                                  * (v2p_env_debug_contacts; 384 B of extra stores per env-step), 2 = of EVERY substep as well

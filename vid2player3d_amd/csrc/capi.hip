@@ -428,11 +428,17 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
     // (mixing trades total work for a shorter critical path: it pays while the launch is as long as its heaviest pair, i.e. up to
     // ~4 env pairs per wave slot; beyond that the launch is throughput bound and pairs of equals are cheaper)
     // (the kernels with joint-limit rows or a ball run 2 waves per SIMD: there pairs of equals measured best, profiles/r02g_racket_ball_sweep.txt)
+    {   // which build of the link-per-lane kernel this batch runs (see the head of this file): by env count, V2P_LL_BUILD=regs|lds overrides (A/B)
+        const char* lb = getenv("V2P_LL_BUILD");
+        e->ll_regs_build = lb ? (strcmp(lb, "regs") == 0) : c->kernel_build ? (c->kernel_build == 2) : (n <= 5120);
+    }
     e->pair_mix_default = c->pair_mix_permille < 0 ? 1 : 0;
     // defaults: measured best.  Round 2 (profiles/r02_job_mono_sweep.txt): 250 / 250; re-swept on the round-4 kernel (profiles/r04_mono_mix_sweep.txt:
     // 5 x 4 grid at 8192 envs, then across TGS / djokovic / per-clip shapes / 4096 and 12288 envs): 60 / 150 is +1 .. 2 % everywhere - with the
     // walk the heaviest chains are shorter, fewer pairs need to keep their substeps in one workgroup
-    e->pair_mix_permille = c->pair_mix_permille < 0 ? ((n <= 12288 && !c->joint_limits) ? 150 : 0) : c->pair_mix_permille;
+    // (the register build runs where a launch is as long as its heaviest wave: there every heavy env takes a light partner, 500 - +1.3 % at 1024
+    // and 4096 envs against 150, profiles/r04e_dual_build.txt)
+    e->pair_mix_permille = c->pair_mix_permille < 0 ? ((n <= 12288 && !c->joint_limits) ? (e->ll_regs_build ? 500 : 150) : 0) : c->pair_mix_permille;
     // (above 12288 envs, with joint limits or with a ball - where the heavy x light mix is off - 250 stays 0.2 .. 1 % better)
     e->job_mono_default = c->job_mono_permille < 0 ? 1 : 0;
     e->job_mono_permille = c->job_mono_permille < 0 ? ((n <= 12288 && !c->joint_limits) ? 60 : 250) : c->job_mono_permille;
@@ -450,11 +456,7 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
         e->job_len = getenv("V2P_JOB_LEN") ? atoi(getenv("V2P_JOB_LEN")) : 0;
         e->job_lead = getenv("V2P_JOB_LEAD") ? atoi(getenv("V2P_JOB_LEAD")) : -1;  // -1: the engine decides (see launch_env_physics_ll)
     }
-    {   // which build of the link-per-lane kernel this batch runs (see the head of this file): by env count, V2P_LL_BUILD=regs|lds overrides (A/B)
-        const char* lb = getenv("V2P_LL_BUILD");
-        e->ll_regs_build = lb ? (strcmp(lb, "regs") == 0) : c->kernel_build ? (c->kernel_build == 2) : (n <= 5120);
-        e->job_interleave = getenv("V2P_JOB_INTERLEAVE") ? atoi(getenv("V2P_JOB_INTERLEAVE")) : 1;  // (A/B switch)
-    }
+    e->job_interleave = getenv("V2P_JOB_INTERLEAVE") ? atoi(getenv("V2P_JOB_INTERLEAVE")) : 1;  // (A/B switch)
     if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->pair_key, sizeof(int32_t) * N), "hipMalloc(pair_key)");
     if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->pair_pos, sizeof(int32_t) * N), "hipMalloc(pair_pos)");
     if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->perm, sizeof(int32_t) * N), "hipMalloc(perm)");
