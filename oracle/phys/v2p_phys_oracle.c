@@ -29,7 +29,9 @@
  *   contacts: hull vertices with z < contact_offset; <=4 per body (deepest, farthest,
  *        extreme left/right); rows n,t1,t2 per point; bias = d/h (d>=0) or
  *        max(erp*d/h, -max_depenetration_velocity) (d<0); box friction |lt| <= mu*ln
- *   PGS (solver_type 0): n_iter sweeps, bodies ascending, points in slot order, rows n,t1,t2;
+ *   PGS (solver_type 0): n_iter sweeps in ALTERNATING direction - even sweeps take the bodies in ascending order, odd sweeps in
+ *        descending order (symmetric Gauss-Seidel over the bodies); inside a body always: limit rows of its joint, hull points in slot
+ *        order, rows n,t1,t2;
  *   TGS (solver_type 1): one sweep per time slice h/n_iter with re-evaluated gaps (see the substep)
  *   v+ = v* + Mt^-1 J^T lambda;  angular damping 1/(1+h*c); |w| clamp; integrate.
  */
@@ -879,6 +881,17 @@ static int substep_impl(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s
          * and runs ONE sweep against  d_c(k) / (h - k hs)  (separated: do not cross the plane in the time that is left)  or
          * max(erp d_c(k) / hs, -max_depenetration)  (penetrating: correct a fraction per slice); impulses accumulate and are clamped
          * on the accumulated value as in PGS. */
+        int sweep_rev[NB * MAXC_BODY + 6 + 3 * NJ]; /* the points stop by stop, last stop first (see the sweep) */
+        {
+            int n = 0;
+            for (int end = nc; end > 0;) {
+                const int stop = rows[end - 1].body;
+                int st = end - 1;
+                while (st > 0 && rows[st - 1].body == stop) --st;
+                for (int c = st; c < end; ++c) sweep_rev[n++] = c;
+                end = st;
+            }
+        }
         for (int it = 0; it < p->n_iter; ++it) {
             if (p->solver_type == 1) {
                 double hs = h / p->n_iter;
@@ -891,7 +904,15 @@ static int substep_impl(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s
                     bias[3 * c] = gap[c] >= 0 ? gap[c] / (h - it * hs) : fmax(p->erp * gap[c] / hs, -p->max_depen_vel);
                 }
             }
-            for (int c = 0; c < nc; ++c)
+            /* PGS: the sweeps alternate their direction over the STOPS (a stop = everything that belongs to one body: the limit rows
+             * of its joint, its hull points, the ball point on its hull / the ball x racket points; the ball x ground point is a stop
+             * of its own after the last body).  Odd sweeps take the stops in descending order, the rows inside a stop in the same
+             * order as ever.  The fixed point is the same; a sweep that starts where the previous one ended is what lets the engine's
+             * tree walk go back and forth instead of returning to the first body after every sweep.  TGS sweeps all run forward (every
+             * slice ends with all links moved: there is no return trip to save).  g_experiment bit 2 (value 4): forward only (A/B). */
+            const int backward = p->solver_type == 0 && (it & 1) && !(g_experiment & 4);
+            for (int cc = 0; cc < nc; ++cc) {
+                const int c = backward ? sweep_rev[cc] : cc;
                 for (int a = 0; a < (rows[c].kind == 3 ? 1 : 3); ++a) {
                     int row = 3 * c + a;
                     double rel = bias[row];
@@ -907,6 +928,7 @@ static int substep_impl(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s
                     lam[row] = nl;
                     for (int col = 0; col < NDT; ++col) v[col] += Tr[row * NDT + col] * dl;
                 }
+            }
         }
         for (int c = 0; c < nc; ++c) {
             const crow_t *r = &rows[c];
@@ -998,19 +1020,22 @@ void v2p_oracle_ball_aero(const v2p_oball *ball, double spin_scale, double force
  * re-evaluated at the start of every simulate() call.  ball_per_sim [nsim][13] (pos quat vel angvel after each call),
  * racket_hit_per_sim [nsim] (1 when the racket-ball contact force was non-zero in the call's last substep, as the reference polls the
  * net contact force tensor after each call), ball_contact [9] of the last substep (from the racket, the ground, the humanoid's links). */
-int v2p_oracle_step_ball(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s, const double *pd_target, const double *ext_force,
+int v2p_oracle_step_ball_io(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s, const double *pd_target, const double *ext_force,
                          const double *ext_torque, int nsub, int hold, int sub_per_sim, double *contact_force, double *dof_force, int *contact_ids,
                          const v2p_oball_params *bp, v2p_oball *ball, double spin_scale, double *ball_per_sim, int *racket_hit_per_sim,
                          double *ball_contact, int *max_hull_points /*[1] nullable: most ball x hull points active in one substep*/,
                          double *contact_force_sum /*[NB*3] nullable: net contact forces summed over the simulate() calls
-                                                                          * (`_contact_forces_sum`, humanoid_smpl_im_mvae.py:781; needs contact_force)*/) {
+                                                                          * (`_contact_forces_sum`, humanoid_smpl_im_mvae.py:781; needs contact_force)*/,
+                            const int *forced_ids /*[nsub][NB*4] nullable: hull vertices to use instead of the selection rule (teacher forcing)*/,
+                            int *own_ids /*[nsub][NB*4] nullable: the rule's own picks*/, double *margins /*[nsub][NB] nullable*/) {
     double f[3] = {0, 0, 0}, bc[9];
     if (contact_force_sum) memset(contact_force_sum, 0, sizeof(double) * NB * 3);
     if (max_hull_points) *max_hull_points = 0;
     for (int i = 0; i < nsub; ++i) {
         if (i % sub_per_sim == 0) v2p_oracle_ball_aero(ball, spin_scale, f);
         int on = i < hold;
-        int rc = substep_impl(m, p, s, pd_target, on ? ext_force : 0, on ? ext_torque : 0, contact_force, dof_force, contact_ids, 0, bp, ball, f, bc);
+        v2p_osub_io io = {forced_ids ? forced_ids + (size_t)i * NB * 4 : 0, own_ids ? own_ids + (size_t)i * NB * 4 : 0, margins ? margins + (size_t)i * NB : 0, 0};
+        int rc = substep_impl(m, p, s, pd_target, on ? ext_force : 0, on ? ext_torque : 0, contact_force, dof_force, contact_ids, &io, bp, ball, f, bc);
         if (rc) return rc;
         if (max_hull_points && g_hull_rows > *max_hull_points) *max_hull_points = g_hull_rows;
         if (i % sub_per_sim == sub_per_sim - 1) {
@@ -1026,6 +1051,16 @@ int v2p_oracle_step_ball(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *
     }
     if (ball_contact) memcpy(ball_contact, bc, sizeof(bc));
     return 0;
+}
+
+int v2p_oracle_step_ball(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s, const double *pd_target, const double *ext_force,
+                         const double *ext_torque, int nsub, int hold, int sub_per_sim, double *contact_force, double *dof_force, int *contact_ids,
+                         const v2p_oball_params *bp, v2p_oball *ball, double spin_scale, double *ball_per_sim, int *racket_hit_per_sim,
+                         double *ball_contact, int *max_hull_points /*[1] nullable: most ball x hull points active in one substep*/,
+                         double *contact_force_sum /*[NB*3] nullable: net contact forces summed over the simulate() calls
+                                                                          * (`_contact_forces_sum`, humanoid_smpl_im_mvae.py:781; needs contact_force)*/) {
+    return v2p_oracle_step_ball_io(m, p, s, pd_target, ext_force, ext_torque, nsub, hold, sub_per_sim, contact_force, dof_force, contact_ids, bp, ball, spin_scale,
+                                   ball_per_sim, racket_hit_per_sim, ball_contact, max_hull_points, contact_force_sum, 0, 0, 0);
 }
 
 int v2p_oracle_sizeof_ball_params(void) { return (int)sizeof(v2p_oball_params); }

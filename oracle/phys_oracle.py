@@ -205,9 +205,11 @@ class PhysOracle:
     def get_ball(self):
         return np.array(list(self.ball.pos) + list(self.ball.quat) + list(self.ball.vel) + list(self.ball.angvel))
 
-    def step_ball(self, pd_target=None, ext_force=None, ext_torque=None, nsub=4, hold=2, sub_per_sim=2):
+    def step_ball(self, pd_target=None, ext_force=None, ext_torque=None, nsub=4, hold=2, sub_per_sim=2, forced_ids=None):
         """One control step with the ball: returns (contact_force [24,3], dof_force, contact ids, ball state after each simulate()
-        [nsim,13], racket-hit flag per simulate() [nsim], force on the ball from racket / ground in the last substep [2,3])."""
+        [nsim,13], racket-hit flag per simulate() [nsim], force on the ball from racket / ground in the last substep [2,3]).
+        forced_ids [nsub,24,4] int32: hull vertices to use instead of the selection rule (teacher forcing, like step()); the rule's own
+        picks and their decision margins are left in self.own_ids [nsub,24,4] / self.margins [nsub,24]."""
         cf, df, ids = np.zeros((NB, 3)), np.zeros(69), np.full(NB * 4, -1, dtype=np.int32)
         nsim = nsub // sub_per_sim
         per_sim, hit, bc, cfs = np.zeros((nsim, 13)), np.zeros(nsim, dtype=np.int32), np.zeros(9), np.zeros((NB, 3))
@@ -215,9 +217,12 @@ class PhysOracle:
         f = None if ext_force is None else np.ascontiguousarray(ext_force, dtype=np.float64)
         t = None if ext_torque is None else np.ascontiguousarray(ext_torque, dtype=np.float64)
         nh = C.c_int(0)
-        rc = self.lib.v2p_oracle_step_ball(C.byref(self.model), C.byref(self.params), C.byref(self.state), _dptr(tar), _dptr(f), _dptr(t), int(nsub), int(hold),
-                                           int(sub_per_sim), _dptr(cf), _dptr(df), _iptr(ids), C.byref(self.ball_params), C.byref(self.ball),
-                                           C.c_double(self.spin_scale), _dptr(per_sim), _iptr(hit), _dptr(bc), C.byref(nh), _dptr(cfs))
+        forced = None if forced_ids is None else np.ascontiguousarray(forced_ids, dtype=np.int32).reshape(nsub, NB * 4)
+        self.own_ids, self.margins = np.full((nsub, NB, 4), -1, dtype=np.int32), np.zeros((nsub, NB))
+        rc = self.lib.v2p_oracle_step_ball_io(C.byref(self.model), C.byref(self.params), C.byref(self.state), _dptr(tar), _dptr(f), _dptr(t), int(nsub), int(hold),
+                                              int(sub_per_sim), _dptr(cf), _dptr(df), _iptr(ids), C.byref(self.ball_params), C.byref(self.ball),
+                                              C.c_double(self.spin_scale), _dptr(per_sim), _iptr(hit), _dptr(bc), C.byref(nh), _dptr(cfs),
+                                              _iptr(forced), _iptr(self.own_ids), _dptr(self.margins))
         self.max_hull_points = int(nh.value)  # most ball x hull points active in one substep of the step
         self.contact_force_sum = cfs  # net contact forces of the links summed over the simulate() calls of the step
         if rc:
@@ -225,7 +230,8 @@ class PhysOracle:
         self.ball_body_force = bc[6:9].copy()  # force on the ball from the humanoid's links, last substep
         return cf, df, ids.reshape(NB, 4), per_sim, hit, bc[:6].reshape(2, 3)
 
-    def ball_sensitivity(self, pd_target=None, ext_force=None, ext_torque=None, nsub=4, hold=2, sub_per_sim=2, trials=8, eps_pos=2e-7, eps_vel=1e-6, seed=0):
+    def ball_sensitivity(self, pd_target=None, ext_force=None, ext_torque=None, nsub=4, hold=2, sub_per_sim=2, trials=8, eps_pos=2e-7, eps_vel=1e-6, seed=0,
+                         forced_ids=None):
         """CONDITIONING of the control step with the ball this instance is about to take (call it before step_ball(); humanoid and ball
         states are left untouched) - BatchOracle.sensitivity for one env with a ball: the largest change, over `trials` runs whose
         humanoid and ball states are perturbed at float32-rounding size, of the rigid-body state [24,13], the net contact forces of the
@@ -236,7 +242,7 @@ class PhysOracle:
         rng = np.random.default_rng(seed)
 
         def run():
-            cf, _, _, ps, _, bc = self.step_ball(pd_target, ext_force, ext_torque, nsub, hold, sub_per_sim)
+            cf, _, _, ps, _, bc = self.step_ball(pd_target, ext_force, ext_torque, nsub, hold, sub_per_sim, forced_ids=forced_ids)
             return {"rb": self.get_state()[3], "cf": cf.copy(), "cfs": self.contact_force_sum.copy(), "ball": ps.copy(),
                     "bc": np.concatenate([bc.reshape(-1), self.ball_body_force]).reshape(3, 3)}
 

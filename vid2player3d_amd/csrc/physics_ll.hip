@@ -288,6 +288,11 @@ constexpr bool PARK3 = V2P_LL_PARK3 != 0;
 #ifndef V2P_LL_WALK
 #define V2P_LL_WALK 1  // 0: the sweep with a leaf -> root -> leaves propagation after every touched group (A/B; the ball / joint-limit kernels use it)
 #endif
+#ifndef V2P_LL_ALT_SWEEP
+#define V2P_LL_ALT_SWEEP 1  // PGS sweeps alternate their direction over the touched links (the model's rule, oracle/phys/v2p_phys_oracle.c): the walk goes
+                            // back and forth and never returns from the last link to the first.  0 = every sweep ascending (the model of rounds 1-3;
+                            // oracle: v2p_oracle_experiment(4)) - A/B only.  (The V2P_LL_WALK=0 path sweeps ascending only.)
+#endif
 #ifndef V2P_LL_DPP_DOWN
 #define V2P_LL_DPP_DOWN 0
 #endif
@@ -1550,9 +1555,13 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                 // LIMITS: the walk also stops at the joints that carry limit rows (their block comes right before the contact block of the link)
                 const unsigned v0 = LIMITS ? m0 | lm0 : m0, v1 = LIMITS ? m1 | lm1 : m1;
                 V3 jt_new{0.f, 0.f, 0.f};  // LIMITS: limit impulse of this joint not yet handed up (its reaction, -jt, goes to the parent)
-                int minfo = 0;
+                // ALT (PGS): odd sweeps visit the stops in DESCENDING order - minfo_rev = the move into a stop from the stop AFTER it (same fields;
+                // the highest stop has none: a backward sweep starts on it, where the forward sweep ended)
+                constexpr bool ALT = V2P_LL_ALT_SWEEP != 0 && !TGS;
+                int minfo = 0, minfo_rev = 0;
                 {
                     int p0 = v0 ? 31 - __clz(v0) : 0, p1 = v1 ? 31 - __clz(v1) : 0;
+                    bool first = true;
                     for (unsigned s0 = v0, s1 = v1; s0 | s1; s0 &= s0 - 1, s1 &= s1 - 1) {
                         const int b0 = s0 ? __ffs(s0) - 1 : p0, b1 = s1 ? __ffs(s1) - 1 : p1;
                         const int selp = half ? p1 : p0, selb = half ? b1 : b0;
@@ -1564,6 +1573,12 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                         const int sd = (half ? M.side_depths[p1] : M.side_depths[p0]) & ~((2 << dl) - 1);
                         // (bit 28: the link itself is not its parent's first child - the one-joint bounce of a limit block needs it)
                         if (valid && lb == selb && ((half ? s1 : s0) != 0u)) minfo = dl | (du << 4) | (dn << 8) | (sd << 12) | ((LIMITS && !firstchild) ? 1 << 28 : 0);
+                        if (ALT && !first) {
+                            // the same pair walked the other way: from the stop b (deeper in the order) back into the stop before it
+                            const int sdr = (half ? M.side_depths[b1] : M.side_depths[b0]) & ~((2 << dl) - 1);
+                            if (valid && lb == selp && ((half ? s1 : s0) != 0u)) minfo_rev = dl | (dn << 4) | (du << 8) | (sdr << 12) | ((LIMITS && !firstchild) ? 1 << 28 : 0);
+                        }
+                        first = false;
                         p0 = b0;
                         p1 = b1;
                     }
@@ -1683,25 +1698,63 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                     }
                     LLSUB(14);
                 };
+                // ---- ball x ground: a stop of its own after the last link - the last rows of a forward sweep, the first of a backward one (point
+                // at -R z of the centre; rows n = z, t1 = x, t2 = y); returns whether any lane's rows changed something
+                auto ball_ground_rows = [&](int done) -> int {
+                    bool bmoved = false;
+                    if (ballground && !((done >> half) & 1)) {
+                        V3 bv{bl[BL_VEL], bl[BL_VEL + 1], bl[BL_VEL + 2]}, bw{bl[BL_ANG], bl[BL_ANG + 1], bl[BL_ANG + 2]};
+                        const V3 rb{0.f, 0.f, -BP.radius};
+                        float lamn = bl[BL_GLAM];
+#pragma unroll
+                        for (int ax = 0; ax < 3; ++ax) {
+                            const V3 dir = ax == 0 ? V3{0.f, 0.f, 1.f} : (ax == 1 ? V3{1.f, 0.f, 0.f} : V3{0.f, 1.f, 0.f});
+                            const V3 jb = cross(rb, dir);
+                            const float wii = BP.inv_mass + BP.inv_inertia * dot(jb, jb);
+                            const float rel = dot(dir, bv) + dot(jb, bw) + (ax == 0 ? bl[BL_GBIAS] : 0.f);
+                            const float old = bl[BL_GLAM + ax];
+                            float nl = old - rel * __builtin_amdgcn_rcpf(wii);
+                            if (ax == 0) nl = fmaxf(nl, 0.f);
+                            else { const float lim = BP.fric_ground * lamn; nl = fminf(fmaxf(nl, -lim), lim); }
+                            const float dl = nl - old;
+                            bl[BL_GLAM + ax] = nl;
+                            if (ax == 0) lamn = nl;
+                            bv = bv + (dl * BP.inv_mass) * dir;
+                            bw = bw + (dl * BP.inv_inertia) * jb;
+                            bmoved = bmoved || dl != 0.f;
+                        }
+                        bl[BL_VEL] = bv.x; bl[BL_VEL + 1] = bv.y; bl[BL_VEL + 2] = bv.z;
+                        bl[BL_ANG] = bw.x; bl[BL_ANG + 1] = bw.y; bl[BL_ANG + 2] = bw.z;
+                    }
+                    const unsigned long long bm = __ballot(bmoved);
+                    return ((unsigned)bm != 0u ? 1 : 0) | ((unsigned)(bm >> 32) != 0u ? 2 : 0);
+                };
+                // an env whose whole sweep changed nothing has reached the fixed point of its rows: it takes no part in the remaining sweeps,
+                // whatever the env it shares the wave with still does (its later sweeps would change nothing - exactly so in the oracle; here
+                // a sweep in the other direction reaches the same links over other moves, i.e. with other rounding)
+                int done = 0;
                 for (int it = 0; it < P.n_iter; ++it) {
-                    unsigned t0 = v0, t1 = v1;
-                    bool moved = false;
+                    unsigned t0 = (done & 1) ? 0u : v0, t1 = (done & 2) ? 0u : v1;
+                    int moved = 0;  // bit h: env h changed something in this sweep (wave-uniform)
+                    const bool backward = ALT && (it & 1);  // (wave-uniform)
                     if (TGS && it > 0) {
                         // gaps advance with the normal velocity the points have after the previous sweep (touched links are current)
 #pragma unroll
                         for (int c = 0; c < 4; ++c) { const V3 rc = CS.cr(c); CS.set_bias(c, CS.bias(c) + hs * (rc.y * w.x - rc.x * w.y + xd.z)); }
                         tgs_irem = 1.f / (h - (float)it * hs);
                     }
+                    if (BALL && backward) moved |= ball_ground_rows(done);  // (the last stop of a forward sweep is the first of a backward one)
                     while (t0 | t1) {
-                        const int b0 = t0 ? __ffs(t0) - 1 : -1, b1 = t1 ? __ffs(t1) - 1 : -1;
-                        t0 &= t0 - 1;
-                        t1 &= t1 - 1;
+                        const int b0 = t0 ? (backward ? 31 - __clz(t0) : __ffs(t0) - 1) : -1, b1 = t1 ? (backward ? 31 - __clz(t1) : __ffs(t1) - 1) : -1;
+                        t0 &= ~(b0 < 0 ? 0u : 1u << b0);
+                        t1 &= ~(b1 < 0 ? 0u : 1u << b1);
                         if (DIAG && a.prof && ((a.prof_heavy ? blockIdx.x < 8u : (blockIdx.x & 63) == 0)) && lane == 0) atomicAdd((unsigned long long*)&a.prof[8], 1ull);
                         // (readfirstlane: wave-uniform by construction, and the compiler must know it - the level loops are scalar loops)
                         const int smv = __builtin_amdgcn_readfirstlane(((live0 && b0 >= 0 && b0 != cur0) ? 1 : 0) | ((live1 && b1 >= 0 && b1 != cur1) ? 2 : 0));
                         int came_down = 0;  // LIMITS: bit h = env h has just come DOWN to its link (the lowest common ancestor of the move lies above it)
                         if (smv) {
-                            const int i0 = __builtin_amdgcn_readlane(minfo, b0 < 0 ? 0 : b0), i1 = __builtin_amdgcn_readlane(minfo, 32 + (b1 < 0 ? 0 : b1));
+                            const int msel = backward ? minfo_rev : minfo;
+                            const int i0 = __builtin_amdgcn_readlane(msel, b0 < 0 ? 0 : b0), i1 = __builtin_amdgcn_readlane(msel, 32 + (b1 < 0 ? 0 : b1));
                             walk_to(b0 < 0 ? 0 : b0, b1 < 0 ? 0 : b1, i0, i1, (smv & 1) != 0, (smv & 2) != 0);
                             if (LIMITS) came_down = smv & (((i0 & 15) < ((i0 >> 8) & 15) ? 1 : 0) | ((i1 & 15) < ((i1 >> 8) & 15) ? 2 : 0));
                         }
@@ -1754,7 +1807,7 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                                     // the joint answers, and so does everything above it: one joint up (the parent turns), one joint down again
                                     live0 = live0 || (sl & 1);
                                     live1 = live1 || (sl & 2);
-                                    moved = true;
+                                    moved |= sl;
                                     walk_to(b0 < 0 ? 0 : b0, b1 < 0 ? 0 : b1, j0i, j1i, (sl & 1) != 0, (sl & 2) != 0);
                                 }
                             }
@@ -1852,45 +1905,20 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                         const unsigned long long chg = __ballot(gn.x != 0.f || gn.y != 0.f || gn.z != 0.f || gf.x != 0.f || gf.y != 0.f || gf.z != 0.f);
                         live0 = live0 || (unsigned)chg != 0u;
                         live1 = live1 || (unsigned)(chg >> 32) != 0u;
-                        moved = moved || chg != 0ull;
+                        moved |= ((unsigned)chg != 0u ? 1 : 0) | ((unsigned)(chg >> 32) != 0u ? 2 : 0);
                         if (DIAG && a.prof && !chg && ((a.prof_heavy ? blockIdx.x < 8u : (blockIdx.x & 63) == 0)) && lane == 0) atomicAdd((unsigned long long*)&a.prof[19], 1ull);
                         LLSUB(11);
                     }
-                    if (BALL) {
-                        // ---- ball x ground: the last rows of the iteration (point at -R z of the centre; rows n = z, t1 = x, t2 = y)
-                        bool bmoved = false;
-                        if (ballground) {
-                            V3 bv{bl[BL_VEL], bl[BL_VEL + 1], bl[BL_VEL + 2]}, bw{bl[BL_ANG], bl[BL_ANG + 1], bl[BL_ANG + 2]};
-                            const V3 rb{0.f, 0.f, -BP.radius};
-                            float lamn = bl[BL_GLAM];
-#pragma unroll
-                            for (int ax = 0; ax < 3; ++ax) {
-                                const V3 dir = ax == 0 ? V3{0.f, 0.f, 1.f} : (ax == 1 ? V3{1.f, 0.f, 0.f} : V3{0.f, 1.f, 0.f});
-                                const V3 jb = cross(rb, dir);
-                                const float wii = BP.inv_mass + BP.inv_inertia * dot(jb, jb);
-                                const float rel = dot(dir, bv) + dot(jb, bw) + (ax == 0 ? bl[BL_GBIAS] : 0.f);
-                                const float old = bl[BL_GLAM + ax];
-                                float nl = old - rel * __builtin_amdgcn_rcpf(wii);
-                                if (ax == 0) nl = fmaxf(nl, 0.f);
-                                else { const float lim = BP.fric_ground * lamn; nl = fminf(fmaxf(nl, -lim), lim); }
-                                const float dl = nl - old;
-                                bl[BL_GLAM + ax] = nl;
-                                if (ax == 0) lamn = nl;
-                                bv = bv + (dl * BP.inv_mass) * dir;
-                                bw = bw + (dl * BP.inv_inertia) * jb;
-                                bmoved = bmoved || dl != 0.f;
-                            }
-                            bl[BL_VEL] = bv.x; bl[BL_VEL + 1] = bv.y; bl[BL_VEL + 2] = bv.z;
-                            bl[BL_ANG] = bw.x; bl[BL_ANG + 1] = bw.y; bl[BL_ANG + 2] = bw.z;
-                        }
-                        if (any64(bmoved)) moved = true;
-                    }
+                    if (BALL && !backward) moved |= ball_ground_rows(done);
                     if (TGS && (live0 || live1)) {
                         walk_close(dneed, false);  // (the links below catch up once, after the last iteration)
                         un_tot = un_new = uf_new = Dw = Dv = V3{0.f, 0.f, 0.f};
                         live0 = live1 = false;
                     }
-                    if (!TGS && !moved) break;  // a whole iteration without any change: the remaining ones would repeat it (PGS: fixed biases)
+                    if (!TGS) {  // (PGS: fixed biases - a sweep without any change would be repeated by the remaining ones)
+                        done |= ~moved & 3;
+                        if (done == 3) break;
+                    }
                 }
                 if (!TGS && (live0 || live1)) walk_close(maxd, true);
                 } else
