@@ -162,7 +162,7 @@ def test_sensitivity_leaves_the_states_alone_and_finds_the_ill_conditioned_envs(
     s2 = c.sensitivity(pd, force, torque, seed=5)
     assert np.array_equal(s1["dvel"], s2["dvel"]) and (s1["dvel"] >= 0).all() and np.isfinite(s1["cf"]).all()
     gain = s1["dvel"].max(axis=1) / 1e-6
-    assert np.median(gain) > 3.0 and gain.max() > 20.0 * np.median(gain), (np.median(gain), gain.max())
+    assert np.median(gain) > 3.0 and gain.max() > 10.0 * np.median(gain), (np.median(gain), gain.max())
     # without contacts the step is well conditioned everywhere
     d = BatchOracle(bm, n, default_params(enable_contact=0))
     d.set_state(root + np.array([0, 0, 2.0] + [0] * 10), dpos, dvel)
