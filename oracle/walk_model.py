@@ -109,14 +109,20 @@ def _solve_row(row, v, lam, Laa, mu):
     return dl
 
 
-def sweep_dense(tree, v0, rows_of, n_iter, mu=1.0):
+def sweep_order(touched, it, alternate):
+    """the touched links in the order sweep `it` takes them: ascending, or (alternate: the model's PGS rule since round 4) ascending in even
+    sweeps and descending in odd ones"""
+    return sorted(touched, reverse=bool(alternate and (it & 1)))
+
+
+def sweep_dense(tree, v0, rows_of, n_iter, mu=1.0, alternate=False):
     v = [x.copy() for x in v0]
     lam = {}
     for a in rows_of:
         for row in rows_of[a]:
             lam[row["id"]] = 0.0
-    for _ in range(n_iter):
-        for a in sorted(rows_of):
+    for it in range(n_iter):
+        for a in sweep_order(rows_of, it, alternate):
             for row in rows_of[a]:
                 dl = _solve_row(row, v[a], lam, tree.Lam[a], mu)
                 if dl != 0.0:
@@ -126,8 +132,11 @@ def sweep_dense(tree, v0, rows_of, n_iter, mu=1.0):
     return v, lam
 
 
-def sweep_walk(tree, v0, rows_of, n_iter, mu=1.0, count=None):
-    """count: optional dict that receives the number of up / down level steps and turns (the cost model of DESIGN.md)"""
+def sweep_walk(tree, v0, rows_of, n_iter, mu=1.0, count=None, alternate=False):
+    """count: optional dict that receives the number of up / down level steps and turns (the cost model of DESIGN.md).
+    alternate: sweeps in alternating direction - a backward sweep starts on the link the forward sweep ended on, so the walk never makes
+    the trip from the last touched link back to the first; the moves themselves (up to the lowest common ancestor, turn, down) are the same
+    in either direction, which is what tests/test_walk_algorithm.py checks against the dense sweep in the same order."""
     n, S = tree.n, tree.S
     dlt = [np.zeros(6) for _ in range(n)]    # velocity change of a link since the start of the sweep, valid where the walk stands
     p_tot = [np.zeros(6) for _ in range(n)]  # impulse a link's subtree has collected so far
@@ -161,10 +170,9 @@ def sweep_walk(tree, v0, rows_of, n_iter, mu=1.0, count=None):
             dlt[j] = tree.Y[j] @ dlt[tree.parents[j]] + S @ tree.Dinv[j] @ (S.T @ p_tot[j])
             stat["down"] += 1
 
-    touched = sorted(rows_of)
     cur, live = None, False
-    for _ in range(n_iter):
-        for a in touched:
+    for it in range(n_iter):
+        for a in sweep_order(rows_of, it, alternate):
             if live and cur is not None and cur != a:
                 move(cur, a)
             cur = a
