@@ -24,8 +24,9 @@
 //     (per-env) shape table through L1/L2; LDS holds the contact records of a link (28 floats per lane) and values a phase does not touch
 //   * 168 VGPRs, 3 waves per SIMD (needs -fno-slp-vectorize: SLP packing costs ~160 registers here)
 //
-// The sequential semantics of the Gauss-Seidel sweep (bodies ascending, points in slot order, rows
-// n, t1, t2) are unchanged, so results agree with the one-env-per-lane kernel and the float64 oracle to rounding.
+// The sequential semantics of the Gauss-Seidel sweep (PGS: bodies ascending in even sweeps and descending in odd ones, TGS: ascending; inside
+// a body the limit rows of its joint, then its points in slot order, rows n, t1, t2) are those of the one-env-per-lane kernel and of the float64
+// oracle, so the results agree with both to rounding.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdlib.h>
@@ -1532,9 +1533,9 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                 const float tgs_pen = P.erp / hs;
                 auto rowbias = [&](float v) -> float { return TGS ? (v >= 0.f ? v * tgs_irem : fmaxf(tgs_pen * v, -P.max_depen)) : v; };
                 if constexpr (WALK) {
-                // ---- the sweep as ONE WALK over the tree.  Solving the touched links one by one in ascending order, iteration after
-                // iteration, visits them in depth-first order, cyclically; between two of them only the links on the tree path
-                // cur -> LCA -> next need anything:
+                // ---- the sweep as ONE WALK over the tree.  Solving the touched links one by one in ascending order visits them in depth-first
+                // order (cyclically, iteration after iteration, when every sweep ascends: TGS; back and forth when the sweeps alternate their
+                // direction: PGS, see ALT below); between two of them only the links on the tree path cur -> LCA -> next need anything:
                 //   up    cur .. LCA: every link hands what its subtree has collected since it last did so (un_new, uf_new) to its parent,
                 //         and the LCA answers what arrives with its own Lambda (Lambda_cc is the response of the whole system at c);
                 //   down  LCA .. next: velocity change of a link = its parent's, carried over the joint, + the joint's answer to everything
