@@ -110,8 +110,8 @@ def _solve_row(row, v, lam, Laa, mu):
 
 
 def sweep_order(touched, it, alternate):
-    """the touched links in the order sweep `it` takes them: ascending, or (alternate: the model's PGS rule since round 4) ascending in even
-    sweeps and descending in odd ones"""
+    """the touched links in the order sweep `it` takes them: ascending (the model), or (alternate: an experiment of round 4, DESIGN.md
+    section 4) ascending in even sweeps and descending in odd ones"""
     return sorted(touched, reverse=bool(alternate and (it & 1)))
 
 

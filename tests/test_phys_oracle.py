@@ -168,3 +168,44 @@ def test_sensitivity_leaves_the_states_alone_and_finds_the_ill_conditioned_envs(
     d.set_state(root + np.array([0, 0, 2.0] + [0] * 10), dpos, dvel)
     g0 = d.sensitivity(pd, force, torque, seed=5)["dvel"].max(axis=1) / 1e-6
     assert g0.max() < 40.0, g0.max()
+
+
+def test_alternating_sweeps_would_cost_accuracy():
+    """Why the PGS sweeps all ascend (round 4): sweeps in alternating direction (v2p_oracle_experiment(4)) would let the
+    engine's tree walk skip the trip from the last touched link back to the first - 8 % fewer instructions - but the link a sweep ends on
+    is then solved twice in a row, and the model's 4 sweeps end farther from the converged solution: in the standing states where the two
+    orders differ at all (about half of them) by a factor of 1.4 (geometric mean), in three of four of those states, +18 % in the mean over
+    all (measured on the envs in which both orders converge to the same solution)."""
+    import ctypes as C
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from oracle.phys_oracle import BatchOracle, default_params, lib
+    from tools.gain_probe import fixture
+
+    n = 512
+    bm, root, dpos, dvel, pd, force, torque = fixture(n, seed=11, lift=0.0, vel_sigma=0.5)
+
+    def run(n_iter, alternate):
+        lib().v2p_oracle_experiment(C.c_int(4 if alternate else 0))
+        try:
+            p = default_params()
+            p.n_iter = n_iter
+            o = BatchOracle(bm, n, p)
+            o.set_state(root, dpos, dvel)
+            return o.step(pd, force, torque, nsub=1, hold=1)["dvel"]
+        finally:
+            lib().v2p_oracle_experiment(C.c_int(0))
+
+    conv_f, conv_a = run(600, False), run(600, True)
+    same = np.abs(conv_f - conv_a).max(axis=1) < 1e-6   # box friction bounded by the current normal impulse: not every env converges
+    assert same.mean() > 0.6
+    res_f = np.abs(run(4, False) - conv_f).max(axis=1)[same]
+    res_a = np.abs(run(4, True) - conv_a).max(axis=1)[same]
+    differ = (res_a != res_f) & (res_a > 0) & (res_f > 0)
+    ratio = float(np.exp(np.mean(np.log(res_a[differ] / res_f[differ]))))
+    worse = float((res_a[differ] > res_f[differ]).mean())
+    print("[sweeps] distance to the converged solution after 4 sweeps over %d envs: mean %.3f (ascending) vs %.3f rad/s (alternating); the orders differ in "
+          "%d envs, there alternating is the farther one in %.0f %%, geometric mean of the ratio %.2f" % (same.sum(), res_f.mean(), res_a.mean(), differ.sum(), 100 * worse, ratio))
+    assert differ.mean() > 0.3 and worse > 0.6 and ratio > 1.2 and res_a.mean() > 1.1 * res_f.mean()

@@ -39,8 +39,9 @@ def test_recursion_matches_the_dense_inverse():
 @pytest.mark.parametrize("alternate", [False, True])
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_walk_equals_the_dense_sweep(name, alternate):
-    """alternate: the model's PGS rule since round 4 - sweeps in alternating direction over the touched links; the walk then goes back and
-    forth (moves towards ancestors and into EARLIER subtrees, which an ascending-only sweep makes only in its wrap-around move)."""
+    """alternate: an experiment of round 4 (not the model: it costs solver accuracy) - sweeps in alternating direction
+    over the touched links; the walk then goes back and forth (moves towards ancestors and into EARLIER subtrees, which an ascending-only
+    sweep makes only in its wrap-around move).  The walk is exact for either order."""
     rng = np.random.default_rng(7 + len(name))
     t = Tree(SMPL_PARENTS, rng)
     v0 = [rng.normal(size=6) for _ in range(t.n)]

@@ -561,12 +561,9 @@ __global__ __launch_bounds__(L) void physics_kernel(PhysArgs a) {
             if (touch && P.n_iter > 0) {
                 for (int it = 0; it < P.n_iter; ++it) {
                     unsigned todo = touch;
-                    // (the sweeps alternate their direction over the touched bodies: ascending in even sweeps, descending in odd ones -
-                    // the model's rule, oracle/phys/v2p_phys_oracle.c; the link-per-lane kernel's tree walk goes back and forth with it)
-                    const bool backward = (it & 1) != 0;
                     while (todo) {
-                        const int b = backward ? 31 - __clz(todo) : __ffs(todo) - 1;
-                        todo &= ~(1u << b);
+                        const int b = __ffs(todo) - 1;
+                        todo &= todo - 1;
                         if (a.prof && blockIdx.x == 0 && lane == 0) atomicAdd((unsigned long long*)&a.prof[8], 1ull);
                         const BodyContacts cur0 = load_body(ws, N, e, b);
                         BodyContacts cur = cur0;

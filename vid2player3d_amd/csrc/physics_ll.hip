@@ -24,9 +24,8 @@
 //     (per-env) shape table through L1/L2; LDS holds the contact records of a link (28 floats per lane) and values a phase does not touch
 //   * 168 VGPRs, 3 waves per SIMD (needs -fno-slp-vectorize: SLP packing costs ~160 registers here)
 //
-// The sequential semantics of the Gauss-Seidel sweep (PGS: bodies ascending in even sweeps and descending in odd ones, TGS: ascending; inside
-// a body the limit rows of its joint, then its points in slot order, rows n, t1, t2) are those of the one-env-per-lane kernel and of the float64
-// oracle, so the results agree with both to rounding.
+// The sequential semantics of the Gauss-Seidel sweep (bodies ascending; inside a body the limit rows of its joint, then its points in slot
+// order, rows n, t1, t2) are those of the one-env-per-lane kernel and of the float64 oracle, so the results agree with both to rounding.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdlib.h>
@@ -290,9 +289,11 @@ constexpr bool PARK3 = V2P_LL_PARK3 != 0;
 #define V2P_LL_WALK 1  // 0: the sweep with a leaf -> root -> leaves propagation after every touched group (A/B; the ball / joint-limit kernels use it)
 #endif
 #ifndef V2P_LL_ALT_SWEEP
-#define V2P_LL_ALT_SWEEP 1  // PGS sweeps alternate their direction over the touched links (the model's rule, oracle/phys/v2p_phys_oracle.c): the walk goes
-                            // back and forth and never returns from the last link to the first.  0 = every sweep ascending (the model of rounds 1-3;
-                            // oracle: v2p_oracle_experiment(4)) - A/B only.  (The V2P_LL_WALK=0 path sweeps ascending only.)
+#define V2P_LL_ALT_SWEEP 0  // 1 = experiment of round 4: PGS sweeps alternate their direction over the touched links (oracle: v2p_oracle_experiment(4)),
+                            // the walk goes back and forth and never returns from the last link to the first: 8 % fewer instructions, +3.5 % at
+                            // 8192 envs, +6 % at 32768 - and 1.5 x the distance to the converged solution after 4 sweeps (the link a sweep ends on is
+                            // solved twice in a row): the gain is paid with solver accuracy, so it is NOT the model.  Parity of
+                            // the switched build with the switched oracle was green on all 110 GPU tests (profiles/r04f_*).
 #endif
 #ifndef V2P_LL_DPP_DOWN
 #define V2P_LL_DPP_DOWN 0
@@ -1534,8 +1535,8 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                 auto rowbias = [&](float v) -> float { return TGS ? (v >= 0.f ? v * tgs_irem : fmaxf(tgs_pen * v, -P.max_depen)) : v; };
                 if constexpr (WALK) {
                 // ---- the sweep as ONE WALK over the tree.  Solving the touched links one by one in ascending order visits them in depth-first
-                // order (cyclically, iteration after iteration, when every sweep ascends: TGS; back and forth when the sweeps alternate their
-                // direction: PGS, see ALT below); between two of them only the links on the tree path cur -> LCA -> next need anything:
+                // order, cyclically, iteration after iteration (back and forth with the experimental ALT switch below); between two of them only
+                // the links on the tree path cur -> LCA -> next need anything:
                 //   up    cur .. LCA: every link hands what its subtree has collected since it last did so (un_new, uf_new) to its parent,
                 //         and the LCA answers what arrives with its own Lambda (Lambda_cc is the response of the whole system at c);
                 //   down  LCA .. next: velocity change of a link = its parent's, carried over the joint, + the joint's answer to everything
@@ -1556,8 +1557,8 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                 // LIMITS: the walk also stops at the joints that carry limit rows (their block comes right before the contact block of the link)
                 const unsigned v0 = LIMITS ? m0 | lm0 : m0, v1 = LIMITS ? m1 | lm1 : m1;
                 V3 jt_new{0.f, 0.f, 0.f};  // LIMITS: limit impulse of this joint not yet handed up (its reaction, -jt, goes to the parent)
-                // ALT (PGS): odd sweeps visit the stops in DESCENDING order - minfo_rev = the move into a stop from the stop AFTER it (same fields;
-                // the highest stop has none: a backward sweep starts on it, where the forward sweep ended)
+                // ALT (experiment, off by default: V2P_LL_ALT_SWEEP): odd PGS sweeps visit the stops in DESCENDING order - minfo_rev = the move into a
+                // stop from the stop AFTER it (same fields; the highest stop has none: a backward sweep starts on it, where the forward sweep ended)
                 constexpr bool ALT = V2P_LL_ALT_SWEEP != 0 && !TGS;
                 int minfo = 0, minfo_rev = 0;
                 {
@@ -1731,8 +1732,10 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                     return ((unsigned)bm != 0u ? 1 : 0) | ((unsigned)(bm >> 32) != 0u ? 2 : 0);
                 };
                 // an env whose whole sweep changed nothing has reached the fixed point of its rows: it takes no part in the remaining sweeps,
-                // whatever the env it shares the wave with still does (its later sweeps would change nothing - exactly so in the oracle; here
-                // a sweep in the other direction reaches the same links over other moves, i.e. with other rounding)
+                // whatever the env it shares the wave with still does.  (Its later sweeps change nothing: exactly so with ascending sweeps,
+                // where the same moves re-derive the same velocities - the block updates they would take are saved; with the ALT experiment a
+                // sweep in the other direction reaches the same links over other moves, i.e. with other rounding, and an env that kept
+                // iterating for its wave partner's sake would depend on it.)
                 int done = 0;
                 for (int it = 0; it < P.n_iter; ++it) {
                     unsigned t0 = (done & 1) ? 0u : v0, t1 = (done & 2) ? 0u : v1;
