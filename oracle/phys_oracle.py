@@ -315,6 +315,20 @@ class BatchOracle:
         saved = st.copy()
         rng = np.random.default_rng(seed)
         keys = ("root", "dpos", "dvel", "rb", "cf", "df")
+        # (the trials run through the -O3 build of the same source: an estimate of a gain needs no bit-exact arithmetic, and the parity
+        # tests spend most of their time here.  Switches set through v2p_oracle_experiment live in the -O2 library only.)
+        lib0 = self.lib
+        try:
+            self.lib = lib_fast()
+        except Exception:
+            pass
+        try:
+            return self._sensitivity(st, saved, rng, keys, pd_target, ext_force, ext_torque, nsub, hold, forced_ids, trials, eps_pos, eps_vel)
+        finally:
+            self.lib = lib0
+            st[:] = saved
+
+    def _sensitivity(self, st, saved, rng, keys, pd_target, ext_force, ext_torque, nsub, hold, forced_ids, trials, eps_pos, eps_vel):
         base = self.step(pd_target, ext_force, ext_torque, nsub, hold, forced_ids)
         sens = {k: np.zeros_like(base[k]) for k in keys}
         for _ in range(trials):
