@@ -45,9 +45,11 @@ struct DeviceGuard {
 // The link-per-lane physics kernel is built TWICE from the same source (build.py): the default object (168 VGPRs, three waves per SIMD,
 // contact records and phase-dead values parked in LDS) and `physics_ll_regs.o` (-Dv2p=v2p_regs -DV2P_LL_WPS=2 -DV2P_LL_PARK2=0
 // -DV2P_LL_PARK3=0: 256 VGPRs, two waves per SIMD, everything in registers).  Where a launch is as long as its heaviest env pair - up to
-// ~5000 envs on one GPU - the register build is 5 - 7 % faster (no LDS round trips in the heaviest wave's chain), where the wave slots
-// are full the LDS build is 15 % faster (profiles/r04_env_count_sweep.txt).  The second object lives in its own namespace;
-// what it calls from this file is forwarded here.
+// ~5000 envs on one GPU - the register build is 7 - 12 % faster (no LDS round trips in the heaviest wave's chain; compiled for ILP), where
+// the wave slots are full the LDS build is 15 % faster (profiles/r04e_dual_build.txt).  The second object lives in its own
+// namespace; what it calls from this file is forwarded here.  (-Dv2p=v2p_regs renames the namespace in every header that object
+// includes as well: the types it sees inside `v2p_env` are `v2p_regs::` twins of this file's - same source, same layout, and only the
+// pointer crosses the boundary.)
 namespace v2p_regs {
 void set_error(const char* fmt, ...) {
     char buf[512];
