@@ -435,11 +435,8 @@ def main():
 
     n = args.num_envs
     G = max(1, args.groups)
-    if G > 1 and args.kernel_build is None:
-        # the engine picks the build of its physics kernel by a batch's env count (register build <= 5120 envs: the launch of a lone small batch
-        # is as long as its heaviest wave); G batches that SHARE the GPU are bound by instruction issue together: the three-wave build
-        # (8192 envs as 2 x 4096: 20.9 M against 19.4 M with the engine's per-batch choice, profiles/r04e_dual_build.txt)
-        args.kernel_build = 1
+    # (the engine picks the build of its physics kernel by the envs RESIDENT on the device - G batches that share the GPU are judged
+    # together: 8192 envs as 2 x 4096 run the three-wave build, 20.9 M against 19.4 M with a per-batch choice, profiles/r04e_dual_build.txt)
     if n % G:
         raise SystemExit("--num-envs %d is not a multiple of --groups %d" % (n, G))
     if stub:
@@ -556,7 +553,13 @@ def main():
     world_seen = 1 if dist is None else dist.get_world_size()
 
     if rank == 0:
-        value = world * n * args.steps / elapsed
+        req_value = world * n * args.steps / elapsed
+        # the headline is the ROLLOUT AVERAGE: the requested region when it is whole epochs, else the whole-epoch block timed right after it
+        # (barrier + synchronize on both sides, MAX over ranks, like the requested region, which stays in the line as `requested_region`)
+        value, ms_per_step = (whole["value"], whole["ms_per_step"]) if whole else (req_value, 1e3 * elapsed / args.steps)
+        if whole:
+            sys.stderr.write("bench.py: --steps %d is not a whole number of %d-step epochs (positions 0..%d of an epoch are the light ones: %.2f M env-steps/s); "
+                             "value = the %d-epoch block timed after it (%.2f M)\n" % (args.steps, HORIZON, args.steps - 1, req_value / 1e6, WHOLE_EPOCHS, value / 1e6))
         nresets = (args.steps + HORIZON - 1) // HORIZON
         valu, traffic = profiles_view()
         # the fractions describe the rollout average: from the whole-epoch block when the requested region is not whole epochs
@@ -594,7 +597,10 @@ def main():
                 rccl = "unknown"
         out = {
             "metric": "env-steps/sec at num_envs=8192, SMPL humanoid imitation", "value": value, "unit": "env-steps/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "value_region": "the %d timed steps (whole epochs)" % args.steps if not whole else
+                            "whole_epoch block: %d steps = %d whole epochs timed right after the %d requested steps, same barriers (a region that is not whole epochs "
+                            "times the light start of an epoch: requested_region)" % (whole["steps"], WHOLE_EPOCHS, args.steps),
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "amass_im num_envs=%d per GPU, %s, imitation reward, per-epoch reset+context every %d steps, 64 synthetic clips, action noise %.3g%s"
                                    % (n, "PD control only (no contact solve)" if args.no_contact else "full contact %s (4 substeps x 4 iterations)" % args.solver.upper(), HORIZON,
@@ -615,6 +621,7 @@ def main():
         }
         if whole:
             out["whole_epoch"] = whole
+            out["requested_region"] = {"steps": args.steps, "value": req_value, "ms_per_step": 1e3 * elapsed / args.steps, "epoch_positions": out["config"]["timed_epoch_positions"]}
         if not stub:
             from vid2player3d_amd import build
             out["build"] = build.build_info()

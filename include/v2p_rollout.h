@@ -34,7 +34,7 @@ extern "C" {
 #define V2P_NUM_OBS 461
 #define V2P_MOTION_STATE_DIM 331  /* root_pos3 root_rot4 dof_pos69 root_vel3 root_ang_vel3 dof_vel69 key_pos12 rb_pos72 rb_rot96 */
 #define V2P_CONTEXT_DIM 378       /* body_pos72 body_rot96 dof_pos69 body_pos_gt72 dof_pos_gt69 (humanoid_smpl_im.py:202) */
-#define V2P_ABI_VERSION 12
+#define V2P_ABI_VERSION 13
 
 typedef enum {
     V2P_OK = 0,
@@ -192,7 +192,8 @@ typedef struct {
                                  * physics launch of the link-per-lane schedule is cut into (substep, env pair) jobs that hand the
                                  * state over through memory - 4x finer load balancing of the launch; results are bit-identical to 0
                                  * (one workgroup per env pair runs all substeps).  Every solver / contact setting of the link-per-lane schedule. */
-    int32_t job_mono_permille;  /* substep_jobs: share of the env pairs (the heaviest) whose substeps stay in one workgroup; -1 = default (60) */
+    int32_t job_mono_permille;  /* substep_jobs: share of the env pairs (the heaviest) whose substeps stay in one workgroup; -1 = default (60; 250 above
+                                 * 12288 envs, with joint limits or with a ball attached) */
     int32_t pair_mix_permille;  /* pair_envs_by_load: share of the envs (the heaviest) that share their wave with one of the lightest envs
                                  * instead of with an equally heavy one (a wave costs the union of its two envs' contact structure, and the
                                  * heaviest envs are the critical path of the launch); 0 = pairs of equals only; -1 = default (150, 500 with the register build - kernel_build; 0 above 12288 envs,
@@ -225,8 +226,17 @@ typedef struct {
                                  * rounding): 1 = three waves per SIMD with the contact records parked in LDS (fastest where the launch is
                                  * bound by instruction issue: BASELINE's 8192 envs), 2 = two waves per SIMD with everything in registers
                                  * (5 - 7 % faster where a launch is as long as its heaviest env pair: small batches).  0 = the engine
-                                 * chooses by env count (2 at <= 5120 envs: measured, profiles/r04e_dual_build.txt).  v2p_env_kernel_build
-                                 * tells which one a batch runs. */
+                                 * chooses, launch by launch, by the number of envs RESIDENT on the device - the sum over the live
+                                 * batches of this process, so that rollout groups sharing a GPU are judged together (2 at <= 5120
+                                 * envs: measured, profiles/r04e_dual_build.txt).  v2p_env_kernel_build tells which one a batch runs. */
+    /* ---- ABI 13: the A/B and test switches of the substep jobs (environment variables until ABI 12).  A zero-initialised block = the
+     * engine's defaults.  The library reads NO engine option from the environment; its profiling switches (V2P_WAVE_TIMES,
+     * V2P_PHASE_TIMING, V2P_PHASE_HEAVY, V2P_ENVS_PER_BLOCK) are honoured only in a process that sets V2P_DEBUG=1. */
+    int32_t job_timeout_spins;  /* substep_jobs: polls (with back-off) a job waits for its predecessor before it recomputes the earlier
+                                 * substeps itself; 0 = default (50000, ~20 ms), < 0 = give up at once (tests of the recovery path) */
+    int32_t job_len;            /* substeps per job; 0 = the engine decides (1, or 2 for launches of >= CUs x 32 env pairs) */
+    int32_t job_lead;           /* substeps of the FIRST job of a cut pair; 0 = the engine decides, < 0 = like the other jobs */
+    int32_t job_no_interleave;  /* 1: the jobs of a pair are not interleaved with those of other pairs in dispatch order (A/B) */
 } v2p_sim_cfg;
 
 /* Caller-owned DEVICE buffers the engine reads/writes; these are the tensors the reference

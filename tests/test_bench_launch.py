@@ -51,14 +51,18 @@ def test_ppo_loop_line_with_two_ranks_and_stub_task():
 def test_short_run_is_followed_by_a_whole_epoch_block():
     """The driver's command (--steps 20 --warmup 5): every run() starts an epoch, so the timed region is reset + positions 0..19 - the
     line must say so, and carry a separately timed block of whole epochs from which the roofline figures are taken."""
-    d, _ = _run(["--stub-task", "--steps", "20", "--warmup", "5", "--num-envs", "64"])
+    d, err = _run(["--stub-task", "--steps", "20", "--warmup", "5", "--num-envs", "64"])
     assert d["n_gpus"] == 1 and d["config"]["world_size_seen"] == 1 and d["steps"] == 20 and d["warmup"] == 5
     assert d["config"]["timed_epoch_positions"] == "0..19" and d["config"]["resets_in_timed_region"] == 1
     assert d["config"]["timed_steps_cover_whole_epochs"] is False
     w = d["whole_epoch"]
     assert w["steps"] == 320 and w["epochs"] == 10 and w["kernel_launches_timed"] == 320
     assert d["roofline"]["kernel_ms"] == w["kernel_ms"] and d["roofline"]["requested_region"]["kernel_launches_timed"] == 20
-    assert abs(d["ms_per_step"] * 20 * 1e-3 - 20 * 64 / d["value"]) < 1e-6  # value = the requested steps
+    # the headline is the rollout average (the whole-epoch block); the requested 20 steps - the light start of an epoch - stay beside it
+    assert d["value"] == w["value"] and d["ms_per_step"] == w["ms_per_step"] and "whole_epoch block" in d["value_region"]
+    r = d["requested_region"]
+    assert r["steps"] == 20 and r["epoch_positions"] == "0..19" and abs(r["ms_per_step"] * 20 * 1e-3 - 20 * 64 / r["value"]) < 1e-6
+    assert "not a whole number" in err
 
 
 def test_whole_epoch_runs_need_no_extra_block():

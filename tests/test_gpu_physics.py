@@ -227,11 +227,26 @@ def test_both_builds_of_the_kernel_match_oracle(mlib, build):
         make_task(8, mlib, kernel_build=3)
 
 
-def test_engine_picks_the_build_by_env_count(mlib):
-    small, large = make_task(64, mlib), make_task(8192, mlib)
-    assert small.kernel_build().startswith("registers") and large.kernel_build().startswith("lds-parked")
+def test_engine_picks_the_build_by_envs_resident_on_the_device(mlib):
+    """kernel_build = 0: by the envs of ALL live batches of the process on the device (rollout groups share the GPU's wave slots), launch
+    by launch - a small batch runs the register build while it is alone and the three-wave build while a large one lives beside it."""
+    small = make_task(64, mlib)
+    assert small.kernel_build().startswith("registers")
+    large = make_task(8192, mlib)
+    assert large.kernel_build().startswith("lds-parked") and small.kernel_build().startswith("lds-parked")
+    halves = [make_task(4096, mlib) for _ in range(2)]  # 2 x 4096 = what bench.py --groups 2 and PPOAgent's rollout groups create
+    assert all(h.kernel_build().startswith("lds-parked") for h in halves)
+    for t in halves + [large]:
+        t.close()
+    assert small.kernel_build().startswith("registers")
+    fixed = make_task(64, mlib, kernel_build=1)
+    assert fixed.kernel_build().startswith("lds-parked") and small.kernel_build().startswith("registers")
+    a = torch.cat([small._target_dof_pos.clone(), torch.zeros((64, 6), device=DEV)], dim=1).contiguous()
+    small.reset_with_times(None, torch.full((64,), 0.3, device=DEV))
+    small.step(a)
+    small.check()
     small.close()
-    large.close()
+    fixed.close()
 
 
 PHYSX_AMASS_IM = {"num_threads": 4, "solver_type": 1, "num_position_iterations": 4, "num_velocity_iterations": 0, "contact_offset": 0.02, "rest_offset": 0.0,
@@ -541,7 +556,7 @@ def test_substep_jobs_are_invisible_in_every_instantiation(mlib, what, env, buil
             assert np.array_equal(x, y), "%s step %d, tensor %d: %d of %d values differ" % (what, k, j, int((x != y).sum()), x.size)
 
 
-def test_a_job_that_gives_up_waiting_recomputes_and_changes_nothing(mlib, monkeypatch):
+def test_a_job_that_gives_up_waiting_recomputes_and_changes_nothing(mlib):
     """Forward progress of the substep jobs must not rest on the dispatch order.  With the time-out set to zero polls every job whose
     predecessor has not finished at its first look gives up at once and recomputes the pair's earlier substeps itself, while the
     predecessor still runs (and later rewrites the same values): results stay bit-identical to whole control steps per workgroup, with
@@ -550,10 +565,8 @@ def test_a_job_that_gives_up_waiting_recomputes_and_changes_nothing(mlib, monkey
 
     n = 4096
     outs = []
-    for jobs, spins in ((False, None), (True, "0")):
-        if spins is not None:
-            monkeypatch.setenv("V2P_JOB_TIMEOUT_SPINS", spins)
-        task = make_task(n, mlib, substep_jobs=2 * int(jobs))
+    for jobs, spins in ((False, 0), (True, -1)):  # v2p_sim_cfg.job_timeout_spins < 0: give up at the first look
+        task = make_task(n, mlib, substep_jobs=2 * int(jobs), job_timeout_spins=spins)
         g = torch.Generator(device=DEV)
         g.manual_seed(29)
         task.reset_with_times(None, torch.rand(n, device=DEV, generator=g) * 0.8)
@@ -577,8 +590,8 @@ def test_a_job_that_gives_up_waiting_recomputes_and_changes_nothing(mlib, monkey
             assert np.array_equal(x, y), "step %d, tensor %d: %d of %d values differ (max %.3e)" % (k, j, int((x != y).sum()), x.size, float(np.abs(x.astype(np.float64) - y).max()))
 
 
-@pytest.mark.parametrize("job_len", [None, "2", "5"])
-def test_substep_jobs_with_twelve_substeps_per_control_step(mlib, job_len, monkeypatch):
+@pytest.mark.parametrize("job_len", [None, 2, 5])
+def test_substep_jobs_with_twelve_substeps_per_control_step(mlib, job_len):
     """sim.substeps 6 x controlFrequencyInv 2 = 12 substeps per control step (vid2player's controller configs,
     vid2player/cfg/*.yaml `substeps: 6`): the progress word of a pair counts launch x (nsub + 1) + substep, so the hand-overs of one
     launch can never satisfy the waits of the next (with the stride fixed at 8 they did from nsub = 9 on).  Jobs on == jobs off, bit
@@ -587,9 +600,7 @@ def test_substep_jobs_with_twelve_substeps_per_control_step(mlib, job_len, monke
     n = 4096
     outs = []
     for jobs in (False, True):
-        if jobs and job_len is not None:
-            monkeypatch.setenv("V2P_JOB_LEN", job_len)
-        task = make_task(n, mlib, sim_overrides={"substeps": 6}, substep_jobs=2 * int(jobs))
+        task = make_task(n, mlib, sim_overrides={"substeps": 6}, substep_jobs=2 * int(jobs), job_len=(job_len or 0) if jobs else 0)
         assert task.sim_params.substeps * task.control_freq_inv == 12
         g = torch.Generator(device=DEV)
         g.manual_seed(23)

@@ -282,7 +282,7 @@ def test_bounce_and_hit_flags(mlib):
 
 
 @pytest.mark.parametrize("n,timeout_spins", [(3, None), (2048, None), (2048, "0")])
-def test_substep_jobs_are_invisible_with_ball(mlib, n, timeout_spins, monkeypatch):
+def test_substep_jobs_are_invisible_with_ball(mlib, n, timeout_spins):
     """Racket + ball + joint limits through substep jobs (the ball's state and its aerodynamic force are handed over with the
     humanoid's; the flags are kept through system-scope accesses): bit-identical to one workgroup per env pair, step after step.
     timeout_spins "0": every job whose predecessor is not done at its first look recomputes the earlier substeps itself (the recovery
@@ -291,9 +291,7 @@ def test_substep_jobs_are_invisible_with_ball(mlib, n, timeout_spins, monkeypatc
 
     outs = []
     for jobs in (False, True):
-        if jobs and timeout_spins is not None:
-            monkeypatch.setenv("V2P_JOB_TIMEOUT_SPINS", timeout_spins)
-        task = make_rb_task(n, mlib, substep_jobs=2 * int(jobs), debug_contacts=0)
+        task = make_rb_task(n, mlib, substep_jobs=2 * int(jobs), debug_contacts=0, job_timeout_spins=-1 if (jobs and timeout_spins is not None) else 0)
         g = torch.Generator(device=DEV)
         g.manual_seed(23)
         task.reset_with_times(None, torch.rand(n, device=DEV, generator=g) * 0.8)
@@ -362,3 +360,21 @@ def test_aero_force_and_bounce_flags_match_reference_vectors(mlib):
     bp = N(task._bounce_pos)
     assert np.array_equal(bp[now1], st[now1, 0:3]) and np.array_equal(bp[now2], ps[now2, 0, 0:3]) and np.all(bp[~(now1 | now2)] == 0)
     task.close()
+
+
+def test_racket_ball_task_builds_from_the_references_physx_block(mlib, capsys):
+    """vid2player's tennis yamls state `solver_type: 1` (TGS); joint limits and the ball are PGS-only in the engine.  The task built from
+    that block runs PGS and says so (it used to fail in v2p_env_create: "joint_limits needs ... the PGS solver"), and steps."""
+    physx = {"num_threads": 4, "solver_type": 1, "num_position_iterations": 4, "num_velocity_iterations": 0, "contact_offset": 0.02, "rest_offset": 0.0,
+             "bounce_threshold_velocity": 0.2, "max_depenetration_velocity": 10.0, "default_buffer_size_multiplier": 10.0}
+    task = make_rb_task(8, mlib, sim_overrides={"physx": physx}, debug_contacts=0)
+    assert task.contact_solver == "pgs"
+    assert "running PGS" in capsys.readouterr().out
+    task.reset_with_times(None, torch.full((8,), 0.3, device=DEV))
+    a = torch.cat([task._target_dof_pos.clone(), torch.zeros((8, 6), device=DEV)], dim=1).contiguous()
+    task.step(a)
+    task.check()
+    assert torch.isfinite(task.obs_buf).all()
+    task.close()
+    with pytest.raises(RuntimeError, match="PGS"):  # an explicit engine-side choice of TGS is refused, not overridden
+        make_rb_task(8, mlib, contact_solver="tgs", debug_contacts=0)

@@ -83,3 +83,23 @@ def test_velocity_iterations_are_refused_by_the_library_not_dropped():
     c = _lib.SimCfg()
     fill_physx(c, SimParams.from_cfg(sim), env={})
     assert c.num_velocity_iterations == 1 and abs(c.rest_offset - 0.005) < 1e-9
+
+
+def test_racket_ball_task_falls_back_to_pgs_when_the_file_says_tgs():
+    """vid2player's tennis configs state solver_type: 1; the racket-arm limit rows and the ball exist in the PGS solver only: the task
+    runs PGS and says so (it used to fail in v2p_env_create) - unless the caller names a solver by the engine's own key."""
+    from vid2player3d_amd.tasks.humanoid_racket_ball import racket_ball_solver_override
+
+    sp = SimParams.from_cfg(yaml.safe_load(AMASS_IM_SIM)["sim"])
+    env, said = {}, []
+    assert racket_ball_solver_override(env, sp, log=said.append) and env["contact_solver"] == "pgs"
+    assert len(said) == 1 and "TGS" in said[0] and "PGS" in said[0]
+    env = {"contact_solver": "tgs"}  # an explicit engine-side choice is left alone (and refused by the engine with its own message)
+    assert not racket_ball_solver_override(env, sp) and env["contact_solver"] == "tgs"
+    assert not racket_ball_solver_override({}, SimParams.from_cfg(default_cfg(4)["sim"]))  # no solver named: PGS anyway, nothing to say
+
+
+def test_zero_initialised_cfg_keeps_the_job_defaults():
+    """ABI 13: the substep-job switches are cfg fields (no environment variables); zero = the engine's defaults."""
+    c = _lib.SimCfg()
+    assert (c.job_timeout_spins, c.job_len, c.job_lead, c.job_no_interleave, c.kernel_build) == (0, 0, 0, 0, 0)

@@ -31,10 +31,10 @@ bash $R/tools/pmc_probe.sh > $O/pmc.log 2>&1
 bash $R/tools/hbm_calib.sh > $O/hbm_calib.log 2>&1
 timeout 900 python tools/parity_sweep.py 2048 > $O/parity_sweep.log 2>&1
 bash $R/tools/valu_probe.sh > $O/valu.log 2>&1
-V2P_WAVE_TIMES=$O/wave_times.bin timeout 300 python bench.py --steps 29 --warmup 0 --no-cpu-baseline --substep-jobs 0 > $O/wt.log 2>&1
+V2P_DEBUG=1 V2P_WAVE_TIMES=$O/wave_times.bin timeout 300 python bench.py --steps 29 --warmup 0 --no-cpu-baseline --substep-jobs 0 > $O/wt.log 2>&1
 python tools/wave_times.py $O/wave_times.bin > $O/wave_times.txt 2>&1; rm -f $O/wave_times.bin
-V2P_PHASE_TIMING=1 timeout 300 python bench.py --steps 64 --warmup 0 --no-cpu-baseline 2>&1 | grep phase > $O/phase.log
-V2P_PHASE_HEAVY=1 V2P_PHASE_TIMING=1 timeout 300 python bench.py --steps 64 --warmup 0 --no-cpu-baseline 2>&1 | grep phase > $O/phase_heavy.log
+V2P_DEBUG=1 V2P_PHASE_TIMING=1 timeout 300 python bench.py --steps 64 --warmup 0 --no-cpu-baseline 2>&1 | grep phase > $O/phase.log
+V2P_PHASE_HEAVY=1 V2P_DEBUG=1 V2P_PHASE_TIMING=1 timeout 300 python bench.py --steps 64 --warmup 0 --no-cpu-baseline 2>&1 | grep phase > $O/phase_heavy.log
 [ -f variants/libv2p_nowalk.so ] && bash tools/walk_ab.sh > $O/walk_ab.log 2>&1
 python tools/epoch_profile.py --epochs 4 > $O/epoch_profile.txt 2>&1
 timeout 600 python tools/limit_cost.py > $O/limit_cost.txt 2>&1

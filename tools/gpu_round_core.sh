@@ -30,7 +30,7 @@ rm -rf $O/prof
 bash $R/tools/pmc_probe.sh > $O/pmc.log 2>&1
 bash $R/tools/valu_probe.sh > $O/valu.log 2>&1
 python tools/epoch_profile.py --epochs 4 > $O/epoch_profile.txt 2>&1
-V2P_PHASE_TIMING=1 timeout 300 python bench.py --steps 64 --warmup 0 --no-cpu-baseline 2>&1 | grep phase > $O/phase.log
+V2P_DEBUG=1 V2P_PHASE_TIMING=1 timeout 300 python bench.py --steps 64 --warmup 0 --no-cpu-baseline 2>&1 | grep phase > $O/phase.log
 timeout 900 python tools/parity_sweep.py 2048 > $O/parity_sweep.log 2>&1
 timeout 600 python tools/soak.py 4000 2>&1 | tail -3 > $O/soak.log
 timeout 600 python tools/soak.py 4000 racket 2>&1 | tail -3 > $O/soak_racket_ball.log

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Timeline of the (substep, env pair) jobs of one launch of the production physics kernel, from a V2P_LL_TIMELINE build run with
-V2P_WAVE_TIMES=<file> (tools/mkvariant.sh timeline with V2P_FLAGS_PHYSICS_LL="-O3 -DV2P_LL_TIMELINE")."""
+V2P_DEBUG=1 V2P_WAVE_TIMES=<file> (tools/mkvariant.sh timeline with V2P_FLAGS_PHYSICS_LL="-O3 -DV2P_LL_TIMELINE")."""
 import sys
 
 import numpy as np

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Analyse the per-wave wall-clock stamps written by V2P_WAVE_TIMES=<file> (physics_ll_kernel, last launch of the run)."""
+"""Analyse the per-wave wall-clock stamps written by V2P_DEBUG=1 V2P_WAVE_TIMES=<file> (physics_ll_kernel, last launch of the run)."""
 import sys
 
 import numpy as np

@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <new>
 #include <vector>
 
@@ -64,6 +65,21 @@ int launch_env_physics_ll(v2p_env* e, hipStream_t s, float* actions, int* fused_
 }  // namespace v2p_regs
 
 using namespace v2p;
+
+// Profiling switches (V2P_WAVE_TIMES, V2P_PHASE_TIMING, V2P_PHASE_HEAVY, V2P_ENVS_PER_BLOCK) are read from the environment ONLY in a
+// process that sets V2P_DEBUG=1 (tools/*.sh do); every engine option is a field of v2p_sim_cfg.
+namespace v2p {
+const char* debug_env(const char* name) {
+    const char* d = getenv("V2P_DEBUG");
+    return (d && d[0] == '1' && d[1] == 0) ? getenv(name) : nullptr;
+}
+}  // namespace v2p
+namespace v2p_regs { const char* debug_env(const char* name) { return v2p::debug_env(name); } }
+
+// envs resident per device (live v2p_env batches of this process): what kernel_build = 0 decides by, launch by launch
+static std::atomic<int64_t> g_resident_envs[64];
+static int64_t resident_envs(int device) { return (device >= 0 && device < 64) ? g_resident_envs[device].load(std::memory_order_relaxed) : 0; }
+static constexpr int64_t REGS_BUILD_MAX_ENVS = 5120;  // measured crossover of the two builds (profiles/r04e_dual_build.txt)
 
 namespace v2p {
 // out[N][525] + ws: only the env-per-lane cross-check schedule stages through global memory
@@ -352,8 +368,8 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
         delete e;
         return V2P_ERR_UNSUPPORTED;
     }
-    if (!(c->bounce_threshold_velocity >= 0.f) || !(c->rest_offset < c->contact_offset)) {
-        set_error("v2p_env_create: bounce_threshold_velocity must be >= 0 and rest_offset below contact_offset");
+    if (!(c->bounce_threshold_velocity >= 0.f) || (c->enable_contact && !(c->rest_offset < c->contact_offset))) {
+        set_error("v2p_env_create: bounce_threshold_velocity must be >= 0 and (with contacts on) rest_offset below contact_offset");
         delete e;
         return V2P_ERR_INVALID;
     }
@@ -430,10 +446,11 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
     // (mixing trades total work for a shorter critical path: it pays while the launch is as long as its heaviest pair, i.e. up to
     // ~4 env pairs per wave slot; beyond that the launch is throughput bound and pairs of equals are cheaper)
     // (the kernels with joint-limit rows or a ball run 2 waves per SIMD: there pairs of equals measured best, profiles/r02g_racket_ball_sweep.txt)
-    {   // which build of the link-per-lane kernel this batch runs (see the head of this file): by env count, V2P_LL_BUILD=regs|lds overrides (A/B)
-        const char* lb = getenv("V2P_LL_BUILD");
-        e->ll_regs_build = lb ? (strcmp(lb, "regs") == 0) : c->kernel_build ? (c->kernel_build == 2) : (n <= 5120);
-    }
+    // which build of the link-per-lane kernel this batch runs (see the head of this file): v2p_sim_cfg.kernel_build, 0 = by the number of
+    // envs RESIDENT on the device - the batches of a process that share a GPU (rollout groups) are bound by instruction issue together,
+    // whatever the size of each - re-evaluated launch by launch (choose_build); the value here is the one a lone batch would get
+    e->kernel_build = c->kernel_build;
+    e->ll_regs_build = c->kernel_build ? (c->kernel_build == 2) : (resident_envs(device) + n <= REGS_BUILD_MAX_ENVS);
     e->pair_mix_default = c->pair_mix_permille < 0 ? 1 : 0;
     // defaults: measured best.  Round 2 (profiles/r02_job_mono_sweep.txt): 250 / 250; re-swept on the round-4 kernel (profiles/r04_mono_mix_sweep.txt:
     // 5 x 4 grid at 8192 envs, then across TGS / djokovic / per-clip shapes / 4096 and 12288 envs): 60 / 150 is +1 .. 2 % everywhere - with the
@@ -451,14 +468,14 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
         if (rc == V2P_OK) rc = check_hip(hipMemset(e->job_progress, 0, sizeof(int32_t) * words), "hipMemset(job_progress)");
         // the state as the jobs hand it over: 50 16-byte chunks per env (see physics_ll.hip)
         if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->job_hand, sizeof(float) * HAND_FLOATS * N * (size_t)(p.nsub > 1 ? p.nsub - 1 : 1)), "hipMalloc(job_hand)");
-        // ~20 ms: far beyond the longest chain of substeps of a launch.  (V2P_JOB_TIMEOUT_SPINS: tests force the recovery path with 0)
-        e->job_timeout_spins = getenv("V2P_JOB_TIMEOUT_SPINS") ? atol(getenv("V2P_JOB_TIMEOUT_SPINS")) : 50000l;
+        // ~20 ms: far beyond the longest chain of substeps of a launch.  (job_timeout_spins < 0: tests force the recovery path)
+        e->job_timeout_spins = c->job_timeout_spins == 0 ? 50000l : (c->job_timeout_spins < 0 ? 0l : (long)c->job_timeout_spins);
         // substeps per job: 1 while the launch is short of jobs, 2 once there are plenty (>= CUs x 32 env pairs: measured crossover at
-        // 16384 envs - a job's prologue / hand-over is ~8 % of a one-substep job); V2P_JOB_LEN: A/B switch
-        e->job_len = getenv("V2P_JOB_LEN") ? atoi(getenv("V2P_JOB_LEN")) : 0;
-        e->job_lead = getenv("V2P_JOB_LEAD") ? atoi(getenv("V2P_JOB_LEAD")) : -1;  // -1: the engine decides (see launch_env_physics_ll)
+        // 16384 envs - a job's prologue / hand-over is ~8 % of a one-substep job); v2p_sim_cfg.job_len: A/B switch
+        e->job_len = c->job_len > 0 ? c->job_len : 0;
+        e->job_lead = c->job_lead == 0 ? -1 : (c->job_lead < 0 ? 0 : c->job_lead);  // -1: the engine decides (see launch_env_physics_ll)
     }
-    e->job_interleave = getenv("V2P_JOB_INTERLEAVE") ? atoi(getenv("V2P_JOB_INTERLEAVE")) : 1;  // (A/B switch)
+    e->job_interleave = c->job_no_interleave ? 0 : 1;  // (A/B switch)
     if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->pair_key, sizeof(int32_t) * N), "hipMalloc(pair_key)");
     if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->pair_pos, sizeof(int32_t) * N), "hipMalloc(pair_pos)");
     if (rc == V2P_OK) rc = check_hip(hipMalloc((void**)&e->perm, sizeof(int32_t) * N), "hipMalloc(perm)");
@@ -480,16 +497,17 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
         if (rc == V2P_OK) rc = check_hip(hipMemcpy(e->pair_pos, iota.data(), sizeof(int32_t) * N, hipMemcpyHostToDevice), "hipMemcpy(pair_pos)");
     }
     if (rc == V2P_OK) rc = check_hip(hipDeviceSynchronize(), "hipDeviceSynchronize(env_create)");
-    if (rc == V2P_OK && getenv("V2P_WAVE_TIMES")) {
+    if (rc == V2P_OK && debug_env("V2P_WAVE_TIMES")) {
         // (one record per wave; per JOB in a V2P_LL_TIMELINE build: up to nsub per wave)
         rc = check_hip(hipMalloc((void**)&e->wave_times, sizeof(long long) * 4 * (N / 2 + 1) * (size_t)p.nsub), "hipMalloc(wave_times)");
         if (rc == V2P_OK) rc = check_hip(hipMemset(e->wave_times, 0, sizeof(long long) * 4 * (N / 2 + 1) * (size_t)p.nsub), "hipMemset(wave_times)");
     }
-    if (rc == V2P_OK && getenv("V2P_PHASE_TIMING")) {
+    if (rc == V2P_OK && debug_env("V2P_PHASE_TIMING")) {
         rc = check_hip(hipMalloc((void**)&e->prof, sizeof(long long) * 24), "hipMalloc(prof)");
         if (rc == V2P_OK) rc = check_hip(hipMemset(e->prof, 0, sizeof(long long) * 24), "hipMemset(prof)");
     }
     if (rc != V2P_OK) { v2p_env_destroy(e); return rc; }
+    if (device >= 0 && device < 64) { g_resident_envs[device] += n; e->counted_resident = 1; }
     *out = e;
     return V2P_OK;
 }
@@ -506,6 +524,7 @@ int v2p_env_create_shapes(const v2p_model* const* shapes, int32_t num_shapes, co
 
 void v2p_env_destroy(v2p_env* e) {
     if (!e) return;
+    if (e->counted_resident) g_resident_envs[e->device] -= e->n;
     DeviceGuard g(e->device);
     if (e->state) (void)hipFree(e->state);
     if (e->ctrl) (void)hipFree(e->ctrl);
@@ -531,7 +550,7 @@ void v2p_env_destroy(v2p_env* e) {
     if (e->wave_times) {
         const size_t nw = ((size_t)e->n / 2 + 1) * (size_t)e->p.nsub;  // (records that were never written stay zero and are skipped)
         std::vector<long long> h(nw * 4);
-        FILE* f = fopen(getenv("V2P_WAVE_TIMES") ? getenv("V2P_WAVE_TIMES") : "wave_times.bin", "wb");
+        FILE* f = fopen(debug_env("V2P_WAVE_TIMES") ? debug_env("V2P_WAVE_TIMES") : "wave_times.bin", "wb");
         if (f && hipMemcpy(h.data(), e->wave_times, sizeof(long long) * h.size(), hipMemcpyDeviceToHost) == hipSuccess) fwrite(h.data(), sizeof(long long), h.size(), f);
         if (f) fclose(f);
         (void)hipFree(e->wave_times);
@@ -569,6 +588,16 @@ int v2p_env_pre_physics(v2p_env* e, float* actions, void* stream) {
     return launch_env_pre(e, actions, (hipStream_t)stream);
 }
 
+// kernel_build = 0: the build follows the envs resident on the device NOW (a second rollout group created after this batch moves both
+// to the three-wave build); the heavy x light pairing share follows the build where it was left to the engine
+static void choose_build(v2p_env* e) {
+    if (e->kernel_build != 0) return;
+    const int regs = resident_envs(e->device) <= REGS_BUILD_MAX_ENVS ? 1 : 0;
+    if (regs == e->ll_regs_build) return;
+    e->ll_regs_build = regs;
+    if (e->pair_mix_default && !e->ball) e->pair_mix_permille = (e->n <= 12288 && !e->p.joint_limits) ? (regs ? 500 : 150) : 0;
+}
+
 // the physics launch of either schedule, bracketed by events while a measurement is open
 static int physics_launch(v2p_env* e, hipStream_t s, float* actions, int* fused_post = nullptr) {
     // (sampled: launch L of the measurement is bracketed when L % stride == (L / period) % stride - every position of a period-long
@@ -578,6 +607,7 @@ static int physics_launch(v2p_env* e, hipStream_t s, float* actions, int* fused_
         const int64_t L = e->prof_seen++;
         if (e->prof_stride > 1) rec = rec && (L % e->prof_stride) == (L / e->prof_period) % e->prof_stride;
     }
+    choose_build(e);
     if (rec) (void)hipEventRecord(e->prof_ev[2 * e->prof_n], s);
     int rc = e->schedule != 0 ? launch_env_physics(e, s)
                               : (e->ll_regs_build ? v2p_regs::launch_env_physics_ll(e, s, actions, fused_post) : launch_env_physics_ll(e, s, actions, fused_post));
@@ -781,7 +811,11 @@ int v2p_env_set_schedule(v2p_env* e, int schedule) {
 }
 
 int v2p_env_target_index(const v2p_env* e) { return e ? e->cur_target : V2P_ERR_INVALID; }
-int v2p_env_kernel_build(const v2p_env* e) { return e ? (e->ll_regs_build ? 2 : 1) : V2P_ERR_INVALID; }
+int v2p_env_kernel_build(const v2p_env* e) {  // (the build the NEXT launch of the batch runs)
+    if (!e) return V2P_ERR_INVALID;
+    choose_build(const_cast<v2p_env*>(e));
+    return e->ll_regs_build ? 2 : 1;
+}
 
 int v2p_env_debug_contacts(v2p_env* e, int32_t* out, void* stream) {
     if (!e || !out) { set_error("v2p_env_debug_contacts: bad argument"); return V2P_ERR_INVALID; }

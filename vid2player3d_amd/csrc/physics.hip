@@ -791,7 +791,7 @@ int launch_env_physics(v2p_env* env, hipStream_t s) {
     // environments per workgroup: 8 puts one wave on each of the 1024 SIMDs at 8192 envs (4 x 39 KB LDS per CU)
     static int envs_per_block = 0;
     if (!envs_per_block) {
-        const char* s_env = getenv("V2P_ENVS_PER_BLOCK");
+        const char* s_env = debug_env("V2P_ENVS_PER_BLOCK");
         envs_per_block = s_env ? atoi(s_env) : 32;
     }
     const bool c = env->p.enable_contact != 0;

@@ -2672,7 +2672,7 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s, float* actions, int* fuse
     a.x_contact = env->buf.contact_force;
     a.x_dof_force = env->buf.dof_force;
     a.prof = env->prof;
-    a.prof_heavy = getenv("V2P_PHASE_HEAVY") ? 1 : 0;  // diagnostics: sample the 8 heaviest waves instead of every 64th
+    a.prof_heavy = debug_env("V2P_PHASE_HEAVY") ? 1 : 0;  // diagnostics: sample the 8 heaviest waves instead of every 64th
     a.wave_times = env->wave_times;
     a.n = env->n;
     a.p = env->p;

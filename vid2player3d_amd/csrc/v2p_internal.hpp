@@ -156,7 +156,9 @@ struct v2p_env {
     int job_interleave;
     int job_len;              // substeps per job; 0 = the engine decides (2 for launches of >= job_len2_blocks env pairs, else 1)
     int job_len2_blocks;
-    int ll_regs_build;        // 1: this batch runs the register build of the link-per-lane kernel (two waves per SIMD), chosen by env count
+    int ll_regs_build;        // 1: this batch runs the register build of the link-per-lane kernel (two waves per SIMD)
+    int kernel_build;         // v2p_sim_cfg.kernel_build (0: ll_regs_build follows the envs resident on the device, launch by launch)
+    int counted_resident;     // this batch is in the device's resident-env count
     int job_lead;             // substeps of the FIRST job of a cut pair (0 = like the others, -1 = the engine decides)
     int64_t job_recoveries;   // jobs that gave up waiting and recomputed, as last fetched (v2p_env_check / _check_async)
     int job_epoch;
@@ -198,6 +200,7 @@ constexpr int OUT_RB = 0, OUT_DOF_POS = NB * 13, OUT_CONTACT = OUT_DOF_POS + NDO
 #define OIDX(slot) ((int64_t)e * v2p::OUT_SLOTS + (slot))
 
 void set_error(const char* fmt, ...);
+const char* debug_env(const char* name);  // getenv in a process that sets V2P_DEBUG=1, else NULL (profiling switches only)
 int check_hip(hipError_t e, const char* what);
 
 // launchers (each in its own translation unit)

@@ -458,7 +458,12 @@ class HumanoidSMPLIM:
         c.substep_jobs = int(env.get("substep_jobs", True)) if c.schedule == 0 else 0
         c.job_mono_permille = int(env.get("job_mono_permille", -1))  # -1: the engine's defaults
         c.pair_mix_permille = int(env.get("pair_mix_permille", -1))
-        c.kernel_build = int(env.get("kernel_build", 0))  # 0: the engine chooses by env count
+        c.kernel_build = int(env.get("kernel_build", 0))  # 0: the engine chooses by the envs resident on the device
+        # A/B and test switches of the substep jobs (v2p_sim_cfg, ABI 13): 0 = the engine's defaults
+        c.job_timeout_spins = int(env.get("job_timeout_spins", 0))
+        c.job_len = int(env.get("job_len", 0))
+        c.job_lead = int(env.get("job_lead", 0))
+        c.job_no_interleave = int(env.get("job_no_interleave", 0))
         # joint ranges of the MJCF enforced as limit rows (Isaac Gym always enforces them; only the racket arm of the player MJCFs has
         # DOFs narrower than a full turn, the amass MJCF has none)
         c.joint_limits = int(env.get("joint_limits", False))
