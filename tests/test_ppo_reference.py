@@ -204,6 +204,68 @@ def test_two_ranks_equal_one_process_on_the_concatenated_batch():
     np.testing.assert_allclose(got[0][4], [float(v.running_mean), float(v.running_var), float(v.count)], rtol=1e-9)
 
 
+def _bcast_main(rank, world, port, q, ckpt):
+    import torch.distributed as dist
+    from vid2player3d_amd.ppo import PPOAgent
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    torch.manual_seed(100 + rank)
+    # DIFFERENT seeds per rank: equal replicas must come from the broadcast, not from equal seeds
+    agent = PPOAgent(stub_task(3), horizon_length=T, units=(32, 16), minibatch_envs=3, seed=5 + 11 * rank)
+    w_init = {k: v.clone().numpy() for k, v in agent.model.state_dict().items()}
+    # a checkpoint only rank 0 can read (with Adam state): restore() hands it to every rank
+    agent.restore(ckpt if rank == 0 else ckpt + ".not-on-this-rank")
+    st = agent.optimizer.state_dict()["state"]
+    q.put((rank, w_init, {k: v.clone().numpy() for k, v in agent.model.state_dict().items()}, agent.model.running_obs.mean.numpy().copy(),
+           [float(agent.value_mean_std.running_mean), float(agent.value_mean_std.count)], agent.epoch_num, agent.frame,
+           {k: {n: np.asarray(t) for n, t in v.items()} for k, v in st.items()}))
+    dist.destroy_process_group()
+
+
+def test_ranks_start_from_rank_0s_state(tmp_path):
+    """PPOAgent.__init__ and restore() broadcast rank 0's model / normalisers / optimizer state / counters (the reference:
+    hvd.setup_algo, im_agent.py:174-175): two ranks built with different seeds hold rank 0's weights, and a checkpoint that only rank 0
+    can read continues identically on both."""
+    import torch.multiprocessing as mp
+    from vid2player3d_amd.ppo import PPOAgent
+
+    src = PPOAgent(stub_task(3), horizon_length=T, units=(32, 16), minibatch_envs=3, seed=99)
+    for p_ in src.model.parameters():  # one Adam step so that the checkpoint carries exp_avg / exp_avg_sq / step
+        p_.grad = torch.full_like(p_, 0.01)
+    src.optimizer.step()
+    src.model.running_obs.mean.fill_(0.25)
+    src.value_mean_std.running_mean.fill_(1.5)
+    src.value_mean_std.count.fill_(77.0)
+    src.epoch_num, src.frame = 12, 3456
+    ckpt = src.save(str(tmp_path / "ck"))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_bcast_main, args=(r, 2, port, q, ckpt)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    r0, r1 = got
+    own1 = PPOAgent(stub_task(3), horizon_length=T, units=(32, 16), minibatch_envs=3, seed=5 + 11).model.state_dict()
+    for k in r0[1]:
+        assert np.array_equal(r0[1][k], r1[1][k]), "after __init__: " + k               # rank 1 holds rank 0's initial weights ...
+    assert any(not np.array_equal(r1[1][k], own1[k].numpy()) for k in r1[1])            # ... not the ones its own seed gives
+    want = src.model.state_dict()
+    for k in r0[2]:
+        assert np.array_equal(r0[2][k], want[k].numpy()) and np.array_equal(r1[2][k], want[k].numpy()), "after restore: " + k
+    assert np.all(r1[3] == 0.25) and r1[4] == [1.5, 77.0] and (r1[5], r1[6]) == (12, 3456)
+    assert len(r1[7]) == len(r0[7]) > 0
+    for k in r0[7]:
+        for n in ("exp_avg", "exp_avg_sq", "step"):
+            assert np.array_equal(r0[7][k][n], r1[7][k][n]), (k, n)
+        assert float(r1[7][k]["step"]) == 1.0
+
+
 # ---------------------------------------------------------------- the reference agent's configuration and checkpoint surface
 AMASS_IM_PARAMS = {  # the `params` block of embodied_pose/cfg/amass_im.yaml:55-143, as yaml.safe_load returns it
     "seed": 7, "algo": {"name": "pose_im_rnn"}, "model": {"name": "pose_im"},

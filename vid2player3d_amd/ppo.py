@@ -37,6 +37,8 @@ torch (rocBLAS): they are NOT part of the accelerated path.  rl_games itself is 
 import math
 import time
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -278,6 +280,37 @@ class PPOAgent(PolicyInference):
         self.frame = 0
         self.dataset = None
         self.noise_fn = None  # tests: noise_fn(n) -> [N, num_actions] standard-normal draws of step n
+        self.broadcast_state()  # world > 1: every rank starts from rank 0's weights, whatever its seed or RNG history
+
+    def broadcast_state(self, src=0):
+        """Rank `src`'s model, normalisers, optimizer state and counters to every rank of the group (RCCL broadcast, one flat buffer per
+        dtype).  The reference's Horovod path does this in `hvd.setup_algo` (im_agent.py:174-175: broadcast_parameters of the model's
+        state_dict + broadcast_optimizer_state): replica identity must not rest on equal seeds or on every rank reading the same file."""
+        if _world(self.group) <= 1:
+            return
+        tensors = [p.data for p in self.model.parameters()] + list(self.model.buffers()) + list(self.model.running_obs.state_dict().values())
+        v = self.value_mean_std
+        tensors += [v.running_mean, v.running_var, v.count]
+        for st in self.optimizer.state.values():  # (empty before the first step; after restore(): exp_avg, exp_avg_sq, step)
+            tensors += [t for t in st.values() if torch.is_tensor(t)]
+        counters = torch.tensor([self.epoch_num, self.frame], dtype=torch.float64, device=self.device)
+        tensors.append(counters)
+        seen, by_dtype = set(), {}
+        for t in tensors:
+            if t.data_ptr() in seen and t.numel() > 0:
+                continue
+            seen.add(t.data_ptr())
+            by_dtype.setdefault((t.dtype, str(t.device)), []).append(t)
+        for (dt, _), ts in by_dtype.items():
+            flat = torch.cat([t.reshape(-1).to(self.device) for t in ts])
+            vdist.dist.broadcast(flat, src=vdist.dist.get_global_rank(self.group, src) if self.group is not None else src, group=self.group)
+            off = 0
+            for t in ts:
+                n = t.numel()
+                t.copy_(flat[off:off + n].reshape(t.shape).to(t.device))
+                off += n
+        self.epoch_num, self.frame = int(counters[0].item()), int(counters[1].item())
+        self.model.running_obs._seen = None  # (host-side cache of n > 0: ask the device again)
 
     # compatibility with the round-2 attribute names
     @property
@@ -634,11 +667,29 @@ class PPOAgent(PolicyInference):
         return fn + ".pth"
 
     def restore(self, path):
-        self.set_full_state_weights(torch.load(path, map_location=self.device, weights_only=False))
+        """world > 1: what rank 0 loaded is what every rank continues from (the file need not be visible to, or the same on, every rank)"""
+        rank0 = _world(self.group) <= 1 or vdist.dist.get_rank(self.group) == 0
+        if rank0 or os.path.exists(path):
+            self.set_full_state_weights(torch.load(path, map_location=self.device, weights_only=False))
+        self._materialise_optimizer_state()
+        self.broadcast_state()
+
+    def _materialise_optimizer_state(self):
+        """Adam's per-parameter state exists only after a step or a load: a rank that could not read the checkpoint gets zero-filled slots
+        of the right shapes so that the broadcast has something to fill."""
+        if _world(self.group) <= 1:
+            return
+        flag = torch.tensor([1.0 if len(self.optimizer.state) else 0.0], device=self.device)
+        vdist.dist.all_reduce(flag, op=vdist.dist.ReduceOp.MAX, group=self.group)
+        if flag.item() > 0 and not len(self.optimizer.state):
+            for g in self.optimizer.param_groups:
+                for p in g["params"]:
+                    self.optimizer.state[p] = {"step": torch.zeros((), dtype=torch.float32), "exp_avg": torch.zeros_like(p), "exp_avg_sq": torch.zeros_like(p)}
 
     def load_pretrained(self, path):
         """ImitatorAgent.load_pretrained (im_agent.py:114-155) for EmbodyPose checkpoints: the weights and normalisers, not the optimizer"""
         self.set_full_state_weights(torch.load(path, map_location=self.device, weights_only=False), optimizer=False)
+        self.broadcast_state()
 
     def train(self, max_epochs=None, log=print, network_path=None):
         """ImitatorAgent.train (im_agent.py:164-269): epochs of train_epoch with the reference's log line; checkpoints `<name>_latest` /
