@@ -150,6 +150,21 @@ int v2p_policy_head(int64_t n, float* mu, const float* context_feat, int64_t ctx
 int v2p_gae(int64_t horizon, int64_t n, const float* fdones, const float* values, const float* rewards, const float* next_values,
             float gamma, float tau, float* advs, void* stream);
 
+/* ---- per-clip body assets ---------------------------------------------------------------
+ * The geometry half of the reference's per-clip asset build (humanoid_smpl_im.py:255-296 -> uhc/smpllib/smpl_local_robot.py:79-143
+ * `get_joint_geometries`: ConvexHull of every body's vertex cloud -> decimated mesh; Isaac Gym then integrates the mass properties at
+ * the geom density), for thousands of (shape, body) JOBS in one launch, one wavefront per job, float64:
+ *   cloud -> convex hull -> at most max_verts (<= 64) support vertices (the Fibonacci-direction tables `dirs`, tried in order until
+ *   the distinct support points fit) -> hull of those -> mass, centre of mass, inertia about it.
+ * All pointers are DEVICE pointers.  points [total,3]; job_offsets [num_jobs+1] (first point of every job); max_points = the
+ * largest cloud (sizes the LDS arrays: ~48 B per point x 2; up to ~1600 points); dirs [.,3] + dir_offsets [num_dir_tables+1].
+ * Out per job: mass, com [3], inertia [9], num_verts, vert_ids [max_verts] (indices into the job's cloud, ascending), verts
+ * [max_verts,3], status (0 ok, 1 fewer than 4 points, 2 coplanar cloud, 3 face capacity, 4 reduction failed).
+ * vid2player3d_amd/body_shapes.py holds the host-side wrapper and the numpy statement of the same algorithm (the checker). */
+int v2p_shapes_compile(int32_t num_jobs, const double* points, const int32_t* job_offsets, int32_t max_points, const double* dirs,
+                       const int32_t* dir_offsets, int32_t num_dir_tables, double density, int32_t max_verts, double eps_rel, double* mass,
+                       double* com, double* inertia, int32_t* num_verts, int32_t* vert_ids, double* verts, int32_t* status, void* stream);
+
 /* ---- environments -----------------------------------------------------------------------
  * Simulation + task parameters (cfg/amass_im.yaml:3-52, utils/config.py:190-222). */
 typedef struct {

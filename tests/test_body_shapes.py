@@ -75,3 +75,21 @@ def test_shape_family_is_non_uniform():
     assert len({tuple(np.diff(m.hull_offsets)) for m in fam}) == len(fam)  # non-affine: every shape has its own hull topology
     uni = base.scaled(1.1)
     assert abs(uni.mass[9] / uni.mass[2] - base.mass[9] / base.mass[2]) < 1e-12  # (what uniform scaling cannot do)
+
+
+def test_batched_family_equals_the_shape_by_shape_one():
+    """family_params draws what the former per-shape loop drew (nine uniforms per shape, in order), and deform_clouds for S shapes at once
+    gives each shape the clouds and rest joints `deform` builds for it alone."""
+    base = load_baked_model()
+    rng = np.random.default_rng(3)
+    P = bs.family_params(4, seed=3)
+    for i in range(4):
+        h = rng.uniform(0.9, 1.1)
+        row = dict(leg=h * rng.uniform(0.92, 1.08), arm=h * rng.uniform(0.92, 1.08), trunk=h * rng.uniform(0.95, 1.05), girth=rng.uniform(0.82, 1.08),
+                   shoulder=rng.uniform(0.9, 1.15), belly=rng.uniform(0.9, 1.2), taper=rng.uniform(-0.25, 0.25), bulge=rng.uniform(-0.15, 0.1))
+        assert all(P[k][i] == row[k] for k in row)
+    clouds, rest = bs.deform_clouds(base, P)
+    one, rest1 = bs.deform_clouds(base, {k: v[2:3] for k, v in P.items()})
+    assert all(np.array_equal(c[2], o[0]) for c, o in zip(clouds, one)) and np.array_equal(rest[2], rest1[0])
+    tabs, off = bs.reduce_direction_tables(64)
+    assert list(np.diff(off)) == [256, 204, 163, 130, 104, 83, 66, 52] and tabs.shape == (off[-1], 3)

@@ -171,50 +171,160 @@ _ARMS = ("L_Thorax", "L_Shoulder", "L_Elbow", "L_Wrist", "L_Hand", "R_Thorax", "
 _TRUNK = ("Pelvis", "Torso", "Spine", "Chest", "Neck", "Head")
 
 
-def deform(base, leg=1.0, arm=1.0, trunk=1.0, girth=1.0, shoulder=1.0, belly=1.0, taper=0.0, bulge=0.0, **model_kw):
-    """One non-uniform variant of `base`: bone offsets of the leg / arm / trunk chains scaled along their own direction, the
-    clouds stretched by the same factor along the bone and by `girth` across it, shoulders moved apart by `shoulder`, the
-    pelvis / torso / spine clouds inflated by `belly` - the kind of variation SMPL betas produce (height, limb proportions, weight).
-    `taper` / `bulge` make the cross-section vary along the bone (linearly / quadratically): NON-affine, so the set of extreme
-    points - the hull topology - changes, not only its coordinates."""
-    clouds, rest = clouds_of(base, dense=(taper != 0.0 or bulge != 0.0))
+FAMILY_PARAMS = ("leg", "arm", "trunk", "girth", "shoulder", "belly", "taper", "bulge")
+_DENSE_CACHE = {}
+
+
+def _dense_clouds(base):
+    """clouds_of(base, dense=True), once per base model (shape independent: every variant deforms the same sampled surface)."""
+    key = id(base)
+    if key not in _DENSE_CACHE or _DENSE_CACHE[key][0] is not base:
+        _DENSE_CACHE.clear()
+        _DENSE_CACHE[key] = (base, clouds_of(base, dense=True))
+    return _DENSE_CACHE[key][1]
+
+
+def deform_clouds(base, params, dense=True):
+    """The vertex clouds and rest joints of S non-uniform variants of `base` at once: params = dict of [S] arrays (FAMILY_PARAMS).
+    Bone offsets of the leg / arm / trunk chains are scaled along their own direction, the clouds stretched by the same factor along
+    the bone and by `girth` across it, shoulders moved apart by `shoulder`, the pelvis / torso / spine clouds inflated by `belly` -
+    the kind of variation SMPL betas produce (height, limb proportions, weight).  `taper` / `bulge` make the cross-section vary along
+    the bone (linearly / quadratically): NON-affine, so the set of extreme points - the hull topology - changes, not only its
+    coordinates.  Returns (clouds: list over bodies of [S, n_b, 3], rest joints [S, 24, 3])."""
+    P = {k: np.atleast_1d(np.asarray(params.get(k, 0.0 if k in ("taper", "bulge") else 1.0), dtype=np.float64)) for k in FAMILY_PARAMS}
+    S = max(len(v) for v in P.values())
+    P = {k: np.broadcast_to(v, (S,)) for k, v in P.items()}
+    clouds, _ = _dense_clouds(base) if dense else clouds_of(base)
     names = base.body_names
     nb = base.num_bodies
-    fac = {n: (leg if n in _LEGS else arm if n in _ARMS else trunk) for n in names}
-    new_local = base.local_pos.copy()
+    fac = np.stack([P["leg"] if n in _LEGS else P["arm"] if n in _ARMS else P["trunk"] for n in names], axis=1)  # [S, nb]
+    new_local = base.local_pos[None] * fac[:, :, None]
+    lat = np.zeros(3)
+    lat[int(np.argmax(np.abs(base.local_pos[base.body_index("L_Shoulder")])))] = 1.0  # the lateral axis of the rest pose
     for b in range(1, nb):
-        new_local[b] = base.local_pos[b] * fac[names[b]]
         if names[b] in ("L_Thorax", "R_Thorax", "L_Shoulder", "R_Shoulder"):
-            lat = np.zeros(3)
-            k = int(np.argmax(np.abs(base.local_pos[base.body_index("L_Shoulder")])))  # the lateral axis of the rest pose
-            lat[k] = 1.0
-            new_local[b] = new_local[b] + (shoulder - 1.0) * (base.local_pos[b] @ lat) * lat
-    new_rest = np.zeros((nb, 3))
+            new_local[:, b] = new_local[:, b] + ((P["shoulder"] - 1.0) * (base.local_pos[b] @ lat))[:, None] * lat
+    new_local[:, 0] = base.local_pos[0]
+    new_rest = np.zeros((S, nb, 3))
     for b in range(nb):
         p = int(base.parents[b])
-        new_rest[b] = new_local[b] + (new_rest[p] if p >= 0 else 0.0)
+        new_rest[:, b] = new_local[:, b] + (new_rest[:, p] if p >= 0 else 0.0)
     children = base.children_lists()
-    new_clouds = []
+    out = []
     for b in range(nb):
         # bone axis of body b: towards its first child (leaves: from the parent)
         axis = base.local_pos[children[b][0]] if children[b] else base.local_pos[b]
         axis = axis / (np.linalg.norm(axis) + 1e-12)
         along = clouds[b] @ axis
         across = clouds[b] - np.outer(along, axis)
-        g = girth * (belly if names[b] in ("Pelvis", "Torso", "Spine") else 1.0)
+        g = P["girth"] * (P["belly"] if names[b] in ("Pelvis", "Torso", "Spine") else 1.0)
         u = (along - along.min()) / (np.ptp(along) + 1e-12)  # 0 .. 1 along the bone
-        prof = g * (1.0 + taper * (u - 0.5) + bulge * (0.25 - (u - 0.5) ** 2) * 4.0)
-        new_clouds.append(np.outer(along * fac[names[b]], axis) + across * prof[:, None])
-    return body_from_clouds(base, new_clouds, new_rest, **model_kw)
+        prof = g[:, None] * (1.0 + P["taper"][:, None] * (u - 0.5)[None] + P["bulge"][:, None] * ((0.25 - (u - 0.5) ** 2) * 4.0)[None])
+        out.append((along[None, :] * fac[:, b, None])[:, :, None] * axis + across[None] * prof[:, :, None])
+    return out, new_rest
 
 
-def synthetic_shape_family(base, num, seed=0, **model_kw):
-    """`num` non-uniform variants of `base` (seeded): the stand-in for one SMPL shape per clip."""
-    rng = np.random.default_rng(seed)
+def deform(base, leg=1.0, arm=1.0, trunk=1.0, girth=1.0, shoulder=1.0, belly=1.0, taper=0.0, bulge=0.0, **model_kw):
+    """One non-uniform variant of `base` (deform_clouds for a single shape, compiled on the CPU)."""
+    clouds, rest = deform_clouds(base, dict(leg=leg, arm=arm, trunk=trunk, girth=girth, shoulder=shoulder, belly=belly, taper=taper, bulge=bulge),
+                                 dense=(taper != 0.0 or bulge != 0.0))
+    return body_from_clouds(base, [c[0] for c in clouds], rest[0], **model_kw)
+
+
+def family_params(num, seed=0):
+    """The seeded parameters of `num` synthetic body shapes (one row of nine uniform draws per shape)."""
+    u = np.random.default_rng(seed).random((num, 9))
+    lohi = [(0.9, 1.1), (0.92, 1.08), (0.92, 1.08), (0.95, 1.05), (0.82, 1.08), (0.9, 1.15), (0.9, 1.2), (-0.25, 0.25), (-0.15, 0.1)]
+    v = [lo + (hi - lo) * u[:, k] for k, (lo, hi) in enumerate(lohi)]
+    h = v[0]  # overall height
+    return dict(leg=h * v[1], arm=h * v[2], trunk=h * v[3], girth=v[4], shoulder=v[5], belly=v[6], taper=v[7], bulge=v[8])
+
+
+def synthetic_shape_family(base, num, seed=0, device=None, **model_kw):
+    """`num` non-uniform variants of `base` (seeded): the stand-in for one SMPL shape per clip.  device = a torch cuda device: hulls and
+    mass properties of all num x 24 bodies in one launch of the engine's shape compiler (v2p_shapes_compile) instead of the numpy loop
+    (0.4 s per shape) - same algorithm, same result to float64 rounding (tests/test_gpu_shapes.py)."""
+    clouds, rest = deform_clouds(base, family_params(num, seed))
+    if device is not None:
+        return bodies_from_clouds_device(base, clouds, rest, device, **model_kw)
+    return [body_from_clouds(base, [c[s] for c in clouds], rest[s], **model_kw) for s in range(num)]
+
+
+def reduce_direction_tables(max_verts=MAX_HULL_VERTS):
+    """The direction sets reduce_hull tries in turn (4 x max_verts Fibonacci directions, then 0.8 x as many, ... until a set no larger
+    than max_verts, whose distinct support points always fit): (dirs [sum k, 3], offsets [tables + 1])."""
+    ks, k = [], 4 * max_verts
+    while True:
+        ks.append(k)
+        if k <= max_verts:
+            break
+        k = int(k * 0.8)
+    return np.concatenate([fibonacci_directions(k) for k in ks]), np.concatenate([[0], np.cumsum(ks)]).astype(np.int32)
+
+
+def compile_clouds_device(points, offsets, device, density=GEOM_DENSITY, max_verts=MAX_HULL_VERTS, eps_rel=1e-10):
+    """The engine's shape compiler on a flat list of clouds: points [T,3] float64, offsets [J+1] -> dict of numpy arrays per job
+    (mass [J], com [J,3], inertia [J,3,3], num_verts [J], vert_ids [J,max_verts], verts [J,max_verts,3]).  HIP only (no CPU path:
+    body_from_clouds is the numpy statement of the same algorithm and the checker of this one)."""
+    import torch
+
+    from . import _lib
+
+    lib = _lib.load()
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError("compile_clouds_device runs on the HIP engine only (device=%r)" % (device,))
+    offsets = np.asarray(offsets, dtype=np.int64)
+    J = len(offsets) - 1
+    sizes = np.diff(offsets)
+    if J < 1 or sizes.min() < 4:
+        raise ValueError("every cloud needs at least 4 points")
+    dirs, doff = reduce_direction_tables(max_verts)
+    with torch.cuda.device(dev):
+        t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(dev)  # noqa: E731
+        pts, off = t(points, torch.float64), t(offsets, torch.int32)
+        d_dirs, d_doff = t(dirs, torch.float64), t(doff, torch.int32)
+        mass = torch.zeros(J, dtype=torch.float64, device=dev)
+        com = torch.zeros((J, 3), dtype=torch.float64, device=dev)
+        inertia = torch.zeros((J, 3, 3), dtype=torch.float64, device=dev)
+        nv = torch.zeros(J, dtype=torch.int32, device=dev)
+        vid = torch.zeros((J, max_verts), dtype=torch.int32, device=dev)
+        verts = torch.zeros((J, max_verts, 3), dtype=torch.float64, device=dev)
+        status = torch.full((J,), -1, dtype=torch.int32, device=dev)
+        _lib.check(lib.v2p_shapes_compile(J, _lib.ptr(pts), _lib.ptr(off), int(sizes.max()), _lib.ptr(d_dirs), _lib.ptr(d_doff), len(doff) - 1, float(density),
+                                          int(max_verts), float(eps_rel), _lib.ptr(mass), _lib.ptr(com), _lib.ptr(inertia), _lib.ptr(nv), _lib.ptr(vid),
+                                          _lib.ptr(verts), _lib.ptr(status), _lib.current_stream(dev)), "v2p_shapes_compile")
+        st = status.cpu().numpy()
+    if (st != 0).any():
+        j = int(np.nonzero(st)[0][0])
+        raise ValueError("v2p_shapes_compile: cloud %d of %d: %s" % (j, J, {1: "fewer than 4 points", 2: "the points are coplanar", 3: "hull face capacity exceeded",
+                                                                          4: "support reduction failed"}.get(int(st[j]), "status %d" % st[j])))
+    return dict(mass=mass.cpu().numpy(), com=com.cpu().numpy(), inertia=inertia.cpu().numpy(), num_verts=nv.cpu().numpy(), vert_ids=vid.cpu().numpy(),
+                verts=verts.cpu().numpy())
+
+
+def bodies_from_clouds_device(base, clouds, rest_joints, device, density=GEOM_DENSITY, max_verts=MAX_HULL_VERTS, **model_kw):
+    """body_from_clouds for S shapes at once on the device: clouds = list over the 24 bodies of [S, n_b, 3] (or of lists of [n, 3], one
+    per shape), rest_joints [S, 24, 3] -> S BodyModels."""
+    nb = base.num_bodies
+    rest = np.asarray(rest_joints, dtype=np.float64)
+    S = rest.shape[0]
+    if len(clouds) != nb or rest.shape != (S, nb, 3):
+        raise ValueError("expected %d cloud sets and rest joints [S,%d,3]" % (nb, nb))
+    per = [[np.asarray(clouds[b][s], dtype=np.float64) for b in range(nb)] for s in range(S)]  # job order = (shape, body)
+    sizes = np.array([[len(c) for c in row] for row in per]).reshape(-1)
+    offsets = np.concatenate([[0], np.cumsum(sizes)])
+    points = np.concatenate([c for row in per for c in row], axis=0)
+    r = compile_clouds_device(points, offsets, device, density, max_verts)
+    par = np.asarray(base.parents)
+    local_pos = rest - np.where(par[None, :, None] >= 0, rest[:, np.maximum(par, 0)], 0.0)
     out = []
-    for _ in range(num):
-        h = rng.uniform(0.9, 1.1)  # overall height
-        out.append(deform(base, leg=h * rng.uniform(0.92, 1.08), arm=h * rng.uniform(0.92, 1.08), trunk=h * rng.uniform(0.95, 1.05),
-                          girth=rng.uniform(0.82, 1.08), shoulder=rng.uniform(0.9, 1.15), belly=rng.uniform(0.9, 1.2),
-                          taper=rng.uniform(-0.25, 0.25), bulge=rng.uniform(-0.15, 0.1), **model_kw))
+    nv = r["num_verts"].reshape(S, nb)
+    for s in range(S):
+        j0 = s * nb
+        blob = dict(base.blob)
+        off = np.concatenate([[0], np.cumsum(nv[s])]).astype(np.int32)
+        hv = np.concatenate([r["verts"][j0 + b, :nv[s, b]] for b in range(nb)], axis=0)
+        blob.update(local_pos=local_pos[s], mass=r["mass"][j0:j0 + nb], com=r["com"][j0:j0 + nb], inertia=r["inertia"][j0:j0 + nb], hull_offsets=off, hull_verts=hv)
+        out.append(BodyModel(blob, **model_kw))
     return out

@@ -323,6 +323,18 @@ int v2p_gae(int64_t horizon, int64_t n, const float* fdones, const float* values
     return launch_gae(horizon, n, fdones, values, rewards, next_values, gamma, tau, advs, (hipStream_t)stream);
 }
 
+int v2p_shapes_compile(int32_t num_jobs, const double* points, const int32_t* job_offsets, int32_t max_points, const double* dirs, const int32_t* dir_offsets,
+                       int32_t num_dir_tables, double density, int32_t max_verts, double eps_rel, double* mass, double* com, double* inertia, int32_t* num_verts,
+                       int32_t* vert_ids, double* verts, int32_t* status, void* stream) {
+    if (num_jobs < 0 || max_points < 0 || max_verts < 4 || max_verts > 64 || num_dir_tables < 1 || !(density > 0.0) || !(eps_rel >= 0.0)) { set_error("v2p_shapes_compile: bad argument"); return V2P_ERR_INVALID; }
+    if (num_jobs > 0 && (!points || !job_offsets || !dirs || !dir_offsets || !mass || !com || !inertia || !num_verts || !vert_ids || !verts || !status)) {
+        set_error("v2p_shapes_compile: null buffer");
+        return V2P_ERR_INVALID;
+    }
+    return launch_shape_compile(num_jobs, points, job_offsets, max_points, dirs, dir_offsets, num_dir_tables, density, max_verts, eps_rel, mass, com, inertia,
+                                num_verts, vert_ids, verts, status, (hipStream_t)stream);
+}
+
 static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, const int32_t* env_shape_id, const v2p_mlib* mlib,
                            const v2p_sim_cfg* c, const int64_t* env_motion_id, int64_t n, const v2p_env_buffers* b, int device, v2p_env** out) {
     if (!shapes || num_shapes < 1 || !shapes[0]) { set_error("v2p_env_create: bad argument"); return V2P_ERR_INVALID; }

@@ -221,6 +221,9 @@ int launch_policy_head(int64_t n, float* mu, const float* context_feat, int64_t 
                        float* action, float* sigma_out, float* neglogp, hipStream_t s);
 int launch_gae(int64_t horizon, int64_t n, const float* fdones, const float* values, const float* rewards, const float* next_values, float gamma,
                float tau, float* advs, hipStream_t s);
+int launch_shape_compile(int32_t jobs, const double* pts, const int32_t* job_off, int32_t max_pts, const double* dirs, const int32_t* dir_off, int32_t num_tables,
+                         double density, int32_t max_verts, double eps_rel, double* mass, double* com, double* inertia, int32_t* num_verts, int32_t* vert_ids,
+                         double* verts, int32_t* status, hipStream_t s);
 int launch_env_reset(v2p_env* e, const int64_t* env_ids, int64_t n, const float* motion_times, hipStream_t s);
 int launch_env_context(v2p_env* e, const int64_t* env_ids, int64_t n, const float* motion_times, hipStream_t s);
 int launch_env_pre(v2p_env* e, float* actions, hipStream_t s);
