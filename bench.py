@@ -75,10 +75,11 @@ def self_launch(gpus, argv, stub):
 
 
 # ---------------------------------------------------------------------------------------------- the workload
-def build_task(num_envs, device_id, seed, contact=True, per_clip_shapes=False, djokovic=False, freeze=False, solver="pgs", racket_ball=False, substep_jobs=False, joint_limits=None, env_extra=None):
+def build_task(num_envs, device_id, seed, contact=True, per_clip_shapes=False, num_shapes=64, djokovic=False, freeze=False, solver="pgs", racket_ball=False, substep_jobs=False, joint_limits=None, env_extra=None):
     from vid2player3d_amd.tasks import HumanoidSMPLIM, HumanoidSMPLIMRacketBall, default_cfg
 
-    cfg = default_cfg(num_envs, synthetic_motions={"seed": 7, "num_clips": 64, "min_frames": 90, "max_frames": 300},
+    num_clips = num_shapes if per_clip_shapes else 64
+    cfg = default_cfg(num_envs, synthetic_motions={"seed": 7, "num_clips": num_clips, "min_frames": 90, "max_frames": 300},
                       enable_contact=contact, contact_solver=solver, substep_jobs=substep_jobs)
     if joint_limits is not None:
         cfg["env"]["joint_limits"] = bool(joint_limits)
@@ -88,11 +89,15 @@ def build_task(num_envs, device_id, seed, contact=True, per_clip_shapes=False, d
     if djokovic:  # BASELINE config 4 = cfg/djokovic_im.yaml: same task class, head termination height -0.5, faster (tennis-like) clips
         cfg["env"]["terminationHeadHeight"] = -0.5
         cfg["env"]["synthetic_motions"]["speed"] = 2.0
-    if per_clip_shapes:  # one body shape per clip like the reference's per-clip SMPL assets: 64 non-uniform shapes built from vertex clouds
+    if per_clip_shapes:  # one body shape per clip like the reference's per-clip SMPL assets: non-uniform shapes built from vertex clouds
         from vid2player3d_amd import body_shapes
         from vid2player3d_amd.model import load_baked_model
 
-        cfg["env"]["body_model"] = body_shapes.synthetic_shape_family(load_baked_model(), 64, seed=7)
+        t0 = time.perf_counter()
+        cfg["env"]["body_model"] = body_shapes.synthetic_shape_family(load_baked_model(), num_shapes, seed=7, device="cuda:%d" % device_id)
+        sys.stderr.write("bench.py: %d body shapes compiled on the device in %.2f s\n" % (num_shapes, time.perf_counter() - t0))
+        if num_shapes != 64:  # env i -> clip i %% num_shapes -> its shape: every shape is simulated (64: clips sampled at random, as in rounds 3-4)
+            cfg["env"]["sample_first_motions"] = True
     torch.manual_seed(seed)
     if racket_ball:  # BASELINE config 4 as it is worded: racket welded to the wrist + free ball in every env
         task = HumanoidSMPLIMRacketBall(cfg, device_type="cuda", device_id=device_id)
@@ -398,7 +403,8 @@ def main():
                     help="enforce the MJCF joint ranges as limit rows (only the racket arm of --racket-ball has any; default: on with --racket-ball, else off)")
     ap.add_argument("--racket-ball", action="store_true", help="BASELINE config 4 as worded: racket welded to the wrist + free ball with drag / Magnus lift, ball-ground and ball-racket contacts (implies --djokovic)")
     ap.add_argument("--ball-body-contacts", type=int, default=1, choices=(0, 1), help="--racket-ball: ball x link-hull contacts (0: only ball x racket and ball x ground, for A/B)")
-    ap.add_argument("--per-clip-shapes", action="store_true", help="one body shape per clip (64 scaled bodies) instead of one shape for all envs")
+    ap.add_argument("--per-clip-shapes", action="store_true", help="one NON-UNIFORM body shape per clip (the reference's per-clip SMPL assets) instead of one shape for all envs")
+    ap.add_argument("--num-shapes", type=int, default=64, help="--per-clip-shapes: clips = shapes (64; 2048 / 8192 = AMASS scale: env i simulates shape i %% num_shapes)")
     ap.add_argument("--ppo", action="store_true", help="BASELINE config 5 loop: device-resident rollout (play_steps) + GAE + PPO update per epoch; prints the reference's fps step / fps total")
     ap.add_argument("--ppo-epochs", type=int, default=4, help="timed PPO epochs (after one untimed warm-up epoch)")
     ap.add_argument("--groups", type=int, default=1, help="rollout groups per GPU: the rank's envs as G env batches on G HIP streams (reported separately from the headline; "
@@ -448,7 +454,7 @@ def main():
             build.build()  # no-op when the in-tree .so is current; one rank per node compiles otherwise
         if dist is not None:
             dist.barrier()
-        tasks = [build_task(n // G, local_rank, seed=7 + rank + 100 * g, contact=not args.no_contact, per_clip_shapes=args.per_clip_shapes, djokovic=args.djokovic or args.racket_ball,
+        tasks = [build_task(n // G, local_rank, seed=7 + rank + 100 * g, contact=not args.no_contact, per_clip_shapes=args.per_clip_shapes, num_shapes=args.num_shapes, djokovic=args.djokovic or args.racket_ball,
                           freeze=args.freeze_terminated, solver=args.solver, racket_ball=args.racket_ball, substep_jobs=bool(args.substep_jobs),
                           joint_limits=args.joint_limits,
                           env_extra={k: v for k, v in (("job_mono_permille", args.job_mono), ("pair_mix_permille", args.pair_mix), ("kernel_build", args.kernel_build), ("ball_body_contacts", None if args.ball_body_contacts else False)) if v is not None})  # per-rank seed like run.py:37
@@ -602,9 +608,9 @@ def main():
                             "whole_epoch block: %d steps = %d whole epochs timed right after the %d requested steps, same barriers (a region that is not whole epochs "
                             "times the light start of an epoch: requested_region)" % (whole["steps"], WHOLE_EPOCHS, args.steps),
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "amass_im num_envs=%d per GPU, %s, imitation reward, per-epoch reset+context every %d steps, 64 synthetic clips, action noise %.3g%s"
+            "config": {"workload": "amass_im num_envs=%d per GPU, %s, imitation reward, per-epoch reset+context every %d steps, %s synthetic clips, action noise %.3g%s"
                                    % (n, "PD control only (no contact solve)" if args.no_contact else "full contact %s (4 substeps x 4 iterations)" % args.solver.upper(), HORIZON,
-                                      args.action_noise, (", one NON-UNIFORM body shape per clip (64 shapes from vertex clouds)" if args.per_clip_shapes else "") + (", djokovic_im variant" if args.djokovic or args.racket_ball else "") + (", RACKET + BALL in every env (reported separately)" if args.racket_ball else "") + (", joint limits on" if (args.joint_limits if args.joint_limits is not None else args.racket_ball) else "") +
+                                      args.num_shapes if args.per_clip_shapes else 64, args.action_noise, (", one NON-UNIFORM body shape per clip (%d shapes from vertex clouds, %d clips)" % (args.num_shapes, args.num_shapes) if args.per_clip_shapes else "") + (", djokovic_im variant" if args.djokovic or args.racket_ball else "") + (", RACKET + BALL in every env (reported separately)" if args.racket_ball else "") + (", joint limits on" if (args.joint_limits if args.joint_limits is not None else args.racket_ball) else "") +
                                       (", %d ROLLOUT GROUPS of %d envs on %d streams (reported separately from the headline)" % (G, ng, G) if G > 1 else "") +
                                       (", stand-in policy evaluated once per epoch (targets = context frames)" if per_epoch else ", stand-in policy evaluated before every step") + (", TERMINATED ENVS FROZEN (not reference behaviour)" if args.freeze_terminated else "") + (", STUB TASK (launch-logic test, not a measurement)" if stub else "")),
                        "num_envs_per_gpu": n, "global_envs": world * n, "parallelism": "env-sharded x%d, no data-path collective" % world,

@@ -150,6 +150,19 @@ int v2p_policy_head(int64_t n, float* mu, const float* context_feat, int64_t ctx
 int v2p_gae(int64_t horizon, int64_t n, const float* fdones, const float* values, const float* rewards, const float* next_values,
             float gamma, float tau, float* advs, void* stream);
 
+/* ---- reference-motion tables from clips ----------------------------------------------------
+ * What the reference computes offline per clip with poselib (uhc/utils/convert_amass_isaac.py:134-153: SkeletonState.from_rotation_and_
+ * root_translation -> SkeletonMotion.from_skeleton_state, poselib/poselib/skeleton/skeleton3d.py:409-431 forward kinematics, :1226-1249
+ * finite-difference + Gaussian velocities) and MotionLib flattens (embodied_pose/utils/motion_lib.py:370-384, 443-458 dof velocities),
+ * for all frames of all clips in two launches.  DEVICE pointers: local_rot [F,24,4] xyzw and root_trans [F,3] (float64, the clips
+ * concatenated), frame_clip [F], clip_start [C] (= length_starts), clip_frames [C], clip_dt [C], local_pos [24,3] - or [C,24,3] with
+ * per_clip_skeleton (every clip of the reference carries its own SMPL shape).  parents [24]: HOST array.  Out (float32, the layout of
+ * v2p_motion_tables): gts [F,24,3] grs [F,24,4] lrs [F,24,4] grvs [F,3] gravs [F,3] dvs [F,69]. */
+int v2p_motion_tables_build(int64_t num_frames_total, int64_t num_clips, const double* local_rot, const double* root_trans,
+                            const int32_t* frame_clip, const int64_t* clip_start, const int32_t* clip_frames, const double* clip_dt,
+                            const int32_t* parents, const double* local_pos, int32_t per_clip_skeleton, float* gts, float* grs, float* lrs,
+                            float* grvs, float* gravs, float* dvs, void* stream);
+
 /* ---- per-clip body assets ---------------------------------------------------------------
  * The geometry half of the reference's per-clip asset build (humanoid_smpl_im.py:255-296 -> uhc/smpllib/smpl_local_robot.py:79-143
  * `get_joint_geometries`: ConvexHull of every body's vertex cloud -> decimated mesh; Isaac Gym then integrates the mass properties at

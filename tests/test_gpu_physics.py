@@ -81,8 +81,9 @@ def _run_pair(mlib, n, contact, seed, lift=0.0, vel_sigma=0.5, steps=1, hold="fi
     par.rest_offset = float(((env.get("sim_overrides") or {}).get("physx") or {}).get("rest_offset", 0.0))
     if shapes is None:
         oracle = BatchOracle(task.body_model, len(ids_o), par)
-    else:  # the oracle of env e simulates the body shape of its clip
-        oracle = BatchOracle(shapes, len(ids_o), par, model_of=np.asarray(task._env_shape_ids)[ids_o])
+    else:  # the oracle of env e simulates the body shape of its clip (only the shapes of the compared envs are built)
+        used, model_of = np.unique(np.asarray(task._env_shape_ids)[ids_o], return_inverse=True)
+        oracle = BatchOracle([shapes[int(k)] for k in used], len(ids_o), par, model_of=model_of)
     oracle.set_state(root[ids_o], dpos[ids_o], dvel[ids_o])
     out = []
     for s in range(steps):
@@ -745,6 +746,29 @@ def test_full_size_sample_matches_oracle(mlib):
     subset = sorted(set([0, 1, 2, n - 1, n - 2] + list(np.random.default_rng(8).integers(0, n, size=59))))
     (got, ref), = _run_pair(mlib, n, contact=True, seed=6, lift=0.0, subset=subset, what="8192-env sample")
     _compare(got, ref, "8192-env sample")
+
+
+def test_full_size_sample_with_one_body_shape_per_clip_at_amass_scale():
+    """The reference's real body configuration at its scale (humanoid_smpl_im.py:247-296: every env simulates the SMPL body of its clip;
+    AMASS = thousands of clips): 2048 non-uniform shapes compiled on the device (v2p_shapes_compile), 2048 clips - each built on its
+    own skeleton -, 8192 envs, env i -> clip i % 2048 -> its shape; 64 sampled envs, each against the float64 oracle of ITS shape."""
+    from vid2player3d_amd import body_shapes, synth
+    from vid2player3d_amd.model import load_baked_model
+    from vid2player3d_amd.motion_lib import MotionLib
+
+    n, S = 8192, 2048
+    base = load_baked_model()
+    shapes = body_shapes.synthetic_shape_family(base, S, seed=21, device=DEV)
+    lib = MotionLib.from_clips(synth.make_clips(9, S, 40, 80), shapes, DEV)
+    subset = sorted(set([0, 1, S - 1, S, n - 1, n - 2] + list(np.random.default_rng(9).integers(0, n, size=58))))
+    for contact, lift, seed in ((True, -0.05, 71), (True, -0.7, 72)):
+        (got, ref), = _run_pair(lib, n, contact, seed, lift=lift, vel_sigma=0.5 if lift > -0.5 else 0.2, shapes=shapes, subset=subset, what="2048 shapes lift %.2f" % lift)
+        assert (got["ids"] >= 0).any(axis=(1, 2)).mean() > 0.8
+        _compare(got, ref, "2048 shapes lift %.2f" % lift)
+    t = make_task(n, lib, body_model=shapes)
+    ids = np.asarray(t._env_shape_ids)
+    assert np.array_equal(ids, np.arange(n) % S) and len(np.unique(np.round(t.humanoid_masses, 6))) > 2000
+    t.close()
 
 
 def test_freeze_terminated_envs_option(mlib):

@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libv2p_rollout.so")
-SOURCES = ["capi.hip", "motion_state.hip", "task_ops.hip", "shape_compile.hip", "physics.hip", "physics_ll.hip"]
+SOURCES = ["capi.hip", "motion_state.hip", "task_ops.hip", "shape_compile.hip", "motion_build.hip", "physics.hip", "physics_ll.hip"]
 HEADERS = ["v2p_internal.hpp", "v2p_dev.hpp", "v2p_math.inc", "phys_math.hpp", "phys_common.hpp", "motion_sample.inc", "hull_gjk.hpp", "post_ops.inc", os.path.join("..", "..", "include", "v2p_rollout.h")]
 ARCH = "gfx950"
 
@@ -61,7 +61,7 @@ def build(force=False, verbose=False, lib_out=None, tag=""):
             # for the default build, bound by instruction issue at three waves per SIMD, the same switch costs 0.3 %: profiles/r04e_dual_build.txt)
             fl += ["-Dv2p=v2p_regs", "-DV2P_LL_WPS=2", "-DV2P_LL_WPS_BALL=2", "-DV2P_LL_WPS_LIMITS=2", "-DV2P_LL_PARK2=0", "-DV2P_LL_PARK3=0",
                    "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
-        if s in ("motion_state.hip", "task_ops.hip", "shape_compile.hip"):
+        if s in ("motion_state.hip", "task_ops.hip", "shape_compile.hip", "motion_build.hip"):
             # the task-side kernels restate torch elementwise code: no FMA contraction, so that ill-conditioned spots of the
             # reference itself (acos of a dot product next to 1 in slerp / angle-axis) round the way torch rounds them
             fl = [f if f != "-ffp-contract=fast" else "-ffp-contract=off" for f in fl]

@@ -323,6 +323,18 @@ int v2p_gae(int64_t horizon, int64_t n, const float* fdones, const float* values
     return launch_gae(horizon, n, fdones, values, rewards, next_values, gamma, tau, advs, (hipStream_t)stream);
 }
 
+int v2p_motion_tables_build(int64_t num_frames_total, int64_t num_clips, const double* local_rot, const double* root_trans, const int32_t* frame_clip,
+                            const int64_t* clip_start, const int32_t* clip_frames, const double* clip_dt, const int32_t* parents, const double* local_pos,
+                            int32_t per_clip_skeleton, float* gts, float* grs, float* lrs, float* grvs, float* gravs, float* dvs, void* stream) {
+    if (num_frames_total < 0 || num_clips < 0 || !parents) { set_error("v2p_motion_tables_build: bad argument"); return V2P_ERR_INVALID; }
+    if (num_frames_total > 0 && (!local_rot || !root_trans || !frame_clip || !clip_start || !clip_frames || !clip_dt || !local_pos || !gts || !grs || !lrs || !grvs || !gravs || !dvs)) {
+        set_error("v2p_motion_tables_build: null buffer");
+        return V2P_ERR_INVALID;
+    }
+    return launch_motion_tables_build(num_frames_total, local_rot, root_trans, frame_clip, clip_start, clip_frames, clip_dt, parents, local_pos, per_clip_skeleton ? 1 : 0,
+                                      gts, grs, lrs, grvs, gravs, dvs, (hipStream_t)stream);
+}
+
 int v2p_shapes_compile(int32_t num_jobs, const double* points, const int32_t* job_offsets, int32_t max_points, const double* dirs, const int32_t* dir_offsets,
                        int32_t num_dir_tables, double density, int32_t max_verts, double eps_rel, double* mass, double* com, double* inertia, int32_t* num_verts,
                        int32_t* vert_ids, double* verts, int32_t* status, void* stream) {

@@ -221,6 +221,9 @@ int launch_policy_head(int64_t n, float* mu, const float* context_feat, int64_t 
                        float* action, float* sigma_out, float* neglogp, hipStream_t s);
 int launch_gae(int64_t horizon, int64_t n, const float* fdones, const float* values, const float* rewards, const float* next_values, float gamma,
                float tau, float* advs, hipStream_t s);
+int launch_motion_tables_build(int64_t F, const double* lrot, const double* root_trans, const int32_t* frame_clip, const int64_t* clip_start,
+                               const int32_t* clip_frames, const double* clip_dt, const int32_t* parents_host, const double* local_pos, int per_clip,
+                               float* gts, float* grs, float* lrs, float* grvs, float* gravs, float* dvs, hipStream_t s);
 int launch_shape_compile(int32_t jobs, const double* pts, const int32_t* job_off, int32_t max_pts, const double* dirs, const int32_t* dir_off, int32_t num_tables,
                          double density, int32_t max_verts, double eps_rel, double* mass, double* com, double* inertia, int32_t* num_verts, int32_t* vert_ids,
                          double* verts, int32_t* status, hipStream_t s);

@@ -57,9 +57,13 @@ class MotionLib:
     @classmethod
     def from_clips(cls, clips, body_model, device, **kw):
         """Synthetic / converted clips -> tables (motion_tables.py) -> device."""
+        # forward kinematics + velocity estimation run on the device (v2p_motion_tables_build); build="host": the numpy statement of it
+        # (motion_tables.build_tables, the checker: pinned to the reference's own constructor path)
+        build = kw.pop("build", "device" if torch.device(device).type == "cuda" else "host")
+        make = (lambda c, p, lp: mt.build_tables_device(c, p, lp, device)) if build == "device" else mt.build_tables
         if isinstance(body_model, (list, tuple)):  # one body shape per clip
-            return cls(mt.build_tables(clips, body_model[0].parents, np.stack([m.local_pos for m in body_model])), device, **kw)
-        lib = cls(mt.build_tables(clips, body_model.parents, body_model.local_pos), device, **kw)
+            return cls(make(clips, body_model[0].parents, np.stack([m.local_pos for m in body_model])), device, **kw)
+        lib = cls(make(clips, body_model.parents, body_model.local_pos), device, **kw)
         lib._single_skeleton = True  # every clip was built on this one skeleton, whatever beta labels the clips carry
         return lib
 

@@ -129,6 +129,57 @@ def build_tables(clips, parents, local_pos):
     return out
 
 
+def build_tables_device(clips, parents, local_pos, device):
+    """build_tables on the HIP engine (v2p_motion_tables_build: forward kinematics + velocity estimation of all frames of all clips in
+    two launches; build_tables above is the numpy statement of the same computation and its checker): the frame tables come back as
+    float32 torch tensors on `device`, the per-clip vectors as numpy arrays - what MotionLib() takes.  No CPU path."""
+    import ctypes as C
+
+    import torch
+
+    from . import _lib
+
+    lib = _lib.load()
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError("build_tables_device runs on the HIP engine only (device=%r)" % (device,))
+    nf = np.array([len(c["local_rot"]) for c in clips], dtype=np.int64)
+    if nf.min() < 2:
+        raise ValueError("every clip needs at least 2 frames")
+    F, Cn = int(nf.sum()), len(clips)
+    starts = np.concatenate([[0], np.cumsum(nf)[:-1]]).astype(np.int64)
+    fps = np.array([float(c["fps"]) for c in clips], dtype=np.float64)
+    dt = 1.0 / fps
+    lp = np.asarray(local_pos, dtype=np.float64)
+    per_clip = lp.ndim == 3
+    if lp.shape[-2:] != (24, 3) or (per_clip and lp.shape[0] != Cn):
+        raise ValueError("local_pos must be [24,3] or [num_clips,24,3]")
+    par = np.ascontiguousarray(parents, dtype=np.int32)
+    with torch.cuda.device(dev):
+        t = lambda a, d: torch.as_tensor(np.ascontiguousarray(a), dtype=d).to(dev)  # noqa: E731
+        lrot = t(np.concatenate([np.asarray(c["local_rot"], dtype=np.float64) for c in clips], axis=0), torch.float64)
+        rtr = t(np.concatenate([np.asarray(c["root_trans"], dtype=np.float64) for c in clips], axis=0), torch.float64)
+        fclip = t(np.repeat(np.arange(Cn, dtype=np.int32), nf), torch.int32)
+        d_start, d_nf, d_dt, d_lp = t(starts, torch.int64), t(nf, torch.int32), t(dt, torch.float64), t(lp, torch.float64)
+        out = {"gts": torch.empty((F, 24, 3), dtype=torch.float32, device=dev), "grs": torch.empty((F, 24, 4), dtype=torch.float32, device=dev),
+               "lrs": torch.empty((F, 24, 4), dtype=torch.float32, device=dev), "grvs": torch.empty((F, 3), dtype=torch.float32, device=dev),
+               "gravs": torch.empty((F, 3), dtype=torch.float32, device=dev), "dvs": torch.empty((F, 69), dtype=torch.float32, device=dev)}
+        _lib.check(lib.v2p_motion_tables_build(F, Cn, _lib.ptr(lrot), _lib.ptr(rtr), _lib.ptr(fclip), _lib.ptr(d_start), _lib.ptr(d_nf), _lib.ptr(d_dt),
+                                               par.ctypes.data_as(_lib.c_i32), _lib.ptr(d_lp), int(per_clip), *[_lib.ptr(out[k]) for k in TABLE_KEYS],
+                                               _lib.current_stream(dev)), "v2p_motion_tables_build")
+        torch.cuda.current_stream(dev).synchronize()  # (the float64 inputs go out of scope here)
+    out["motion_num_frames"] = nf
+    out["motion_lengths"] = (dt * (nf - 1)).astype(np.float32)
+    out["motion_dt"] = dt.astype(np.float32)
+    out["motion_fps"] = fps.astype(np.float32)
+    w = np.full(Cn, 1.0 / Cn, dtype=np.float32)
+    out["motion_weights"] = w / w.sum()
+    out["motion_bodies"] = np.stack([np.concatenate([[_GENDER_ID[c["gender"]]], np.asarray(c["beta"], dtype=np.float64)]) for c in clips]).astype(np.float32)
+    out["motion_min_verts_h"] = np.array([c["min_verts_h"] for c in clips], dtype=np.float32)
+    out["length_starts"] = starts
+    return out
+
+
 # ---- one flat, memory-mappable file per motion library -----------------------------------------------------------------------------------
 # (an AMASS-sized library is gigabytes of frame tables: the reference unpickles all of it into host memory, then copies it to the device,
 # `utils/motion_lib.py:67-135`; a mapped file is paged in once, straight into the host-to-device copy, and shared between the ranks of a node)
