@@ -23,7 +23,8 @@ One JSON line on rank 0, with
                 kernel / 157.3 TFLOP/s (vector peak), with the FLOPs per launch taken from the committed SQ counter profile
                 (labelled "from_profiles"); `traffic` (HBM bytes per launch, PMC) is "from_profiles" as well.
   cpu_baseline  the oracle timed on this host's cores on a bounded sample of the same workload (rank 0, N=1 only): the C float64
-                physics restatement stepped as ONE batched OpenMP call per control step + the numpy task ops; kind "port".
+                physics restatement stepped as ONE batched OpenMP call per control step + the numpy task ops, on as many threads as the
+                process may run at once (affinity capped by the cgroup CPU quota); kind "port".
 """
 import argparse
 import json
@@ -220,49 +221,101 @@ def host_cpu_model():
     return "unknown"
 
 
+def usable_cores():
+    """CPUs this process can actually run on at once: the affinity mask, capped by the cgroup's CPU quota (the GPU boxes of this pool
+    show 256 logical CPUs and a quota of 16: more threads than the quota only throttle, profiles/r05_cpu_scaling_*.txt)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:  # cgroup v2
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, quota
+
+
 def cpu_baseline(sizes=((4, 32, 3.0), (1024, 8, 5.0), (8192, 3, 12.0)), sigma=0.17):
     """The oracle on the host cores, same workload (contacts on, sigma-noise actions around the target pose) at the env counts BASELINE.md
     section 3 names (4, 1024, 8192): per control step ONE batched C call for the physics of all envs (OpenMP over envs; the float64 dense
-    restatement built with -O3 -mavx2 -mfma, oracle/phys/Makefile `fast`) and the numpy task ops (single-threaded restatement of the
-    reference's torch ops), timed separately.  sizes: (envs, most steps, seconds budget) - a bounded sample each; `value` is the 8192-env
-    figure (the size the metric is quoted on)."""
+    restatement built with -O3 -mavx2 -mfma, oracle/phys/Makefile `fast`) and the numpy task ops, sharded over the same number of
+    threads (numpy releases the GIL inside its loops).  Threads = the CPUs the process may use at once (affinity capped by the cgroup
+    quota).  sizes: (envs, most steps, seconds budget) - a bounded sample each; `value` is the 8192-env figure (the size the metric is
+    quoted on); the per-thread physics rate is reported at every size, and `scaling_ok` says whether the largest size keeps at least half
+    the per-thread rate of the smallest (a harness that loses more than that is measuring itself)."""
+    from concurrent.futures import ThreadPoolExecutor
+
     from oracle import task_oracle as O
     from oracle.phys_oracle import FAST_FLAGS, BatchOracle, default_params, lib_fast
     from vid2player3d_amd import motion_tables, synth
     from vid2player3d_amd.model import load_baked_model
 
-    cores = os.cpu_count() or 1
-    threads = min(cores, lib_fast().v2p_oracle_max_threads())
+    logical = os.cpu_count() or 1
+    threads, quota = usable_cores()
+    threads = min(threads, lib_fast().v2p_oracle_max_threads())
     bm = load_baked_model()
     clips = synth.make_clips(7, 8, 90, 300)
     tabs = motion_tables.build_tables(clips, bm.parents, bm.local_pos)
+    kp32 = bm.kp.astype(np.float32)
     by_n = {}
+    pool = ThreadPoolExecutor(max_workers=threads)
     for n, max_steps, budget_s in sizes:
         rng = np.random.default_rng(7)
-        task = O.TaskOracle(tabs, np.arange(n) % 8, bm.kp.astype(np.float32))
-        task.reset_all(rng.uniform(0.1, 1.0, size=n).astype(np.float32))
         th = min(threads, n)
+        shards = max(1, min(th, n // 128))  # task ops: one numpy oracle per shard of >= 128 envs, stepped in parallel
+        bounds = np.linspace(0, n, shards + 1).astype(int)
+        ids = np.arange(n) % 8
+        tasks = [O.TaskOracle(tabs, ids[a:b], kp32) for a, b in zip(bounds[:-1], bounds[1:])]
+        times0 = rng.uniform(0.1, 1.0, size=n).astype(np.float32)
+        for t, a, b in zip(tasks, bounds[:-1], bounds[1:]):
+            t.reset_all(times0[a:b])
         oracle = BatchOracle(bm, n, default_params(), threads=th, fast=True)
-        oracle.set_state(task.root_states, task.dof_pos, task.dof_vel)
+        oracle.set_state(np.concatenate([t.root_states for t in tasks]), np.concatenate([t.dof_pos for t in tasks]), np.concatenate([t.dof_vel for t in tasks]))
+        pd, force, torque = np.zeros((n, 69), np.float32), np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+
+        def pre(k):
+            t, a, b = tasks[k], bounds[k], bounds[k + 1]
+            r = np.random.default_rng((7, steps, k))
+            act = np.concatenate([t.target[2] + r.normal(0, sigma, size=(b - a, 69)), r.normal(0, sigma, size=(b - a, 6))], axis=1).astype(np.float32)
+            _, pd[a:b], _, force[a:b], torque[a:b] = t.pre_physics_step(act)
+
+        def post(k):
+            t, a, b = tasks[k], bounds[k], bounds[k + 1]
+            t.set_sim_state(res["dpos"][a:b].astype(np.float32), res["dvel"][a:b].astype(np.float32), res["rb"][a:b].astype(np.float32))
+            t.post_physics_step()
+
         t_phys = t_task = 0.0
-        steps = 0
+        steps = -1  # (one untimed step first: OpenMP team start-up, first touch of the work arrays)
         t0 = time.perf_counter()
-        while steps < max_steps and (steps == 0 or time.perf_counter() - t0 < budget_s):
+        while steps < max_steps and (steps <= 0 or time.perf_counter() - t0 < budget_s):
             steps += 1
+            if steps == 0:
+                list(pool.map(pre, range(shards)))
+                res = oracle.step(pd, force, torque, nsub=4, hold=2)
+                list(pool.map(post, range(shards)))
+                t0 = time.perf_counter()
+                continue
             ta = time.perf_counter()
-            act = np.concatenate([task.target[2] + rng.normal(0, sigma, size=(n, 69)), rng.normal(0, sigma, size=(n, 6))], axis=1).astype(np.float32)
-            _, pd, _, force, torque = task.pre_physics_step(act)
+            list(pool.map(pre, range(shards)))
             tb = time.perf_counter()
             res = oracle.step(pd, force, torque, nsub=4, hold=2)
             tc = time.perf_counter()
-            task.set_sim_state(res["dpos"].astype(np.float32), res["dvel"].astype(np.float32), res["rb"].astype(np.float32))
-            task.post_physics_step()
+            list(pool.map(post, range(shards)))
             td = time.perf_counter()
             t_phys += tc - tb
             t_task += (tb - ta) + (td - tc)
         by_n[str(n)] = {"value": n * steps / (t_phys + t_task), "physics_env_steps_per_s": n * steps / t_phys, "task_ops_env_steps_per_s": n * steps / t_task,
-                        "physics_threads": th, "physics_env_steps_per_s_per_thread": n * steps / t_phys / th, "steps": steps,
+                        "physics_threads": th, "physics_env_steps_per_s_per_thread": n * steps / t_phys / th, "task_ops_threads": shards, "steps": steps,
                         "seconds": {"physics": t_phys, "task_ops": t_task}}
+    pool.shutdown()
     ref_ops = None
     try:  # the reference's OWN task code timed in the build container (tools/ref_cpu_baseline.py; the reference tree does not travel)
         r = json.load(open(os.path.join(REPO, "profiles", "r03_ref_cpu_task_ops.json")))
@@ -271,13 +324,18 @@ def cpu_baseline(sizes=((4, 32, 3.0), (1024, 8, 5.0), (8192, 3, 12.0)), sigma=0.
                    "envs": r["envs"], "ms_per_step": r["ms_per_step"], "source": "from_profiles: profiles/r03_ref_cpu_task_ops.json"}
     except Exception:
         pass
-    big = by_n[str(sizes[-1][0])]
-    return {"value": big["value"], "unit": "env-steps/s", "cores": threads, "kind": "port", "host": "%s, %d logical cores" % (host_cpu_model(), cores),
+    small, big = by_n[str(sizes[0][0])], by_n[str(sizes[-1][0])]
+    ratio = big["physics_env_steps_per_s_per_thread"] / small["physics_env_steps_per_s_per_thread"]
+    return {"value": big["value"], "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "host": "%s, %d logical CPUs, %s: %d threads used" % (host_cpu_model(), logical, "no cgroup CPU quota" if quota is None else "cgroup CPU quota %.1f" % quota, threads),
             "by_num_envs": by_n, "reference_task_ops": ref_ops, "oracle_build_flags": FAST_FLAGS,
             "physics_env_steps_per_s": big["physics_env_steps_per_s"], "physics_env_steps_per_s_per_core": big["physics_env_steps_per_s_per_thread"],
-            "task_ops_env_steps_per_s": big["task_ops_env_steps_per_s"], "task_ops_threads": 1,
-            "sample": "num_envs %s: %s control steps each (4 substeps, contacts on): C float64 dense oracle (%s), one batched OpenMP call per step on up to %d threads "
-                      "+ numpy task ops on 1 thread; value = the %d-env figure; NOT the reference's PhysX-CPU path (closed, absent)"
+            "task_ops_env_steps_per_s": big["task_ops_env_steps_per_s"], "task_ops_threads": big["task_ops_threads"],
+            # a harness check, not a property of the CPU: the per-thread physics rate must survive the batch size
+            "per_thread_rate_largest_over_smallest": ratio, "scaling_ok": bool(ratio >= 0.5),
+            "sample": "num_envs %s: %s control steps each (4 substeps, contacts on): C float64 dense oracle (%s), one batched OpenMP call per step on %d threads "
+                      "(= the CPUs the process may use at once: affinity capped by the cgroup quota) + numpy task ops sharded over the same threads; value = the %d-env "
+                      "figure; NOT the reference's PhysX-CPU path (closed, absent)"
                       % ("/".join(str(x[0]) for x in sizes), "/".join(str(by_n[str(x[0])]["steps"]) for x in sizes), FAST_FLAGS, threads, sizes[-1][0])}
 
 
