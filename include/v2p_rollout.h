@@ -145,6 +145,16 @@ int v2p_obs_imitation_packed(int64_t rows, int64_t steps, const float* obs /*[ro
 int v2p_policy_head(int64_t n, float* mu, const float* context_feat, int64_t ctx_frames, int64_t frame, const float* logstd /*[75]*/,
                     const float* noise, float* action, float* sigma, float* neglogp, void* stream);
 
+/* Bookkeeping of one rollout step after env.step (ImitatorAgent.play_steps, agents/im_agent.py:380-409) in one launch: rewards / dones /
+ * next_obses rows of the experience buffer, dones / terminate as floats, running episode returns and lengths, and the episode statistics
+ * the reference collects through .nonzero() on the host - here float64 device accumulators:
+ *   acc[0] += #episodes finished at this step, acc[1] += their returns, acc[2] += their lengths, acc[3] += #envs not done before the
+ *   step, acc[4] += their rewards; sub_acc[k] += their sub-rewards k.  prev_dones / cur_rewards / cur_lengths [n] are updated in place.
+ * obs [n,obs_dim] -> next_obs_row (nullable: no copy); rew [n], reset / terminate [n] int64, sub_rewards [n,4]; all DEVICE pointers. */
+int v2p_rollout_record(int64_t n, const float* obs, int64_t obs_dim, const float* rew, const int64_t* reset, const int64_t* terminate,
+                       const float* sub_rewards, float* next_obs_row, float* rewards_row, float* dones_row, float* dones, float* terminated,
+                       float* prev_dones, float* cur_rewards, float* cur_lengths, double* acc /*[>=5]*/, double* sub_acc /*[4]*/, void* stream);
+
 /* GAE reverse scan of the PPO rollout, CommonAgent.discount_values (learning/common_agent.py:423-435):
  * fdones [T,N], values / rewards / next_values / advs [T,N,1] (device). */
 int v2p_gae(int64_t horizon, int64_t n, const float* fdones, const float* values, const float* rewards, const float* next_values,

@@ -120,8 +120,65 @@ def test_one_critic_pass_per_step_beside_the_physics_is_bit_identical(lib):
     a, b, c = _rollout(lib, 192, 1, False), _rollout(lib, 192, 1, True, overlap=False), _rollout(lib, 192, 1, True, overlap=True)
     assert a["dones"].sum() > 0 and np.abs(a["values"]).max() > 0 and np.abs(a["next_values"]).max() > 0
     for k in a:
+        if k == "stats":  # (a: the torch bookkeeping, float32 sums; b, c: v2p_rollout_record, float64 block sums)
+            np.testing.assert_allclose(a[k], b[k], rtol=1e-6)
+            assert np.array_equal(b[k], c[k]) or np.allclose(b[k], c[k], rtol=1e-12)
+            continue
         assert np.array_equal(a[k], b[k]), k
         assert np.array_equal(a[k], c[k]), k
+
+
+def test_fused_step_record_equals_the_torch_bookkeeping(lib):
+    """v2p_rollout_record (one launch per step: buffer rows, dones / terminate as floats, episode returns / lengths, statistics) against
+    the ~25 torch ops it replaces, on the same rollout: buffer bit for bit, statistics to float32 summation order; and on random inputs
+    with an odd env count (scalar copy path, partial block)."""
+    from vid2player3d_amd import _lib as L
+    from vid2player3d_amd.ppo import PPOAgent
+
+    outs = []
+    for fused in (True, False):
+        orig = PPOAgent.__init__
+
+        def patched(self, *a, **kw):
+            orig(self, *a, **kw)
+            self.fused_record = fused
+        PPOAgent.__init__ = patched
+        try:
+            outs.append(_rollout(lib, 192, 1, True))
+        finally:
+            PPOAgent.__init__ = orig
+    a, b = outs
+    assert a["dones"].sum() > 0
+    for k in a:
+        if k == "stats":
+            np.testing.assert_allclose(a[k], b[k], rtol=1e-6)
+        else:
+            assert np.array_equal(a[k], b[k]), k
+    n, D = 1001, 461
+    g = torch.Generator(device=DEV)
+    g.manual_seed(4)
+    R = lambda *s: torch.rand(s, device=DEV, generator=g)  # noqa: E731
+    obs, rew, sub = R(n, D), R(n), R(n, 4)
+    reset, term = (R(n) < 0.3).long(), (R(n) < 0.1).long()
+    prev, cr, cl = (R(n) < 0.2).float(), R(n) * 5, torch.floor(R(n) * 20)
+    acc, sacc = torch.zeros(8, dtype=torch.float64, device=DEV), torch.zeros(4, dtype=torch.float64, device=DEV)
+    big = torch.zeros((3, n + 7, D), device=DEV)  # an odd row offset: the destination is not 16-byte aligned
+    row = big[1, 3:3 + n]
+    rr, dr, dn, tm = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV), torch.zeros((n, 1), device=DEV)
+    want_cr, want_cl = cr + rew, cl + 1
+    d = reset.float()
+    sd, alive = d * (1 - prev), 1 - prev
+    want_acc = [sd.double().sum(), (want_cr * sd).double().sum(), (want_cl * sd).double().sum(), alive.double().sum(), (rew * alive).double().sum()]
+    want_sub = (sub * alive[:, None]).double().sum(0)
+    L.check(L.load().v2p_rollout_record(n, L.ptr(obs), D, L.ptr(rew), L.ptr(reset), L.ptr(term), L.ptr(sub), L.ptr(row), L.ptr(rr), L.ptr(dr), L.ptr(dn), L.ptr(tm),
+                                        L.ptr(prev), L.ptr(cr), L.ptr(cl), L.ptr(acc), L.ptr(sacc), L.current_stream(torch.device(DEV))), "v2p_rollout_record")
+    torch.cuda.synchronize()
+    assert torch.equal(row, obs) and torch.equal(rr, rew) and torch.equal(dr, d) and torch.equal(dn, d) and torch.equal(tm[:, 0], term.float())
+    assert torch.equal(prev, d) and torch.equal(cr, want_cr) and torch.equal(cl, want_cl)
+    assert float(big[1, :3].abs().sum()) == 0 and float(big[1, 3 + n:].abs().sum()) == 0 and float(big[0].abs().sum()) == 0  # nothing beside the row
+    np.testing.assert_allclose(N(acc[:5]), [float(x) for x in want_acc], rtol=1e-12)
+    np.testing.assert_allclose(N(sacc), N(want_sub), rtol=1e-12)
+    assert float(acc[5:].abs().sum()) == 0
 
 
 def test_two_rollout_groups_fill_the_same_buffer(lib):

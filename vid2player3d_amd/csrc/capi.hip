@@ -323,6 +323,18 @@ int v2p_gae(int64_t horizon, int64_t n, const float* fdones, const float* values
     return launch_gae(horizon, n, fdones, values, rewards, next_values, gamma, tau, advs, (hipStream_t)stream);
 }
 
+int v2p_rollout_record(int64_t n, const float* obs, int64_t obs_dim, const float* rew, const int64_t* reset, const int64_t* terminate, const float* sub_rewards,
+                       float* next_obs_row, float* rewards_row, float* dones_row, float* dones, float* terminated, float* prev_dones, float* cur_rewards,
+                       float* cur_lengths, double* acc, double* sub_acc, void* stream) {
+    if (n < 0 || obs_dim < 0 || (n > 0 && (!rew || !reset || !terminate || !sub_rewards || !rewards_row || !dones_row || !dones || !terminated || !prev_dones ||
+                                           !cur_rewards || !cur_lengths || !acc || !sub_acc || (next_obs_row && !obs)))) {
+        set_error("v2p_rollout_record: bad argument");
+        return V2P_ERR_INVALID;
+    }
+    return launch_rollout_record(n, obs, obs_dim, rew, reset, terminate, sub_rewards, next_obs_row, rewards_row, dones_row, dones, terminated, prev_dones, cur_rewards,
+                                 cur_lengths, acc, sub_acc, (hipStream_t)stream);
+}
+
 int v2p_motion_tables_build(int64_t num_frames_total, int64_t num_clips, const double* local_rot, const double* root_trans, const int32_t* frame_clip,
                             const int64_t* clip_start, const int32_t* clip_frames, const double* clip_dt, const int32_t* parents, const double* local_pos,
                             int32_t per_clip_skeleton, float* gts, float* grs, float* lrs, float* grvs, float* gravs, float* dvs, void* stream) {

@@ -227,6 +227,81 @@ int launch_gae(int64_t horizon, int64_t n, const float* fdones, const float* val
 }
 
 // ------------------------------------------------------------------------------------------
+// Bookkeeping of one rollout step AFTER env.step (ImitatorAgent.play_steps, agents/im_agent.py:380-409): what the reference does with
+// ~25 small torch ops and two .nonzero() host syncs per step - rewards / dones / next_obses into the experience buffer, the dones and
+// terminate flags as floats, the running episode returns and lengths, and the episode statistics (here: device accumulators in float64)
+// - in ONE launch: workgroups [0, env_blocks) take 256 envs each (scalars + a block reduction -> 9 atomic adds), the rest stream the
+// observation rows into the buffer.
+//   dones = reset.float(); terminated = terminate.float(); cur_rewards += rew; cur_lengths += 1
+//   step_dones = dones (1 - prev_dones); alive_before = 1 - prev_dones
+//   acc[0] += sum step_dones; acc[1] += sum cur_rewards step_dones; acc[2] += sum cur_lengths step_dones; acc[3] += sum alive_before;
+//   acc[4] += sum rew alive_before; sub_acc[k] += sum sub_rewards[:, k] alive_before; prev_dones = dones
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rollout_record_kernel(int64_t n, int env_blocks, const float* __restrict__ obs, int64_t obs_dim, const float* __restrict__ rew,
+                                                             const int64_t* __restrict__ reset, const int64_t* __restrict__ terminate,
+                                                             const float* __restrict__ sub_rewards, float* __restrict__ next_obs_row,
+                                                             float* __restrict__ rewards_row, float* __restrict__ dones_row, float* __restrict__ dones,
+                                                             float* __restrict__ terminated, float* __restrict__ prev_dones, float* __restrict__ cur_rewards,
+                                                             float* __restrict__ cur_lengths, double* __restrict__ acc, double* __restrict__ sub_acc) {
+    if ((int)blockIdx.x >= env_blocks) {
+        // the observation rows: a flat, coalesced copy (16-byte pieces when both sides allow it)
+        const int64_t total = n * obs_dim, nb = gridDim.x - env_blocks, bi = blockIdx.x - env_blocks;
+        if ((((uintptr_t)obs | (uintptr_t)next_obs_row) & 15) == 0 && (total & 3) == 0) {
+            const float4* s4 = (const float4*)obs;
+            float4* d4 = (float4*)next_obs_row;
+            for (int64_t i = bi * 256 + threadIdx.x; i < total / 4; i += nb * 256) d4[i] = s4[i];
+        } else {
+            for (int64_t i = bi * 256 + threadIdx.x; i < total; i += nb * 256) next_obs_row[i] = obs[i];
+        }
+        return;
+    }
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (e < n) {
+        const float r = rew[e], d = (float)reset[e], pd = prev_dones[e];
+        const float cr = cur_rewards[e] + r, cl = cur_lengths[e] + 1.f;
+        const float sd = d * (1.f - pd), alive = 1.f - pd;
+        rewards_row[e] = r;
+        dones_row[e] = d;
+        dones[e] = d;
+        terminated[e] = (float)terminate[e];
+        cur_rewards[e] = cr;
+        cur_lengths[e] = cl;
+        prev_dones[e] = d;
+        v[0] = sd; v[1] = cr * sd; v[2] = cl * sd; v[3] = alive; v[4] = r * alive;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[5 + k] = sub_rewards[e * 4 + k] * alive;
+    }
+    __shared__ double red[4][9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
+    }
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 9; ++k) red[threadIdx.x >> 6][k] = v[k];
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        const double s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (threadIdx.x < 5) atomicAdd(acc + threadIdx.x, s);
+        else atomicAdd(sub_acc + (threadIdx.x - 5), s);
+    }
+}
+
+int launch_rollout_record(int64_t n, const float* obs, int64_t obs_dim, const float* rew, const int64_t* reset, const int64_t* terminate, const float* sub_rewards,
+                          float* next_obs_row, float* rewards_row, float* dones_row, float* dones, float* terminated, float* prev_dones, float* cur_rewards,
+                          float* cur_lengths, double* acc, double* sub_acc, hipStream_t s) {
+    if (n <= 0) return V2P_OK;
+    const int env_blocks = (int)((n + 255) / 256);
+    const int64_t total = n * obs_dim;
+    int copy_blocks = next_obs_row ? (int)((total / 4 + 1023) / 1024) : 0;  // ~4 float4 per thread
+    if (copy_blocks > 4096) copy_blocks = 4096;
+    hipLaunchKernelGGL(rollout_record_kernel, dim3(env_blocks + copy_blocks), dim3(256), 0, s, n, env_blocks, obs, obs_dim, rew, reset, terminate, sub_rewards,
+                       next_obs_row, rewards_row, dones_row, dones, terminated, prev_dones, cur_rewards, cur_lengths, acc, sub_acc);
+    return check_hip(hipGetLastError(), "rollout_record_kernel");
+}
+
+// ------------------------------------------------------------------------------------------
 // policy head of the rollout (models/im_network_builder.py:219-228 `eval_actor`: residual action, mu[:, :69] += the context's dof_pos of
 // step t; models/im_models.py:45-48: action = Normal(mu, sigma).sample(), neglogp): one wave per env, the 75 action components on lanes
 // k and k + 64, the two sums of neglogp as wave reductions.  `noise` is the standard-normal draw (torch's generator stays the source

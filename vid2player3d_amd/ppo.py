@@ -241,6 +241,7 @@ class PPOAgent(PolicyInference):
         self.grad_norm, self.truncate_grads = grad_norm, truncate_grads
         self.normalize_value, self.normalize_advantage = normalize_value, normalize_advantage
         self.reuse_next_values, self.overlap_critic = reuse_next_values, overlap_critic
+        self.fused_record = True  # (tests switch it off to compare the launch with the torch statement of the same bookkeeping)
         # cfg `mixed_precision` (amass_im.yaml: False): the reference wraps the forward pass and the losses of calc_gradients in
         # torch.cuda.amp.autocast and scales the loss (im_agent.py:509, 548-563); the rollout stays float32 there as well
         self.mixed_precision = bool(mixed_precision)
@@ -378,6 +379,12 @@ class PPOAgent(PolicyInference):
             start.record(main)
         cuda = self.device.type == "cuda"
         overlap = self.overlap_critic and self.reuse_next_values and cuda
+        # the after-step bookkeeping as one HIP launch (device tensors, the default rollout); the torch statement of it below stays for CPU
+        # tensors (the gloo tests' stub tasks) and for the reference's two-critic-passes variant, and is what the kernel is tested against
+        fused = cuda and self.reuse_next_values and self.fused_record and all(hasattr(g.task, "extras") and g.task.obs_buf.is_contiguous() for g in self.groups)
+        if fused:
+            for s in st:
+                s["sub"] = torch.zeros(4, dtype=torch.float64, device=self.device)
 
         def on(g):
             return torch.cuda.stream(g.stream) if multi else _NullCtx()
@@ -433,6 +440,20 @@ class PPOAgent(PolicyInference):
                         critic_of(g, s, s["feat"], n, s["term"])
                     task.step(res["actions"])  # masks the rows of finished envs in place, like the reference
                     obs, rewards = task.obs_buf, task.rew_buf
+                    if fused:
+                        # rewards / next_obses / dones rows, dones and terminate as floats, episode returns / lengths and the statistics
+                        # below: ONE launch (v2p_rollout_record) instead of ~25 elementwise / reduction kernels per step
+                        terminated = torch.empty((task.num_envs, 1), device=self.device)
+                        td = buf.tensor_dict
+                        _lib.check(self._lib.v2p_rollout_record(
+                            task.num_envs, _lib.ptr(obs), obs.shape[1], _lib.ptr(rewards), _lib.ptr(task.reset_buf), _lib.ptr(task.extras["terminate"]),
+                            _lib.ptr(task.extras["sub_rewards"]), _lib.ptr(td["next_obses"][n, sl]), _lib.ptr(td["rewards"][n, sl]), _lib.ptr(td["dones"][n, sl]),
+                            _lib.ptr(self.dones[sl]), _lib.ptr(terminated), _lib.ptr(s["prev_dones"]), _lib.ptr(self.current_rewards[sl]),
+                            _lib.ptr(self.current_lengths[sl]), _lib.ptr(s["acc"]), _lib.ptr(s["sub"]), _lib.current_stream(self.device)), "v2p_rollout_record")
+                        s["feat"], s["term"] = self._features(task, obs, n + 1), terminated
+                        if n == T - 1:
+                            critic_of(g, s, s["feat"], T, terminated)
+                        continue
                     dones = task.reset_buf.float()
                     self.dones[sl] = dones
                     buf.update_data("rewards", n, rewards, sl)  # rewards_shaper scale_value 1
