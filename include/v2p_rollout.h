@@ -145,6 +145,13 @@ int v2p_obs_imitation_packed(int64_t rows, int64_t steps, const float* obs /*[ro
 int v2p_policy_head(int64_t n, float* mu, const float* context_feat, int64_t ctx_frames, int64_t frame, const float* logstd /*[75]*/,
                     const float* noise, float* action, float* sigma, float* neglogp, void* stream);
 
+/* v2p_policy_head with the experience buffer's rows as additional destinations (the rollout: ExperienceBuffer.update_data of actions / mus /
+ * sigmas / neglogpacs, im_agent.py:348-352, without the four copy kernels): sigma_row [n,75] and neglogp_row [n] are written in place of
+ * `sigma` / `neglogp`, action_row / mu_row [n,75] (nullable) receive copies of `action` / the residual mean.  `action` stays a tensor of
+ * its own - env.step masks the rows of finished envs in place, the buffer keeps the sampled actions. */
+int v2p_policy_head_record(int64_t n, float* mu, const float* context_feat, int64_t ctx_frames, int64_t frame, const float* logstd,
+                           const float* noise, float* action, float* sigma_row, float* neglogp_row, float* action_row, float* mu_row, void* stream);
+
 /* Bookkeeping of one rollout step after env.step (ImitatorAgent.play_steps, agents/im_agent.py:380-409) in one launch: rewards / dones /
  * next_obses rows of the experience buffer, dones / terminate as floats, running episode returns and lengths, and the episode statistics
  * the reference collects through .nonzero() on the host - here float64 device accumulators:

@@ -317,6 +317,15 @@ int v2p_policy_head(int64_t n, float* mu, const float* context_feat, int64_t ctx
     return launch_policy_head(n, mu, context_feat, ctx_frames, frame, logstd, noise, action, sigma, neglogp, (hipStream_t)stream);
 }
 
+int v2p_policy_head_record(int64_t n, float* mu, const float* context_feat, int64_t ctx_frames, int64_t frame, const float* logstd, const float* noise,
+                           float* action, float* sigma_row, float* neglogp_row, float* action_row, float* mu_row, void* stream) {
+    if (n < 0 || !mu || !context_feat || !logstd || !noise || !action || !neglogp_row || frame < 0 || frame >= ctx_frames) {
+        set_error("v2p_policy_head_record: bad argument");
+        return V2P_ERR_INVALID;
+    }
+    return launch_policy_head(n, mu, context_feat, ctx_frames, frame, logstd, noise, action, sigma_row, neglogp_row, (hipStream_t)stream, action_row, mu_row);
+}
+
 int v2p_gae(int64_t horizon, int64_t n, const float* fdones, const float* values, const float* rewards, const float* next_values, float gamma,
             float tau, float* advs, void* stream) {
     if (horizon < 0 || n < 0) { set_error("v2p_gae: bad argument"); return V2P_ERR_INVALID; }

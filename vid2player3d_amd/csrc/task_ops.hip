@@ -309,7 +309,8 @@ int launch_rollout_record(int64_t n, const float* obs, int64_t obs_dim, const fl
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void policy_head_kernel(int64_t n, float* __restrict__ mu, const float* __restrict__ context_feat, int64_t ctx_frames,
                                                           int64_t frame, const float* __restrict__ logstd, const float* __restrict__ noise,
-                                                          float* __restrict__ action, float* __restrict__ sigma_out, float* __restrict__ neglogp) {
+                                                          float* __restrict__ action, float* __restrict__ sigma_out, float* __restrict__ neglogp,
+                                                          float* __restrict__ action_row, float* __restrict__ mu_row) {
     const int lane = threadIdx.x & 63;
     const int64_t e = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (e >= n) return;
@@ -328,6 +329,10 @@ __global__ __launch_bounds__(256) void policy_head_kernel(int64_t n, float* __re
             mu[i] = m;
             action[i] = a;
             if (sigma_out) sigma_out[i] = sg;
+            // (the experience buffer's rows, written here instead of by copy kernels behind this one; `action` stays a tensor of its own:
+            // env.step masks it in place)
+            if (action_row) action_row[i] = a;
+            if (mu_row) mu_row[i] = m;
             quad += z * z;
             lsum += ls;
         }
@@ -338,10 +343,10 @@ __global__ __launch_bounds__(256) void policy_head_kernel(int64_t n, float* __re
 }
 
 int launch_policy_head(int64_t n, float* mu, const float* context_feat, int64_t ctx_frames, int64_t frame, const float* logstd, const float* noise,
-                       float* action, float* sigma_out, float* neglogp, hipStream_t s) {
+                       float* action, float* sigma_out, float* neglogp, hipStream_t s, float* action_row, float* mu_row) {
     if (n <= 0) return V2P_OK;
     hipLaunchKernelGGL(policy_head_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, n, mu, context_feat, ctx_frames, frame, logstd, noise, action,
-                       sigma_out, neglogp);
+                       sigma_out, neglogp, action_row, mu_row);
     return check_hip(hipGetLastError(), "policy_head_kernel");
 }
 

@@ -218,7 +218,7 @@ int launch_obs_imitation(int64_t n, const float* body_pos, const float* body_rot
 int launch_obs_imitation_packed(int64_t rows, int64_t steps, const float* obs461, const float* context_feat, int64_t ctx_frames, int64_t first_frame,
                                 const float* nmean, const float* nstd, float nclip, float* obs, hipStream_t s);
 int launch_policy_head(int64_t n, float* mu, const float* context_feat, int64_t ctx_frames, int64_t frame, const float* logstd, const float* noise,
-                       float* action, float* sigma_out, float* neglogp, hipStream_t s);
+                       float* action, float* sigma_out, float* neglogp, hipStream_t s, float* action_row = nullptr, float* mu_row = nullptr);
 int launch_gae(int64_t horizon, int64_t n, const float* fdones, const float* values, const float* rewards, const float* next_values, float gamma,
                float tau, float* advs, hipStream_t s);
 int launch_motion_tables_build(int64_t F, const double* lrot, const double* root_trans, const int32_t* frame_clip, const int64_t* clip_start,
