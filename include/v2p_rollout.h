@@ -41,7 +41,8 @@ typedef enum {
     V2P_ERR_INVALID = -1,     /* bad argument */
     V2P_ERR_UNSUPPORTED = -2, /* valid in the reference, not built yet (e.g. anisotropic joint gains) */
     V2P_ERR_HIP = -3,         /* HIP runtime error */
-    V2P_ERR_NOMEM = -4
+    V2P_ERR_NOMEM = -4,
+    V2P_ERR_INTERNAL = -5     /* the engine noticed that a launch did not do all it should have (v2p_env_check: skipped substep jobs) */
 } v2p_status;
 
 typedef struct v2p_model v2p_model; /* body model (host copy + device constants) */
@@ -434,10 +435,15 @@ int v2p_env_profile_end(v2p_env* e, double* physics_ms_total, int64_t* launches)
  * numbered the way workgroups are dispatched).  v2p_env_check synchronises `stream` and fetches the counter; v2p_env_check_async (ABI 9)
  * enqueues the fetch behind the work already on `stream` and picks up what the previous call's fetch brought back, without waiting (one
  * call per epoch: HumanoidSMPLIM.reset of all envs makes it); v2p_env_job_recoveries returns the count as last fetched (total since
- * the batch was created). */
+ * the batch was created).
+ * A recovery loses time only.  One consequence of it can lose DATA: when the late predecessor finally starts after the whole step of its pair
+ * is complete, it must not run (its inputs are the next step's) and is skipped - and what only that job publishes (the exposed PD targets,
+ * the in-place masking of dead envs' actions, the ball's per-simulate() records) is then missing for that step.  Such skips are counted
+ * too (v2p_env_jobs_skipped, ABI 13); v2p_env_check returns V2P_ERR_INTERNAL the first time it sees new ones. */
 int v2p_env_check(v2p_env* e, void* stream);
 int v2p_env_check_async(v2p_env* e, void* stream);
 int v2p_env_job_recoveries(v2p_env* e, int64_t* count);
+int v2p_env_jobs_skipped(v2p_env* e, int64_t* count);
 
 const char* v2p_last_error(void);
 int v2p_abi_version(void);

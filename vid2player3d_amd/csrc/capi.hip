@@ -718,9 +718,18 @@ int v2p_env_check(v2p_env* e, void* stream) {
     DeviceGuard g(e->device);
     int rc = check_hip(hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize");
     if (rc != V2P_OK || !e->job_progress) return rc;
-    int32_t count = 0;
-    rc = check_hip(hipMemcpy(&count, e->job_progress + v2p::job_wave_slots(e->n), sizeof(count), hipMemcpyDeviceToHost), "hipMemcpy(job recovery counter)");
-    if (rc == V2P_OK) e->job_recoveries = count;
+    int32_t count[2] = {0, 0};
+    rc = check_hip(hipMemcpy(count, e->job_progress + v2p::job_wave_slots(e->n), sizeof(count), hipMemcpyDeviceToHost), "hipMemcpy(job recovery counters)");
+    if (rc == V2P_OK) { e->job_recoveries = count[0]; e->jobs_skipped = count[1]; }
+    if (rc == V2P_OK && e->jobs_skipped > e->jobs_skipped_reported) {
+        // a late job of a cut pair found its step complete and did not run: its substeps were replayed by its successors (results are the
+        // same bits), but what only IT publishes - exposed PD targets, the in-place masking of dead envs' actions, the ball's per-call
+        // records - is missing for that step
+        set_error("v2p_env_check: %lld substep job(s) started after their env pair's step was complete and were skipped: the per-call records they own were not "
+                  "published for those steps (dispatch far out of order; v2p_sim_cfg.substep_jobs = 0 avoids it)", (long long)(e->jobs_skipped - e->jobs_skipped_reported));
+        e->jobs_skipped_reported = e->jobs_skipped;
+        return V2P_ERR_INTERNAL;
+    }
     return rc;
 }
 
@@ -730,7 +739,7 @@ int v2p_env_check_async(v2p_env* e, void* stream) {
     DeviceGuard g(e->device);
     int rc = V2P_OK;
     if (!e->err_host) {
-        rc = check_hip(hipHostMalloc((void**)&e->err_host, sizeof(int32_t), hipHostMallocDefault), "hipHostMalloc(job recovery counter)");
+        rc = check_hip(hipHostMalloc((void**)&e->err_host, 2 * sizeof(int32_t), hipHostMallocDefault), "hipHostMalloc(job recovery counter)");
         if (rc == V2P_OK) {
             rc = check_hip(hipEventCreateWithFlags(&e->err_event, hipEventDisableTiming), "hipEventCreate(job recovery counter)");
             if (rc != V2P_OK) { (void)hipHostFree(e->err_host); e->err_host = nullptr; }  // (no half-built pair: a later call starts over)
@@ -738,13 +747,14 @@ int v2p_env_check_async(v2p_env* e, void* stream) {
             e->err_host = nullptr;
         }
         if (rc != V2P_OK) return rc;
-        *e->err_host = 0;
+        e->err_host[0] = e->err_host[1] = 0;
     } else if (e->err_pending && hipEventQuery(e->err_event) == hipSuccess) {
         e->err_pending = 0;
-        e->job_recoveries = *e->err_host;
+        e->job_recoveries = e->err_host[0];
+        e->jobs_skipped = e->err_host[1];
     }
     if (!e->err_pending) {  // fetch the counter as it stands behind everything enqueued so far; looked at by the next call
-        rc = check_hip(hipMemcpyAsync(e->err_host, e->job_progress + v2p::job_wave_slots(e->n), sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream),
+        rc = check_hip(hipMemcpyAsync(e->err_host, e->job_progress + v2p::job_wave_slots(e->n), 2 * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream),
                        "hipMemcpyAsync(job recovery counter)");
         if (rc == V2P_OK) rc = check_hip(hipEventRecord(e->err_event, (hipStream_t)stream), "hipEventRecord(job recovery counter)");
         if (rc == V2P_OK) e->err_pending = 1;
@@ -755,6 +765,12 @@ int v2p_env_check_async(v2p_env* e, void* stream) {
 int v2p_env_job_recoveries(v2p_env* e, int64_t* count) {
     if (!e || !count) { set_error("v2p_env_job_recoveries: bad argument"); return V2P_ERR_INVALID; }
     *count = e->job_recoveries;
+    return V2P_OK;
+}
+
+int v2p_env_jobs_skipped(v2p_env* e, int64_t* count) {
+    if (!e || !count) { set_error("v2p_env_jobs_skipped: bad argument"); return V2P_ERR_INVALID; }
+    *count = e->jobs_skipped;
     return V2P_OK;
 }
 

@@ -418,7 +418,12 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
     if constexpr (JOBS) if (!mono) {
         int done = 0;
         if (lane == 0) done = (handed && V2P_LL_FAST_HANDOVER != 0 ? poll0 : __hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) >= a.job_epoch * (a.p.nsub + 1) + a.p.nsub;
-        if (__builtin_amdgcn_readfirstlane(done)) return;
+        if (__builtin_amdgcn_readfirstlane(done)) {
+            // (counted: what this job owns besides its substeps - the exposed PD targets, the in-place action masking, the ball's per-call
+            // records - was published by nobody for that step; v2p_env_check reports it as an error, not as lost time)
+            if (lane == 0 && half == 0) __hip_atomic_fetch_add(a.job_progress + a.job_blocks * LL_WPB + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
     }
     auto wait_for_predecessor = [&]() {
     if constexpr (JOBS) if (handed) {

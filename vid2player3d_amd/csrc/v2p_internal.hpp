@@ -161,6 +161,8 @@ struct v2p_env {
     int counted_resident;     // this batch is in the device's resident-env count
     int job_lead;             // substeps of the FIRST job of a cut pair (0 = like the others, -1 = the engine decides)
     int64_t job_recoveries;   // jobs that gave up waiting and recomputed, as last fetched (v2p_env_check / _check_async)
+    int64_t jobs_skipped;     // late jobs that found their pair's step complete and did not run (their per-call records are missing for that step)
+    int64_t jobs_skipped_reported;
     int job_epoch;
     int pair_mix_permille;    // share of the envs (the heaviest) that are paired with the lightest ones instead of with each other
     int pair_mix_default;     // pair_mix_permille was left to the engine (-1)

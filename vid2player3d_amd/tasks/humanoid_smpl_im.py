@@ -745,7 +745,19 @@ class HumanoidSMPLIM:
         _lib.check(self._lib.v2p_env_job_recoveries(self._h_env, C.byref(n)), "v2p_env_job_recoveries")
         return int(n.value)
 
+    def jobs_skipped(self):
+        """Late substep jobs that found their pair's step complete and were skipped (as last fetched): the per-call records those jobs own
+        were not published for that step.  Never observed; check() raises on it, the per-epoch reset() too."""
+        n = C.c_int64(0)
+        _lib.check(self._lib.v2p_env_jobs_skipped(self._h_env, C.byref(n)), "v2p_env_jobs_skipped")
+        return int(n.value)
+
     def _warn_job_recoveries(self):
+        k = self.jobs_skipped()
+        if k > getattr(self, "_jobs_skipped_seen", 0):
+            self._jobs_skipped_seen = k
+            raise RuntimeError("%d substep job(s) of the physics launches started after their env pair's step was complete and were skipped: exposed PD targets, "
+                               "in-place action masking and the ball's per-call records of those steps are missing (cfg env substep_jobs=False avoids it)" % k)
         n = self.job_recoveries()
         if n > getattr(self, "_job_recoveries_seen", 0):
             import warnings
