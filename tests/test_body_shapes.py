@@ -93,3 +93,77 @@ def test_batched_family_equals_the_shape_by_shape_one():
     assert all(np.array_equal(c[2], o[0]) for c, o in zip(clouds, one)) and np.array_equal(rest[2], rest1[0])
     tabs, off = bs.reduce_direction_tables(64)
     assert list(np.diff(off)) == [256, 204, 163, 130, 104, 83, 66, 52] and tabs.shape == (off[-1], 3)
+
+
+def synthetic_smpl_model(base, seed=0):
+    """A model file of the SMPL FORMAT (v_template, shapedirs, J_regressor, weights) built from the baked body: its hull vertices placed at
+    the rest joints are the skin, every vertex weighted 0.7 / 0.3 to its body's joint / the parent's; row j of the joint regressor is the
+    minimum-norm affine combination of body j's vertices that gives its rest joint exactly; shape direction 0 = uniform growth by 5 % per
+    unit, directions 1 .. 9 random."""
+    clouds, rest = bs.clouds_of(base)
+    names = list(base.body_names)
+    vt, owner, span = [], [], {}
+    for b, c in enumerate(clouds):
+        j = bs.SMPL_JOINT_NAMES.index(names[b])
+        span[j] = (len(owner), len(owner) + len(c))
+        vt.append(c + rest[b])
+        owner += [j] * len(c)
+    vt, owner = np.concatenate(vt), np.array(owner)
+    V = len(vt)
+    w = np.zeros((V, 24))
+    for j, n in enumerate(bs.SMPL_JOINT_NAMES):
+        p = base.parents[names.index(n)]
+        pj = bs.SMPL_JOINT_NAMES.index(names[p]) if p >= 0 else j
+        a, e = span[j]
+        w[a:e, j] += 0.7
+        w[a:e, pj] += 0.3
+    jr = np.zeros((24, V))
+    for j, n in enumerate(bs.SMPL_JOINT_NAMES):
+        a, e = span[j]
+        A = np.concatenate([vt[a:e].T, np.ones((1, e - a))])                 # 4 equations: sum c v = joint, sum c = 1
+        jr[j, a:e] = np.linalg.lstsq(A, np.concatenate([rest[names.index(n)], [1.0]]), rcond=None)[0]
+    rng = np.random.default_rng(seed)
+    sd = rng.normal(0, 0.004, size=(V, 3, 10))
+    sd[:, :, 0] = 0.05 * vt
+    return {"v_template": vt, "shapedirs": sd, "J_regressor": jr, "weights": w}
+
+
+def test_smpl_betas_to_bodies(tmp_path):
+    """SMPL(betas) -> vertex clouds -> bodies (smpl_parser.get_mesh_offsets + get_joint_geometries of the reference; the licensed model file
+    is absent: a synthetic file of the same format).  betas = 0 gives back the body the file was built from; the first shape direction of
+    this file is uniform growth, so betas = (2, 0, ...) must give the body uniformly scaled by 1.1; other directions deform it; the file
+    round-trips through .npz and through a plain pickle (and a pickle that smuggles a callable in is refused)."""
+    import pickle
+
+    base = load_baked_model()
+    smpl = synthetic_smpl_model(base)
+    np.savez(tmp_path / "m.npz", **smpl)
+    loaded = bs.load_smpl_model(str(tmp_path / "m.npz"))
+    assert all(np.array_equal(loaded[k], smpl[k]) for k in smpl)
+    with open(tmp_path / "m.pkl", "wb") as f:
+        pickle.dump({k: v for k, v in smpl.items()}, f, protocol=2)
+    assert np.array_equal(bs.load_smpl_model(str(tmp_path / "m.pkl"))["weights"], smpl["weights"])
+    with open(tmp_path / "evil.pkl", "wb") as f:
+        pickle.dump({"v_template": print}, f)
+    with pytest.raises(pickle.UnpicklingError):
+        bs.load_smpl_model(str(tmp_path / "evil.pkl"))
+
+    betas = np.zeros((3, 10))
+    betas[1, 0] = 2.0
+    betas[2, 1:] = np.random.default_rng(1).normal(0, 1.0, size=9)
+    same, grown, other = bs.bodies_from_smpl(smpl, betas, base)
+    assert np.allclose(same.local_pos, base.local_pos, atol=1e-10) and np.array_equal(same.hull_offsets, base.hull_offsets)
+    assert abs(same.total_mass / base.total_mass - 1.0) < 1e-6 and np.allclose(same.com, base.com, atol=1e-6)
+    want = base.scaled(1.1)
+    assert np.allclose(grown.local_pos, want.local_pos, atol=1e-10) and np.allclose(grown.mass, want.mass, rtol=1e-6)
+    assert np.allclose(grown.inertia, want.inertia, rtol=1e-5, atol=1e-10) and np.allclose(grown.kp, want.kp, rtol=1e-6)
+    assert abs(other.total_mass / base.total_mass - 1.0) > 1e-3 and not np.allclose(other.local_pos, base.local_pos, atol=1e-4)
+    assert np.all(np.linalg.eigvalsh(other.inertia) > 0) and np.diff(other.hull_offsets).max() <= 64
+    # the options of get_mesh_offsets: a global scale, flat feet (the lowest centimetre of the skin levelled)
+    c0, r0 = bs.smpl_clouds(smpl, betas[:1], base)
+    c1, r1 = bs.smpl_clouds(smpl, betas[:1], base, scale=1.2)
+    assert np.allclose(r1, 1.2 * r0) and all(np.allclose(a, 1.2 * b) for a, b in zip(c1, c0))
+    c2, _ = bs.smpl_clouds(smpl, betas[:1], base, flatfoot=True)
+    toe = base.body_index("L_Toe")
+    low0, low2 = np.sort(c0[toe][0][:, 1])[:3], np.sort(c2[toe][0][:, 1])[:3]
+    assert low2.min() >= low0.min() - 1e-12 and np.ptp(low2[:2]) <= np.ptp(low0[:2]) + 1e-12

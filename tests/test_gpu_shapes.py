@@ -112,3 +112,18 @@ def test_2048_shapes_compile_in_seconds():
     assert masses.min() > 30 and masses.max() < 200 and np.all([np.diff(m.hull_offsets).max() <= 64 for m in fam[::97]])
     for s in (0, 1023, 2047):  # spot checks against the numpy statement
         _same_body(fam[s], bs.body_from_clouds(base, [c[s] for c in clouds], rest[s]), "shape %d of 2048" % s)
+
+
+def test_smpl_betas_to_bodies_on_the_device():
+    """bodies_from_smpl with a device: the clouds of a batch of betas through v2p_shapes_compile == the numpy path, shape by shape."""
+    from tests.test_body_shapes import synthetic_smpl_model
+
+    base = load_baked_model()
+    smpl = synthetic_smpl_model(base)
+    betas = np.random.default_rng(2).normal(0, 1.0, size=(6, 10))
+    betas[0] = 0.0
+    got = bs.bodies_from_smpl(smpl, betas, base, device=DEV)
+    want = bs.bodies_from_smpl(smpl, betas, base)
+    for s in range(6):
+        _same_body(got[s], want[s], "betas %d" % s)
+    assert abs(got[0].total_mass / base.total_mass - 1.0) < 1e-6

@@ -328,3 +328,84 @@ def bodies_from_clouds_device(base, clouds, rest_joints, device, density=GEOM_DE
         blob.update(local_pos=local_pos[s], mass=r["mass"][j0:j0 + nb], com=r["com"][j0:j0 + nb], inertia=r["inertia"][j0:j0 + nb], hull_offsets=off, hull_verts=hv)
         out.append(BodyModel(blob, **model_kw))
     return out
+
+
+# ---- SMPL(betas) -> per-body vertex clouds -----------------------------------------------------------------------------------------------
+# What the reference does per clip before the hulls (uhc/smpllib/smpl_local_robot.py:1232-1251 -> smpl_parser.py:413-458 `get_mesh_offsets`,
+# then `get_joint_geometries`, smpl_local_robot.py:79-101): the SMPL body of the clip's betas in the ZERO pose - vertices = v_template +
+# shapedirs . betas (pose blend shapes and skinning vanish at zero pose), joints = J_regressor . vertices - and every vertex handed to the
+# joint with the largest skinning weight, relative to that joint.  The SMPL model FILE is licensed and not shipped; this is the code that
+# consumes it (any container of its four standard arrays), tested on a synthetic model of the same format (tests/test_body_shapes.py).
+SMPL_JOINT_NAMES = ("Pelvis", "L_Hip", "R_Hip", "Torso", "L_Knee", "R_Knee", "Spine", "L_Ankle", "R_Ankle", "Chest", "L_Toe", "R_Toe", "Neck",
+                    "L_Thorax", "R_Thorax", "Head", "L_Shoulder", "R_Shoulder", "L_Elbow", "R_Elbow", "L_Wrist", "R_Wrist", "L_Hand", "R_Hand")  # smpl_parser.py:10-35
+
+
+def load_smpl_model(path):
+    """{v_template [V,3], shapedirs [V,3,K], J_regressor [24+,V], weights [V,24]} from an .npz, or from a pickle of plain numpy /
+    scipy-sparse arrays (the SMPL release's .pkl with its chumpy objects converted: `np.array(x)`); read through the restricted unpickler."""
+    if str(path).endswith(".npz"):
+        with np.load(path, allow_pickle=False) as z:
+            d = {k: z[k] for k in z.files}
+    else:
+        import pickle
+
+        allowed = {("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"), ("numpy", "ndarray"), ("numpy", "dtype"),
+                   ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"), ("scipy.sparse.csc", "csc_matrix"),
+                   ("scipy.sparse._csc", "csc_matrix"), ("scipy.sparse.csr", "csr_matrix"), ("scipy.sparse._csr", "csr_matrix"),
+                   ("_codecs", "encode")}  # (protocol-2 numpy pickles carry their bytes as a latin-1 string + _codecs.encode)
+
+        class _Plain(pickle.Unpickler):  # arrays and sparse matrices only: a model file from the internet cannot run code
+            def find_class(self, module, name):
+                if (module, name) in allowed:
+                    return super().find_class(module, name)
+                raise pickle.UnpicklingError("SMPL model file: refusing to unpickle %s.%s (convert chumpy objects with np.array first)" % (module, name))
+
+        with open(path, "rb") as f:
+            d = _Plain(f, encoding="latin1").load()
+    out = {}
+    for k in ("v_template", "shapedirs", "J_regressor", "weights"):
+        if k not in d:
+            raise KeyError("%s: not an SMPL model (no %r)" % (path, k))
+        v = d[k]
+        out[k] = np.asarray(v.toarray() if hasattr(v, "toarray") else v, dtype=np.float64)
+    return out
+
+
+def smpl_clouds(smpl, betas, base, scale=None, flatfoot=False, joint_names=SMPL_JOINT_NAMES):
+    """Per-body vertex clouds (body-joint frames) and rest joints of S SMPL shapes, in `base`'s MJCF body order: betas [S,K] ->
+    (list over the 24 bodies of [S, n_b, 3], rest joints [S, 24, 3]).  scale [S] / flatfoot: the options of get_mesh_offsets
+    (smpl_parser.py:424-429)."""
+    betas = np.atleast_2d(np.asarray(betas, dtype=np.float64))
+    S, K = betas.shape
+    vt, sd, jr, w = smpl["v_template"], smpl["shapedirs"], smpl["J_regressor"], smpl["weights"]
+    if sd.shape[2] < K or w.shape[1] < len(joint_names) or jr.shape[0] < len(joint_names):
+        raise ValueError("SMPL model with %d shape directions / %d joints; need %d / %d" % (sd.shape[2], w.shape[1], K, len(joint_names)))
+    verts = vt[None] + np.einsum("vck,sk->svc", sd[:, :, :K], betas)          # [S,V,3]
+    joints = np.einsum("jv,svc->sjc", jr[:len(joint_names)], verts)           # (from the un-flattened vertices, like the reference)
+    if scale is not None:
+        sc = np.broadcast_to(np.asarray(scale, dtype=np.float64), (S,))
+        verts, joints = verts * sc[:, None, None], joints * sc[:, None, None]
+    if flatfoot:
+        for s in range(S):
+            feet = verts[s, :, 1] < verts[s, :, 1].min() + 0.01
+            verts[s, feet, 1] = verts[s, feet, 1].mean()
+    owner = w[:, :len(joint_names)].argmax(axis=1)                            # vertex -> SMPL joint (skin_weights.argmax, smpl_local_robot.py:91)
+    names = list(base.body_names)
+    clouds, rest = [], np.zeros((S, len(names), 3))
+    for b, name in enumerate(names):
+        j = joint_names.index(name)
+        vind = np.nonzero(owner == j)[0]
+        if len(vind) < 4:
+            raise ValueError("SMPL joint %s owns %d vertices: no hull" % (name, len(vind)))
+        clouds.append(verts[:, vind] - joints[:, j:j + 1])
+        rest[:, b] = joints[:, j]
+    return clouds, rest
+
+
+def bodies_from_smpl(smpl, betas, base, device=None, scale=None, flatfoot=False, **model_kw):
+    """One BodyModel per row of `betas`: the per-clip humanoid assets of the reference (humanoid_smpl_im.py:255-296), without the MJCF / STL
+    files in between.  device = a torch cuda device: all hulls in one launch of v2p_shapes_compile."""
+    clouds, rest = smpl_clouds(smpl, betas, base, scale, flatfoot)
+    if device is not None:
+        return bodies_from_clouds_device(base, clouds, rest, device, **model_kw)
+    return [body_from_clouds(base, [c[s] for c in clouds], rest[s], **model_kw) for s in range(len(rest))]

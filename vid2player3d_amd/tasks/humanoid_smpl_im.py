@@ -128,8 +128,9 @@ def default_cfg(num_envs=8192, **env_overrides):
 
 
 # uhc/smpllib/smpl_parser.py:10-35: the SMPL joints in SMPL order, by the names the MJCF bodies carry
-SMPL_BONE_ORDER_NAMES = ["Pelvis", "L_Hip", "R_Hip", "Torso", "L_Knee", "R_Knee", "Spine", "L_Ankle", "R_Ankle", "Chest", "L_Toe", "R_Toe", "Neck",
-                         "L_Thorax", "R_Thorax", "Head", "L_Shoulder", "R_Shoulder", "L_Elbow", "R_Elbow", "L_Wrist", "R_Wrist", "L_Hand", "R_Hand"]
+from ..body_shapes import SMPL_JOINT_NAMES as _SMPL_JOINT_NAMES  # noqa: E402
+
+SMPL_BONE_ORDER_NAMES = list(_SMPL_JOINT_NAMES)
 
 
 class HumanoidSMPLIM:
