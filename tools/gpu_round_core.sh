@@ -34,4 +34,14 @@ V2P_DEBUG=1 V2P_PHASE_TIMING=1 timeout 300 python bench.py --steps 64 --warmup 0
 timeout 900 python tools/parity_sweep.py 2048 > $O/parity_sweep.log 2>&1
 timeout 600 python tools/soak.py 4000 2>&1 | tail -3 > $O/soak.log
 timeout 600 python tools/soak.py 4000 racket 2>&1 | tail -3 > $O/soak_racket_ball.log
+# round 5: two processes on one GPU, the rollout's kernel budget, per-clip shapes at scale (own script), MFMA microbenchmark, host CPU scaling
+timeout 900 python tools/soak2.py 2000 > $O/soak_two_processes.log 2>&1
+timeout 300 python tools/play_profile.py 4 > $O/play_wall.log 2>&1
+rm -rf $O/prof && mkdir -p $O/prof
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o play -- python $R/tools/play_profile.py 4 > $O/play_rocprof.log 2>&1)
+python $R/tools/play_summary.py $O/prof/play_results.db 5 > $O/play_steps_kernels.txt 2>&1
+rm -rf $O/prof
+[ -x $R/tools/ubench/mfma_congruence ] && $R/tools/ubench/mfma_congruence > $O/mfma_congruence.txt 2>&1
+timeout 300 python tools/cpu_scaling_probe.py 4096 > $O/cpu_scaling_default.txt 2>&1
+# (bash tools/shapes_scale.sh: bench + rocprofv3 + PMC at 1 / 64 / 2048 / 8192 body shapes -> gpurun_out/shapes/)
 tail -3 $O/pytest_gpu.log; tail -2 $O/smoke.log; tail -1 $O/bench.log | cut -c1-700; cut -c1-220 $O/bench_variants.log; tail -1 $O/bench_ppo.log | cut -c1-300; head -5 $O/rocprof_stats_default_cmd.txt; tail -3 $O/parity_sweep.log; cat $O/soak.log
