@@ -153,6 +153,13 @@ int v2p_policy_head(int64_t n, float* mu, const float* context_feat, int64_t ctx
 int v2p_policy_head_record(int64_t n, float* mu, const float* context_feat, int64_t ctx_frames, int64_t frame, const float* logstd,
                            const float* noise, float* action, float* sigma_row, float* neglogp_row, float* action_row, float* mu_row, void* stream);
 
+/* The critic's output of a rollout step into the experience buffer (im_agent.py:292-303, 355, 398): value_raw [n] (the network's output) is
+ * un-normalised with the value normaliser (running_mean / running_var: DEVICE float64 scalars of rl_games' RunningMeanStd; both NULL = no
+ * normaliser) - sqrt(var + epsilon) * clamp(x, -5, 5) + mean - and written to values_row [n] (nullable) and, times (1 - terminated [n]), to
+ * next_values_row [n] (nullable): one launch instead of ~9 elementwise kernels and two copies. */
+int v2p_value_record(int64_t n, const float* value_raw, const double* running_mean, const double* running_var, float epsilon,
+                     const float* terminated, float* values_row, float* next_values_row, void* stream);
+
 /* Bookkeeping of one rollout step after env.step (ImitatorAgent.play_steps, agents/im_agent.py:380-409) in one launch: rewards / dones /
  * next_obses rows of the experience buffer, dones / terminate as floats, running episode returns and lengths, and the episode statistics
  * the reference collects through .nonzero() on the host - here float64 device accumulators:

@@ -100,6 +100,7 @@ def load():
         "v2p_policy_head": [C.c_int64, vp, vp, C.c_int64, C.c_int64, vp, vp, vp, vp, vp, vp],
         "v2p_policy_head_record": [C.c_int64, vp, vp, C.c_int64, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp],
         "v2p_gae": [C.c_int64, C.c_int64, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp],
+        "v2p_value_record": [C.c_int64, vp, vp, vp, C.c_float, vp, vp, vp, vp],
         "v2p_rollout_record": [C.c_int64, vp, C.c_int64] + [vp] * 15,
         "v2p_motion_tables_build": [C.c_int64, C.c_int64, vp, vp, vp, vp, vp, vp, c_i32, vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp],
         "v2p_shapes_compile": [C.c_int32, vp, vp, C.c_int32, vp, vp, C.c_int32, C.c_double, C.c_int32, C.c_double, vp, vp, vp, vp, vp, vp, vp, vp],
@@ -142,7 +143,7 @@ def load():
 
 EXPORTED_SYMBOLS = (
     "v2p_model_create", "v2p_model_destroy", "v2p_mlib_create", "v2p_mlib_destroy", "v2p_motion_state", "v2p_reward", "v2p_reset_flags",
-    "v2p_obs_imitation", "v2p_obs_imitation_packed", "v2p_policy_head", "v2p_policy_head_record", "v2p_gae", "v2p_rollout_record", "v2p_motion_tables_build", "v2p_shapes_compile", "v2p_env_create", "v2p_env_create_shapes", "v2p_env_destroy", "v2p_env_reset", "v2p_env_context", "v2p_env_step", "v2p_env_pre_physics", "v2p_env_physics", "v2p_env_export",
+    "v2p_obs_imitation", "v2p_obs_imitation_packed", "v2p_policy_head", "v2p_policy_head_record", "v2p_gae", "v2p_value_record", "v2p_rollout_record", "v2p_motion_tables_build", "v2p_shapes_compile", "v2p_env_create", "v2p_env_create_shapes", "v2p_env_destroy", "v2p_env_reset", "v2p_env_context", "v2p_env_step", "v2p_env_pre_physics", "v2p_env_physics", "v2p_env_export",
     "v2p_env_post_physics", "v2p_env_push_state", "v2p_env_target_index", "v2p_env_kernel_build", "v2p_env_set_schedule", "v2p_env_debug_contacts", "v2p_env_debug_contacts_substeps", "v2p_env_debug_pairing", "v2p_env_attach_ball", "v2p_env_check", "v2p_env_check_async", "v2p_env_job_recoveries", "v2p_env_jobs_skipped", "v2p_env_profile_begin", "v2p_env_profile_begin_sampled", "v2p_env_profile_end", "v2p_last_error", "v2p_abi_version",
 )
 

@@ -332,6 +332,15 @@ int v2p_gae(int64_t horizon, int64_t n, const float* fdones, const float* values
     return launch_gae(horizon, n, fdones, values, rewards, next_values, gamma, tau, advs, (hipStream_t)stream);
 }
 
+int v2p_value_record(int64_t n, const float* value_raw, const double* running_mean, const double* running_var, float epsilon, const float* terminated,
+                     float* values_row, float* next_values_row, void* stream) {
+    if (n < 0 || (n > 0 && (!value_raw || ((running_mean == nullptr) != (running_var == nullptr)) || (next_values_row && !terminated)))) {
+        set_error("v2p_value_record: bad argument");
+        return V2P_ERR_INVALID;
+    }
+    return launch_value_record(n, value_raw, running_mean, running_var, epsilon, terminated, values_row, next_values_row, (hipStream_t)stream);
+}
+
 int v2p_rollout_record(int64_t n, const float* obs, int64_t obs_dim, const float* rew, const int64_t* reset, const int64_t* terminate, const float* sub_rewards,
                        float* next_obs_row, float* rewards_row, float* dones_row, float* dones, float* terminated, float* prev_dones, float* cur_rewards,
                        float* cur_lengths, double* acc, double* sub_acc, void* stream) {

@@ -288,6 +288,29 @@ __global__ __launch_bounds__(256) void rollout_record_kernel(int64_t n, int env_
     }
 }
 
+// The critic's output of a rollout step into the experience buffer (im_agent.py:292-303, 355, 398): un-normalised with the value normaliser
+// (rl_games RunningMeanStd, unnorm: sqrt(var + eps) * clamp(x, -5, 5) + mean, float32 like torch evaluates it), written as `values` of step n
+// and - masked by the terminations of the step that produced the observation (end_value_type 'next') - as `next_values` of step n - 1.
+__global__ void value_record_kernel(int64_t n, const float* __restrict__ x, const double* __restrict__ mean, const double* __restrict__ var, float eps,
+                                    const float* __restrict__ terminated, float* __restrict__ values_row, float* __restrict__ next_values_row) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    float y = x[e];
+    if (mean) {
+        const float scale = sqrtf((float)var[0] + eps);
+        y = scale * fminf(fmaxf(y, -5.f), 5.f) + (float)mean[0];
+    }
+    if (values_row) values_row[e] = y;
+    if (next_values_row) next_values_row[e] = y * (1.f - terminated[e]);
+}
+
+int launch_value_record(int64_t n, const float* x, const double* mean, const double* var, float eps, const float* terminated, float* values_row,
+                        float* next_values_row, hipStream_t s) {
+    if (n <= 0) return V2P_OK;
+    hipLaunchKernelGGL(value_record_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, x, mean, var, eps, terminated, values_row, next_values_row);
+    return check_hip(hipGetLastError(), "value_record_kernel");
+}
+
 int launch_rollout_record(int64_t n, const float* obs, int64_t obs_dim, const float* rew, const int64_t* reset, const int64_t* terminate, const float* sub_rewards,
                           float* next_obs_row, float* rewards_row, float* dones_row, float* dones, float* terminated, float* prev_dones, float* cur_rewards,
                           float* cur_lengths, double* acc, double* sub_acc, hipStream_t s) {

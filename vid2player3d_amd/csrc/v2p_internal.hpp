@@ -229,6 +229,8 @@ int launch_motion_tables_build(int64_t F, const double* lrot, const double* root
 int launch_shape_compile(int32_t jobs, const double* pts, const int32_t* job_off, int32_t max_pts, const double* dirs, const int32_t* dir_off, int32_t num_tables,
                          double density, int32_t max_verts, double eps_rel, double* mass, double* com, double* inertia, int32_t* num_verts, int32_t* vert_ids,
                          double* verts, int32_t* status, hipStream_t s);
+int launch_value_record(int64_t n, const float* x, const double* mean, const double* var, float eps, const float* terminated, float* values_row,
+                        float* next_values_row, hipStream_t s);
 int launch_rollout_record(int64_t n, const float* obs, int64_t obs_dim, const float* rew, const int64_t* reset, const int64_t* terminate, const float* sub_rewards,
                           float* next_obs_row, float* rewards_row, float* dones_row, float* dones, float* terminated, float* prev_dones, float* cur_rewards,
                           float* cur_lengths, double* acc, double* sub_acc, hipStream_t s);

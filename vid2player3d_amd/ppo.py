@@ -422,6 +422,16 @@ class PPOAgent(PolicyInference):
             that produced the observation, `next_values` of step n - 1.  With overlap_critic on the group's SIDE stream: the critic pass is
             needed by the buffer only, never by the next physics launch, so it runs while the actor pass and the physics of step n do."""
             def work():
+                if fused:
+                    # critic output -> un-normalised -> `values` of step n and the masked `next_values` of step n - 1: one launch
+                    raw = self.model.critic(feat)
+                    vms, td = self.value_mean_std, buf.tensor_dict
+                    _lib.check(self._lib.v2p_value_record(
+                        raw.shape[0], _lib.ptr(raw), _lib.ptr(vms.running_mean) if self.normalize_value else None,
+                        _lib.ptr(vms.running_var) if self.normalize_value else None, float(vms.epsilon), _lib.ptr(terminated) if n > 0 else None,
+                        _lib.ptr(td["values"][n, g.sl]) if n < T else None, _lib.ptr(td["next_values"][n - 1, g.sl]) if n > 0 else None,
+                        _lib.current_stream(self.device)), "v2p_value_record")
+                    return
                 v = self._value(feat)
                 if n < T:
                     buf.update_data("values", n, v, g.sl)
