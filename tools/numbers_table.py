@@ -57,12 +57,13 @@ def main(prefix, write):
         if os.path.exists(p):
             d = last_json(p)
             rows.append(("`--per-clip-shapes --num-shapes %d` (one body shape per clip, env i -> shape i %% %d)" % (S, S), *fmt(d), "`r05_shapes_bench_%d.log`" % S))
-    d = last_json(P("bench_ppo.log"))
+    ppo_log = os.path.join(ROOT, "profiles", "r05g_bench_ppo.log")  # (the rollout fusion landed after the r05f round: its own log)
+    d = last_json(ppo_log if os.path.exists(ppo_log) else P("bench_ppo.log"))
     ppo = ""
     if d:
         c = d["config"]
-        ppo = ("\n\nFull PPO loop (`bench.py --ppo`, 8192 envs, `%s_bench_ppo.log`): **fps step %.2f M** (rollout: T_play %.4f s per epoch), fps total %.3f M "
-               "(T_update %.3f s per epoch: fp32 MLPs through rocBLAS, outside this path)." % (prefix, c["fps_step"] / 1e6, c["T_play_s_per_epoch"], c["fps_total"] / 1e6, c["T_update_s_per_epoch"]))
+        ppo = ("\n\nFull PPO loop (`bench.py --ppo`, 8192 envs, `%s`): **fps step %.2f M** (rollout: T_play %.4f s per epoch), fps total %.3f M "
+               "(T_update %.3f s per epoch: fp32 MLPs through rocBLAS, outside this path)." % ("r05g_bench_ppo.log" if os.path.exists(ppo_log) else prefix + "_bench_ppo.log", c["fps_step"] / 1e6, c["T_play_s_per_epoch"], c["fps_total"] / 1e6, c["T_update_s_per_epoch"]))
     r = head["roofline"]
     cb = head.get("cpu_baseline")
     out = ["| configuration (one MI355X) | env-steps/s | ms per step | physics kernel ms | log |", "|---|---|---|---|---|"]
