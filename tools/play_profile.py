@@ -21,9 +21,12 @@ if __name__ == "__main__":
     agent.play_steps()  # warm-up (allocator, rocBLAS heuristics)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    enq = 0.0
     for _ in range(epochs):
+        ta = time.perf_counter()
         agent.play_steps()
-    torch.cuda.synchronize()
+        enq += time.perf_counter() - ta  # (host time to ENQUEUE the epoch: equal to the wall clock = the rollout is launch bound)
+        torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     steps = epochs * agent.horizon_length
-    print("[play] %d epochs x %d steps x %d envs: %.3f ms per step, %.2f M frames/s (fps step)" % (epochs, agent.horizon_length, task.num_envs, 1e3 * dt / steps, task.num_envs * steps / dt / 1e6))
+    print("[play] %d epochs x %d steps x %d envs: %.3f ms per step, %.2f M frames/s (fps step); host enqueue time %.3f ms per step" % (epochs, agent.horizon_length, task.num_envs, 1e3 * dt / steps, task.num_envs * steps / dt / 1e6, 1e3 * enq / steps))
