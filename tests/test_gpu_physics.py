@@ -863,3 +863,66 @@ def test_rest_contact_supports_the_weight_at_full_size(mlib):
     assert float((z - z[0]).abs().max()) < 2e-3 and float(z.min()) > 0.05  # lying on the plane, not in it
     assert float(task._rigid_body_vel.abs().max()) < 0.2
     task.close()
+
+
+def test_engine_obeys_the_closed_form_friction_law(mlib):
+    """Closed-form facts of the contact model, on the HIP ENGINE itself (tests/test_phys_oracle.py checks the same on the float64 oracle):
+    a rigid box on the plane (the root link of a 24-link model whose other links are 0.1 g points on stiff drives, far from the ground),
+    pushed horizontally at its centre of mass with alpha x its weight through the residual-force actions (a slope of tan(theta) = alpha),
+    mu = 1: along a tangent axis it sticks at alpha = 0.9 and slides with (alpha - mu) g at 1.1; along the DIAGONAL it still sticks at 1.3
+    and slides with (alpha - sqrt(2) mu) g at 1.5 - the friction limit is a pyramid aligned with world x / y (box friction per tangent row)."""
+    from scipy.spatial.transform import Rotation
+
+    from tests.test_phys_oracle import box_model
+    from vid2player3d_amd.model import load_baked_model
+
+    BASEQ = np.array([0.5, 0.5, 0.5, 0.5])
+    R = Rotation.from_quat(BASEQ).as_matrix()                      # body -> world at the root pose of the test (SMPL y-up body, z-up world)
+    half_world = np.array([0.25, 0.25, 0.1])
+    half_body = np.abs(R.T) @ half_world
+    bm = box_model(load_baked_model(), half=tuple(half_body), mass=10.0)
+    up_body = R.T @ np.array([0.0, 0.0, 1.0])                      # the 23 point links stack upwards in the WORLD
+    lp = bm.blob["local_pos"].copy()
+    lp[1:] = 0.05 * up_body
+    blob = dict(bm.blob, local_pos=lp)
+    from vid2player3d_amd.model import BodyModel
+    bm = BodyModel(blob, default_humanoid_mass=float(bm.mass.sum()))
+    cases = [(0.9, (1, 0)), (1.1, (1, 0)), (1.3, (1, 1)), (1.5, (1, 1)), (0.9, (0, 1)), (1.1, (0, -1))]
+    n = len(cases)
+    task = make_task(n, mlib, body_model=bm, residual_force_hold="all", terminationHeadHeight=-0.5, enableEarlyTermination=False, debug_contacts=1)
+    task.reset_with_times(None, torch.full((n,), 0.1, device=DEV))
+    root = np.zeros((n, 13), np.float32)
+    root[:, 2], root[:, 3:7] = 0.1, BASEQ
+    task._humanoid_root_states[:] = T(root)
+    task._dof_pos.zero_()
+    task._dof_vel.zero_()
+    task._reset_env_tensors(None)
+    weight = bm.total_mass * 9.81
+    act = np.zeros((n, 75), np.float32)
+    for _ in range(10):  # settle
+        task.step(T(act.copy()))
+    dirs = np.array([np.array(d, np.float64) / np.linalg.norm(d) for _, d in cases])
+    for e, (alpha, _) in enumerate(cases):
+        act[e, 69:71] = alpha * weight * dirs[e] / 31.85
+    v = []
+    for _ in range(30):
+        task.step(T(act.copy()))
+        v.append(N(task._humanoid_root_states)[:, 7:9].copy())
+    torch.cuda.synchronize()
+    assert int(N(task.reset_buf).sum()) == 0                       # (no env was reset: the pushes acted for all 30 steps)
+    ids = N(task.debug_contacts())
+    assert np.all((ids[:, 0] >= 0).sum(axis=1) == 4) and np.all(ids[:, 1:] < 0)    # the boxes rest on their four bottom corners
+    fz = N(task._contact_forces)[:, :, 2].sum(axis=1)
+    assert np.all(np.abs(fz - weight) < 0.02 * weight)
+    v = np.array(v)                                                # [steps, env, 2]
+    t = 30 / 30.0
+    mu = 1.0
+    for e, (alpha, d) in enumerate(cases):
+        along = v[:, e] @ dirs[e]
+        limit = mu * (np.sqrt(2.0) if abs(d[0]) == abs(d[1]) else 1.0)
+        if alpha < limit:
+            assert np.abs(v[-10:, e]).max() < 1e-2 and abs(along[-1] - along[-11]) / (10 / 30.0) < 0.005 * 9.81, (e, alpha, np.abs(v[-10:, e]).max())
+        else:
+            want = (alpha - limit) * 9.81 * t
+            assert abs(along[-1] - want) < 0.06 * want and np.all(np.diff(along) > 0), (e, alpha, along[-1], want)
+    task.close()
