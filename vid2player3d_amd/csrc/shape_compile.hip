@@ -420,11 +420,13 @@ int launch_shape_compile(int32_t jobs, const double* pts, const int32_t* job_off
     int rc = check_hip(hipFuncSetAttribute((const void*)shape_compile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(shape_compile_kernel)");
     if (rc != V2P_OK) return rc;
     ShapeCompileArgs a{pts, job_off, dirs, dir_off, num_tables, jobs, max_pts, max_verts, density, eps_rel, mass, com, inertia, num_verts, vert_ids, verts, status};
-    // persistent waves: as many workgroups as the LDS lets the chip hold (256 CUs x floor(160 KB / lds)), each looping over jobs
+    // persistent waves: as many workgroups as the LDS lets the chip hold (CUs x floor(160 KB / lds)), each looping over jobs
     int per_cu = (int)((160 * 1024) / (lds + 512));
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 16) per_cu = 16;
-    int grid = 256 * per_cu;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    int grid = cus * per_cu;
     if (grid > jobs) grid = jobs;
     hipLaunchKernelGGL(shape_compile_kernel, dim3(grid), dim3(SC_WAVE), lds, s, a);
     return check_hip(hipGetLastError(), "shape_compile_kernel");
