@@ -13,7 +13,7 @@ def main(db, epochs):
     calls = dict.fromkeys(groups, 0)
     print("%-86s %8s %10s %9s" % ("kernel", "calls", "us", "avg_us"))
     for name, n, total, avg in rows:
-        short = name.split("(")[0].replace("void ", "")[:84]
+        short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")[:84]
         g = "physics" if "physics_ll" in name else "gemm" if ("Cijk" in name or "gemm" in name.lower()) else "engine (v2p) other" if "v2p::" in name else "glue (torch elementwise / copies / reductions)"
         groups[g] += total / steps
         calls[g] += n / steps

@@ -13,7 +13,7 @@ def main(path):
     print("# rocprofv3 --kernel-trace --stats summary of %s (durations in microseconds)" % path)
     print("%-72s %8s %14s %12s %8s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
     for name, calls, total, avg, pct in rows:
-        short = name.split("(")[0].replace("void ", "")
+        short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
         if len(short) > 70:
             short = short[:67] + "..."
         print("%-72s %8d %14.1f %12.3f %8.3f" % (short, calls, total, avg, pct))
@@ -22,7 +22,7 @@ def main(path):
     print("\n# per-dispatch resources of the engine's kernels (duration ns)")
     print("%-44s %5s %5s %5s %7s %7s %9s %5s %6s %12s %12s %12s" % ("kernel", "vgpr", "agpr", "sgpr", "lds", "scratch", "grid", "wg", "n", "avg_ns", "min_ns", "max_ns"))
     for r in cur:
-        short = r[0].split("(")[0].replace("void ", "")
+        short = r[0].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
         print("%-44s %5d %5d %5d %7d %7d %9d %5d %6d %12.0f %12.0f %12.0f" % ((short[:44],) + tuple(r[1:])))
 
 
