@@ -105,3 +105,32 @@ def test_model_blob_and_table_builder(golden_tables):
         assert np.abs(tabs[k].astype(np.float64) - golden_tables[k]).max() < 1e-6, k
     for k in ("motion_lengths", "motion_num_frames", "motion_dt", "motion_bodies", "motion_min_verts_h", "length_starts"):
         assert np.array_equal(tabs[k], golden_tables[k]), k
+
+
+def test_new_entry_points_refuse_bad_arguments_without_touching_a_gpu():
+    """Argument validation of the ABI 13 entry points happens before any HIP call: bad sizes / null buffers come back as V2P_ERR_INVALID
+    with a message (no compute call is made here)."""
+    from vid2player3d_amd import _lib
+
+    L = _lib.load()
+    INVALID = -1
+    null = None
+    one = ctypes.c_void_p(16)  # (a non-null placeholder: every call below is refused before anything is dereferenced)
+    assert L.v2p_shapes_compile(-1, null, null, 0, null, null, 1, 900.0, 64, 1e-10, null, null, null, null, null, null, null, null) == INVALID
+    assert L.v2p_shapes_compile(4, one, one, 100, one, one, 1, 900.0, 65, 1e-10, one, one, one, one, one, one, one, null) == INVALID  # max_verts > 64
+    assert L.v2p_shapes_compile(4, null, one, 100, one, one, 1, 900.0, 64, 1e-10, one, one, one, one, one, one, one, null) == INVALID  # null points
+    assert b"v2p_shapes_compile" in L.v2p_last_error()
+    par = (ctypes.c_int32 * 24)(*([-1] + list(range(23))))
+    assert L.v2p_motion_tables_build(-1, 1, null, null, null, null, null, null, par, null, 0, null, null, null, null, null, null, null) == INVALID
+    assert L.v2p_motion_tables_build(10, 1, null, one, one, one, one, one, par, one, 0, one, one, one, one, one, one, null) == INVALID
+    assert L.v2p_motion_tables_build(10, 1, one, one, one, one, one, one, None, one, 0, one, one, one, one, one, one, null) == INVALID  # no tree
+    assert L.v2p_rollout_record(-1, null, 461, *([null] * 15)) == INVALID
+    assert L.v2p_rollout_record(8, null, 461, one, one, one, one, one, one, one, one, one, one, one, one, one, one, null) == INVALID  # rows to copy, no obs
+    assert L.v2p_value_record(8, null, null, null, 1e-5, null, null, null, null) == INVALID
+    assert L.v2p_value_record(8, one, one, null, 1e-5, null, one, null, null) == INVALID      # mean without var
+    assert L.v2p_value_record(8, one, null, null, 1e-5, null, null, one, null) == INVALID     # next_values without terminated
+    assert L.v2p_policy_head_record(8, one, one, 48, 48, one, one, one, one, one, null, null, null) == INVALID  # frame outside the context window
+    assert L.v2p_policy_head_record(8, one, one, 48, 8, one, one, one, one, null, null, null, null) == INVALID   # no neglogp row
+    # zero-sized calls are no-ops, not errors
+    assert L.v2p_rollout_record(0, null, 461, *([null] * 15)) == 0 and L.v2p_value_record(0, null, null, null, 1e-5, null, null, null, null) == 0
+    assert L.v2p_shapes_compile(0, null, null, 0, null, null, 1, 900.0, 64, 1e-10, null, null, null, null, null, null, null, null) == 0
