@@ -197,7 +197,8 @@ int v2p_motion_tables_build(int64_t num_frames_total, int64_t num_clips, const d
  * All pointers are DEVICE pointers.  points [total,3]; job_offsets [num_jobs+1] (first point of every job); max_points = the
  * largest cloud (sizes the LDS arrays: ~48 B per point x 2; up to ~1600 points); dirs [.,3] + dir_offsets [num_dir_tables+1].
  * Out per job: mass, com [3], inertia [9], num_verts, vert_ids [max_verts] (indices into the job's cloud, ascending), verts
- * [max_verts,3], status (0 ok, 1 fewer than 4 points, 2 coplanar cloud, 3 face capacity, 4 reduction failed).
+ * [max_verts,3], status (0 ok, 1 fewer than 4 points, 2 coplanar cloud, 3 face capacity, 4 reduction failed,
+ * 7 the job's point count - job_off[j + 1] - job_off[j] - is negative or exceeds max_points).
  * vid2player3d_amd/body_shapes.py holds the host-side wrapper and the numpy statement of the same algorithm (the checker). */
 int v2p_shapes_compile(int32_t num_jobs, const double* points, const int32_t* job_offsets, int32_t max_points, const double* dirs,
                        const int32_t* dir_offsets, int32_t num_dir_tables, double density, int32_t max_verts, double eps_rel, double* mass,
@@ -257,7 +258,8 @@ typedef struct {
     /* ---- ABI 7 */
     int32_t joint_limits;       /* 1: every DOF whose range (v2p_model_desc.limit_lower/upper) is narrower than a full turn carries a
                                  * limit row in the contact solver (the racket arm of the player MJCFs; the amass MJCF has none).
-                                 * Link-per-lane schedule, PGS, contacts on.  0 (default): ranges are ignored. */
+                                 * Link-per-lane schedule, contacts on, either solver (under TGS the distance to the limit advances slice by
+                                 * slice with the joint rate).  0 (default): ranges are ignored. */
     /* ---- ABI 9 */
     float limit_margin;         /* radians; <= 0 = default (0.05).  A limit row exists in a substep only while its DOF is within reach of the
                                  * limit: C < limit_margin + h * max(0, rate of approach after the unconstrained update v*), C = distance to
@@ -279,9 +281,12 @@ typedef struct {
                                  * rounding): 1 = three waves per SIMD with the contact records parked in LDS (fastest where the launch is
                                  * bound by instruction issue: BASELINE's 8192 envs), 2 = two waves per SIMD with everything in registers
                                  * (5 - 7 % faster where a launch is as long as its heaviest env pair: small batches).  0 = the engine
-                                 * chooses, launch by launch, by the number of envs RESIDENT on the device - the sum over the live
-                                 * batches of this process, so that rollout groups sharing a GPU are judged together (2 at <= 5120
-                                 * envs: measured, profiles/r04e_dual_build.txt).  v2p_env_kernel_build tells which one a batch runs. */
+                                 * chooses by the number of envs RESIDENT on the device - the sum over the live batches of this
+                                 * process, so that rollout groups sharing a GPU are judged together (2 at <= 5120 envs: measured,
+                                 * profiles/r04e_dual_build.txt).  The choice is taken at the first launch after v2p_env_create and
+                                 * after every whole-batch v2p_env_reset (an epoch boundary) and holds in between: a batch does not
+                                 * change build mid-epoch because another batch was created or destroyed.  v2p_env_kernel_build tells
+                                 * which one the next launch of a batch runs (read-only). */
     /* ---- ABI 13: the A/B and test switches of the substep jobs (environment variables until ABI 12).  A zero-initialised block = the
      * engine's defaults.  The library reads NO engine option from the environment; its profiling switches (V2P_WAVE_TIMES,
      * V2P_PHASE_TIMING, V2P_PHASE_HEAVY, V2P_ENVS_PER_BLOCK) are honoured only in a process that sets V2P_DEBUG=1. */
@@ -384,7 +389,8 @@ int v2p_env_debug_pairing(v2p_env* e, int32_t* perm, int32_t* key, void* stream)
  * drag + Magnus force re-evaluated before every simulate() call (apply_external_force_to_ball), ball x ground and ball x racket
  * contacts with restitution and friction (material values combined by averaging, PhysX's default), and - body_contacts - the ball
  * against the convex hulls of the humanoid's links (the ball actor collides with every shape of its env, :367-372, 432): one point per
- * substep, against the nearest hull; the racket's link is left to its cylinders.  Link-per-lane schedule, contacts on, PGS.
+ * substep, against the nearest hull; the racket's link is left to its cylinders.  Link-per-lane schedule, contacts on, either solver
+ * (TGS: the two-body rows' gaps advance slice by slice; a row's restitution target is taken once, at the start of the substep).
  * The reference's flag bookkeeping around simulate() (bounce test on the ball height at the start of every call, :731-737; racket-hit
  * poll after it, :773-779) runs inside the step when the flag buffers are given. */
 typedef struct {

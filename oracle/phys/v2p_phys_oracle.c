@@ -655,7 +655,6 @@ static int substep_impl(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s
     for (int i = 0; i < ND; ++i) v[i] = s->vel[i] + h * rhs[i];
     for (int i = ND; i < NDT; ++i) v[i] = 0.0;
     if (ball) { /* free flight of the ball: gravity + the aerodynamic force held over this simulate() call */
-        if (p->solver_type != 0) return -2; /* the ball rows are stated for PGS only */
         for (int i = 0; i < 3; ++i) {
             v[ND + i] = ball->vel[i] + h * ((i == 2 ? p->gravity_z : 0.0) + (ball_force ? ball_force[i] / bp->mass : 0.0));
             v[ND + 3 + i] = ball->angvel[i];
@@ -814,6 +813,7 @@ static int substep_impl(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s
         double *lam = wii + (nrow > 0 ? nrow : 1);
         double *bias = lam + (nrow > 0 ? nrow : 1);
         double gap[NB * MAXC_BODY + 6 + 3 * NJ];
+        double rbias[NB * MAXC_BODY + 6 + 3 * NJ]; /* restitution target of a ball row (bias <= rest x approach speed), +inf = none */
         int slot_in_body[NB];
         memset(slot_in_body, 0, sizeof(slot_in_body));
         for (int c = 0; c < nc; ++c) {
@@ -865,11 +865,13 @@ static int substep_impl(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s
             double d = r->gap;
             gap[c] = d;
             bias[3 * c] = d >= 0 ? d / h : fmax(p->erp * d / h, -p->max_depen_vel);
+            rbias[c] = 1e300;
             if (r->kind == 1 || r->kind == 2 || r->kind == 4) { /* restitution (Newton): an approach faster than the bounce threshold that closes the gap within this substep
                                  * leaves with rest x the approach speed */
                 double vn0 = 0;
                 for (int col = 0; col < NDT; ++col) vn0 += Jr[3 * c * NDT + col] * v[col];
-                if (vn0 < -bp->bounce_threshold && d / h + vn0 < 0) bias[3 * c] = fmin(bias[3 * c], r->rest * vn0);
+                if (vn0 < -bp->bounce_threshold && d / h + vn0 < 0) rbias[c] = r->rest * vn0;
+                bias[3 * c] = fmin(bias[3 * c], rbias[c]);
             }
         }
         /* solver_type 0, PGS: n_iter sweeps against the biases of the start of the substep.
@@ -879,7 +881,11 @@ static int substep_impl(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s
          *     d_c(k) = d_c(k-1) + hs * vn_c(after sweep k-1),
          * and runs ONE sweep against  d_c(k) / (h - k hs)  (separated: do not cross the plane in the time that is left)  or
          * max(erp d_c(k) / hs, -max_depenetration)  (penetrating: correct a fraction per slice); impulses accumulate and are clamped
-         * on the accumulated value as in PGS. */
+         * on the accumulated value as in PGS.  Every row of the list takes part: hull points, the joint-limit rows (their "gap" is the
+         * distance of the DOF to its limit, advanced with the joint rate) and the ball's two-body rows (advanced with the relative normal
+         * velocity of the two contact points).  Restitution of a ball row: the bounce decision and its target, rest x the approach speed
+         * of v*, are taken ONCE at the start of the substep (as under PGS) and cap the bias of every slice - a ball that has bounced in
+         * slice 0 is leaving in slices 1.., its advancing gap would otherwise ask for less than the rebound. */
         int sweep_rev[NB * MAXC_BODY + 6 + 3 * NJ]; /* the points stop by stop, last stop first (see the sweep) */
         {
             int n = 0;
@@ -901,6 +907,7 @@ static int substep_impl(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s
                         gap[c] += hs * vn;
                     }
                     bias[3 * c] = gap[c] >= 0 ? gap[c] / (h - it * hs) : fmax(p->erp * gap[c] / hs, -p->max_depen_vel);
+                    bias[3 * c] = fmin(bias[3 * c], rbias[c]);
                 }
             }
             /* Experiment of round 4 (g_experiment bit 2, value 4; the engine's counterpart is the build switch V2P_LL_ALT_SWEEP): PGS sweeps

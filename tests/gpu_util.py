@@ -1,5 +1,4 @@
 """Helpers shared by the `-m gpu` parity tests."""
-import os
 
 import numpy as np
 import torch
@@ -64,16 +63,29 @@ def close(a, b, tol, what="", sens=None, k_sens=16.0):
     if sens is not None and (err > flat).any():
         print("[close] %s: %d of %d elements need the conditioning term (largest error there = %.1f x sensitivity)"
               % (what, int((err > flat).sum()), err.size, float((err[err > flat] / np.maximum(np.asarray(sens, dtype=np.float64)[err > flat], 1e-300)).max())))
-    if os.environ.get("V2P_CLOSE_REPORT"):  # A/B of kernel variants: print how much of each tolerance is used instead of asserting
+    if _report_only(what):  # A/B of kernel variants: print how much of each tolerance is used instead of asserting
         print("[close] %-40s err %.3e  limit %.3e  used %.3f" % (what, err.max(), flat, use))
         return
     assert not over.any(), "%s: max abs err %.3e, %.2f x its bound (%.1e%s)" % (what, err.max(), use, flat, "" if sens is None else " + %g x sensitivity" % k_sens)
 
 
-SENS_CAP = 1000.0   # the conditioning term never exceeds this many flat bounds (0.2 m/s + 0.5 |ref| on a velocity, 50 N + |ref| on a force)
-SENS_SHARE = 0.04   # share of the envs of a comparison that may need the conditioning term (measured: <= 1.1 % of 2048-env fixtures) ...
+SENS_CAP = 200.0    # the conditioning term never exceeds this many flat bounds (0.04 m/s + 0.1 |ref| on a velocity, 10 N + 0.2 |ref| on a force).
+                    # Round 6 (VERDICT r5 #4a): 1000 -> 200; the largest excess over a flat bound that was ever traced to conditioning is ~130 x
+                    # (one element of the 4-env epoch test, profiles/r05f_rows.log), 31 x in the 2048 / 16384-env sweeps
+SENS_SHARE = 0.02   # share of the envs of a comparison that may need the conditioning term (round 6: 0.04 -> 0.02; measured <= 1.1 % of
+                    # 2048 / 16384-env fixtures) ...
 SENS_MIN_ENVS = 4   # ... or this many envs, never more than half of them (small fixtures; measured over the whole suite, profiles/r05f_rows_all.log:
                     # at most 3 of 48 - ragdolls late in an epoch -, 2 of 64, 1 of 4; largest use of a bound 0.75)
+# Report mode: a TOOL that wants the percentiles of a comparison without its pass / fail (A/B of kernel variants) sets this attribute in its
+# own process - `gpu_util.REPORT_ONLY = True` - and every comparison then says so, loudly.  (Until round 5 two environment variables did
+# this: a stray export in a CI shell weakened every parity test without a trace.  No environment variable is read any more.)
+REPORT_ONLY = False
+
+
+def _report_only(what):
+    if REPORT_ONLY:
+        print("[gpu_util] WARNING: REPORT_ONLY is set by the calling tool - '%s' is printed, NOT asserted" % what, flush=True)
+    return REPORT_ONLY
 
 
 def rows_close(a, b, atol, rtol, what, sens=None, k_sens=16.0):
@@ -100,7 +112,7 @@ def rows_close(a, b, atol, rtol, what, sens=None, k_sens=16.0):
     bad = (use > 1.0).reshape(a.shape[0], -1).any(axis=1)
     if sens is not None:
         n_need = int((err > flat).reshape(a.shape[0], -1).any(axis=1).sum())
-        assert os.environ.get("V2P_SENS_SHARE_REPORT") or n_need <= min(max(SENS_MIN_ENVS, int(SENS_SHARE * a.shape[0])), max(1, a.shape[0] // 2)), "%s: %d of %d envs need the conditioning term (more than %.0f %%): not a conditioning effect" % (what, n_need, a.shape[0], 100 * SENS_SHARE)
+        assert _report_only(what + " (share of envs that need the conditioning term)") or n_need <= min(max(SENS_MIN_ENVS, int(SENS_SHARE * a.shape[0])), max(1, a.shape[0] // 2)), "%s: %d of %d envs need the conditioning term (more than %.0f %%): not a conditioning effect" % (what, n_need, a.shape[0], 100 * SENS_SHARE)
     pe, pu = np.percentile(err, [50, 99, 100]), np.percentile(use, [50, 99, 100])
     extra = ""
     if sens is not None:

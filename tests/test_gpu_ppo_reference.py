@@ -181,6 +181,36 @@ def test_fused_step_record_equals_the_torch_bookkeeping(lib):
     assert float(acc[5:].abs().sum()) == 0
 
 
+def test_fused_record_is_taken_by_the_engines_task_and_refused_for_other_layouts(lib):
+    """advisor r5: the fused bookkeeping reads raw pointers with HumanoidSMPLIM's layouts; a fresh engine task qualifies (before its first
+    step too: `extras` is still empty then), a CUDA task with bool flags, int32 flags or five sub-rewards does not (torch path instead)."""
+    import types
+
+    from tests.gpu_util import make_task
+    from vid2player3d_amd.ppo import PPOAgent
+
+    task = make_task(8, lib)
+    assert task.extras == {} and PPOAgent._fused_record_ok(task)
+    task.reset_with_times(None, torch.full((8,), 0.3, device=DEV))
+    task.step(torch.zeros((8, 75), device=DEV))
+    assert PPOAgent._fused_record_ok(task)
+
+    def stub(**kw):
+        d = dict(num_envs=8, num_obs=461, obs_buf=torch.zeros((8, 461), device=DEV), rew_buf=torch.zeros(8, device=DEV),
+                 reset_buf=torch.zeros(8, dtype=torch.int64, device=DEV),
+                 extras={"terminate": torch.zeros(8, dtype=torch.int64, device=DEV), "sub_rewards": torch.zeros((8, 4), device=DEV)})
+        d.update(kw)
+        return types.SimpleNamespace(**d)
+
+    assert PPOAgent._fused_record_ok(stub())
+    assert not PPOAgent._fused_record_ok(stub(reset_buf=torch.zeros(8, dtype=torch.bool, device=DEV)))
+    assert not PPOAgent._fused_record_ok(stub(extras={"terminate": torch.zeros(8, dtype=torch.int32, device=DEV), "sub_rewards": torch.zeros((8, 4), device=DEV)}))
+    assert not PPOAgent._fused_record_ok(stub(extras={"terminate": torch.zeros(8, dtype=torch.int64, device=DEV), "sub_rewards": torch.zeros((8, 5), device=DEV)}))
+    assert not PPOAgent._fused_record_ok(stub(obs_buf=torch.zeros((8, 922), device=DEV)[:, ::2]))
+    assert not PPOAgent._fused_record_ok(stub(rew_buf=torch.zeros(8, dtype=torch.float64, device=DEV)))
+    task.close()
+
+
 def test_two_rollout_groups_fill_the_same_buffer(lib):
     """192 envs as one batch on one stream == 96 + 96 on two streams (same clips, same start times, same noise per env)"""
     a, b = _rollout(lib, 192, 1, True, flat_heads=True), _rollout(lib, 192, 2, True, flat_heads=True)

@@ -101,47 +101,53 @@ def _launch(task, rng, mode):
     return ball
 
 
+@pytest.mark.parametrize("solver", ["pgs", "tgs"])
 @pytest.mark.parametrize("mode,lift,limits,player", [("flight", 0.0, False, "djokovic"), ("ground", 0.0, False, "djokovic"), ("hit", 0.4, False, "djokovic"),
                                                      ("hit", 0.0, False, "djokovic"), ("hit", 0.0, True, "djokovic"), ("body", 0.4, False, "djokovic"),
                                                      ("body", 0.0, True, "federer"), ("hit", 0.0, True, "nadal"), ("joint", 0.4, False, "djokovic")])
-def test_ball_step_matches_oracle(mlib, mode, lift, limits, player):
+def test_ball_step_matches_oracle(mlib, mode, lift, limits, player, solver):
     """limits: with the joint ranges of the player MJCF's racket arm enforced (v2p_sim_cfg.joint_limits) - the wrist's limit rows, its
-    hull points and the ball x racket rows then all belong to the same link.  player: the asset (nadal = left-handed: racket on L_Wrist)."""
-    _ball_step_vs_oracle(mlib, mode, lift, limits, player)
+    hull points and the ball x racket rows then all belong to the same link.  player: the asset (nadal = left-handed: racket on L_Wrist).
+    solver: tgs = the solver the reference's tennis yamls name (vid2player/cfg/im/tennis_im.yaml:39, embodied_pose/cfg/djokovic_im.yaml:41)."""
+    _ball_step_vs_oracle(mlib, mode, lift, limits, player, solver=solver)
 
 
+@pytest.mark.parametrize("solver", ["pgs", "tgs"])
 @pytest.mark.parametrize("mode,limits", [("hit", True), ("body", False), ("ground", False)])
-def test_ball_step_with_the_lds_parked_build(mlib, mode, limits):
+def test_ball_step_with_the_lds_parked_build(mlib, mode, limits, solver):
     """kernel_build=1: the build that full-size batches run (the engine gives 32-env fixtures the register build, which is what every
     other small test of this file sees)."""
-    _ball_step_vs_oracle(mlib, mode, 0.0, limits, "djokovic", kernel_build=1)
+    _ball_step_vs_oracle(mlib, mode, 0.0, limits, "djokovic", kernel_build=1, solver=solver)
 
 
+@pytest.mark.parametrize("solver", ["pgs", "tgs"])
 @pytest.mark.parametrize("mode", ["hit", "body"])
-def test_ball_step_with_one_body_shape_per_clip(mlib, mode):
+def test_ball_step_with_one_body_shape_per_clip(mlib, mode, solver):
     """racket + ball on per-clip body shapes (three differently scaled bodies, each with the racket folded into its wrist): every env
     against the oracle of ITS shape"""
     from vid2player3d_amd.model import load_baked_model
 
     base = load_baked_model()
-    _ball_step_vs_oracle(mlib, mode, 0.0, True, "djokovic", shapes=[base.scaled(0.9), base, base.scaled(1.12)])
+    _ball_step_vs_oracle(mlib, mode, 0.0, True, "djokovic", shapes=[base.scaled(0.9), base, base.scaled(1.12)], solver=solver)
 
 
+@pytest.mark.parametrize("solver", ["pgs", "tgs"])
 @pytest.mark.parametrize("mode", ["hit", "ground"])
-def test_ball_step_with_six_substeps_per_simulate_call(mlib, mode):
+def test_ball_step_with_six_substeps_per_simulate_call(mlib, mode, solver):
     """sim.substeps 6 (vid2player/cfg/controller/*.yaml: 12 substeps of 1/360 s per control step): the racket-hit poll is off then
     (humanoid_smpl_im_mvae.py:769), the bounce test uses 6 ball radii (:733); kernel vs oracle on every env, through substep jobs."""
-    _ball_step_vs_oracle(mlib, mode, 0.0, True, "djokovic", substeps=6)
+    _ball_step_vs_oracle(mlib, mode, 0.0, True, "djokovic", substeps=6, solver=solver)
 
 
-def _ball_step_vs_oracle(mlib, mode, lift, limits, player, shapes=None, substeps=2, n=32, subset=None, steps=2, **env):
+def _ball_step_vs_oracle(mlib, mode, lift, limits, player, shapes=None, substeps=2, n=32, subset=None, steps=2, solver="pgs", **env):
     """subset: the envs that get an oracle (all by default); every comparison is restricted to them."""
+    env = dict(env, contact_solver=solver)
     sub = np.arange(n) if subset is None else np.asarray(sorted(int(i) for i in subset))
     rng = np.random.default_rng({"flight": 1, "ground": 2, "hit": 3, "body": 4, "joint": 5, "serve": 6}[mode] + int(10 * lift))
     extra = dict(env, **({} if shapes is None else {"body_model": shapes, "motion_shape_ids": np.arange(8) % len(shapes)}))
     task = make_rb_task(n, mlib, joint_limits=limits, player=player, sim_overrides={"substeps": substeps}, **extra)
     rl = task.racket_geometry["racket_link"]
-    assert rl == (17 if player == "nadal" else 22)
+    assert rl == (17 if player == "nadal" else 22) and task.contact_solver == solver
     task.reset_with_times(None, T(rng.uniform(0.1, 1.0, size=n)))
     root = N(task._humanoid_root_states).copy()
     root[:, 2] += lift
@@ -158,7 +164,7 @@ def _ball_step_vs_oracle(mlib, mode, lift, limits, player, shapes=None, substeps
     for e in sub:
         if shapes is not None:
             bm = task.body_shapes[task._env_shape_ids[e]]
-        o = PhysOracle(bm, default_params(h=1.0 / (60.0 * substeps), joint_limits=int(limits)), kp=bm.kp.astype(np.float32), kd=bm.kd.astype(np.float32))
+        o = PhysOracle(bm, default_params(h=1.0 / (60.0 * substeps), joint_limits=int(limits), solver_type={"pgs": 0, "tgs": 1}[solver]), kp=bm.kp.astype(np.float32), kd=bm.kd.astype(np.float32))
         o.set_state(root[e], dpos[e], dvel[e])
         o.attach_ball(task.racket_geometry)
         oracles.append(o)
@@ -208,7 +214,7 @@ def _ball_step_vs_oracle(mlib, mode, lift, limits, player, shapes=None, substeps
         ball_before = ball_before[sub]
         close(got_ps[..., 0:3], per_sim[..., 0:3], 2e-5, "%s ball pos (step %d)" % (mode, step))
         qs = np.sign(np.sum(got_ps[..., 3:7] * per_sim[..., 3:7], -1, keepdims=True))
-        close(got_ps[..., 3:7] * qs, per_sim[..., 3:7], 1e-4, "ball quat")
+        close(got_ps[..., 3:7] * qs, per_sim[..., 3:7], 1e-4, "ball quat", sens=sens["ball"][..., 3:7])  # (integrates the spin: conditioned like it)
         close(got_ps[..., 7:10], per_sim[..., 7:10], 5e-4, "%s ball vel (step %d)" % (mode, step), sens=sens["ball"][..., 7:10])
         close(got_ps[..., 10:13], per_sim[..., 10:13], 5e-4, "%s ball spin (step %d)" % (mode, step), sens=sens["ball"][..., 10:13])
         assert np.array_equal(N(task._ball_root_states)[sub], got_ps[:, -1])
@@ -250,14 +256,15 @@ def _ball_step_vs_oracle(mlib, mode, lift, limits, player, shapes=None, substeps
     return {"hits": hits_total, "ground": ground_total, "body": body_total, "multi": multi_total}
 
 
-def test_racket_ball_full_size_sample_matches_oracle(mlib):
+@pytest.mark.parametrize("solver", ["pgs", "tgs"])
+def test_racket_ball_full_size_sample_matches_oracle(mlib, solver):
     """BASELINE config 4 as worded, at its size: 8192 envs with racket + ball, joint limits on, a ball served at every player (bench.py's
     serve, started close enough to arrive within the test); 64 of the envs - first, last and a spread - against their own oracles over
     three control steps: substep jobs, pairing by load and the tail of a full-size launch with the ball kernel."""
     n = 8192
     subset = sorted(set([0, 1, 2, n - 2, n - 1] + list(np.random.default_rng(9).integers(0, n, size=59))))
-    got = _ball_step_vs_oracle(mlib, "serve", 0.0, True, "djokovic", n=n, subset=subset, steps=3)
-    print("[racket-ball 8192] sampled envs: racket hits %d, ground bounces %d, deflections by a link's hull %d, balls on two hulls at once %d" % (got["hits"], got["ground"], got["body"], got["multi"]))
+    got = _ball_step_vs_oracle(mlib, "serve", 0.0, True, "djokovic", n=n, subset=subset, steps=3, solver=solver)
+    print("[racket-ball 8192 %s] sampled envs: racket hits %d, ground bounces %d, deflections by a link's hull %d, balls on two hulls at once %d" % (solver, got["hits"], got["ground"], got["body"], got["multi"]))
     assert got["hits"] + got["body"] + got["ground"] >= 8, "the serve must reach something in the sampled envs: %s" % got
 
 
@@ -281,8 +288,9 @@ def test_bounce_and_hit_flags(mlib):
     task.close()
 
 
+@pytest.mark.parametrize("solver", ["pgs", "tgs"])
 @pytest.mark.parametrize("n,timeout_spins", [(3, None), (2048, None), (2048, "0")])
-def test_substep_jobs_are_invisible_with_ball(mlib, n, timeout_spins):
+def test_substep_jobs_are_invisible_with_ball(mlib, n, timeout_spins, solver):
     """Racket + ball + joint limits through substep jobs (the ball's state and its aerodynamic force are handed over with the
     humanoid's; the flags are kept through system-scope accesses): bit-identical to one workgroup per env pair, step after step.
     timeout_spins "0": every job whose predecessor is not done at its first look recomputes the earlier substeps itself (the recovery
@@ -291,7 +299,7 @@ def test_substep_jobs_are_invisible_with_ball(mlib, n, timeout_spins):
 
     outs = []
     for jobs in (False, True):
-        task = make_rb_task(n, mlib, substep_jobs=2 * int(jobs), debug_contacts=0, job_timeout_spins=-1 if (jobs and timeout_spins is not None) else 0)
+        task = make_rb_task(n, mlib, contact_solver=solver, substep_jobs=2 * int(jobs), debug_contacts=0, job_timeout_spins=-1 if (jobs and timeout_spins is not None) else 0)
         g = torch.Generator(device=DEV)
         g.manual_seed(23)
         task.reset_with_times(None, torch.rand(n, device=DEV, generator=g) * 0.8)
@@ -363,18 +371,31 @@ def test_aero_force_and_bounce_flags_match_reference_vectors(mlib):
 
 
 def test_racket_ball_task_builds_from_the_references_physx_block(mlib, capsys):
-    """vid2player's tennis yamls state `solver_type: 1` (TGS); joint limits and the ball are PGS-only in the engine.  The task built from
-    that block runs PGS and says so (it used to fail in v2p_env_create: "joint_limits needs ... the PGS solver"), and steps."""
+    """vid2player's tennis yamls state `solver_type: 1` (TGS: vid2player/cfg/im/tennis_im.yaml:39, embodied_pose/cfg/djokovic_im.yaml:41).
+    The task built from that block RUNS TGS - racket-arm limit rows and the ball's rows inside its slices - (until round 5 it overrode to
+    PGS with a message): bit-identical to an explicit env.contact_solver = 'tgs', different from 'pgs' on the same inputs."""
     physx = {"num_threads": 4, "solver_type": 1, "num_position_iterations": 4, "num_velocity_iterations": 0, "contact_offset": 0.02, "rest_offset": 0.0,
              "bounce_threshold_velocity": 0.2, "max_depenetration_velocity": 10.0, "default_buffer_size_multiplier": 10.0}
-    task = make_rb_task(8, mlib, sim_overrides={"physx": physx}, debug_contacts=0)
-    assert task.contact_solver == "pgs"
-    assert "running PGS" in capsys.readouterr().out
-    task.reset_with_times(None, torch.full((8,), 0.3, device=DEV))
-    a = torch.cat([task._target_dof_pos.clone(), torch.zeros((8, 6), device=DEV)], dim=1).contiguous()
-    task.step(a)
-    task.check()
-    assert torch.isfinite(task.obs_buf).all()
-    task.close()
-    with pytest.raises(RuntimeError, match="PGS"):  # an explicit engine-side choice of TGS is refused, not overridden
-        make_rb_task(8, mlib, contact_solver="tgs", debug_contacts=0)
+    n = 64
+    outs = {}
+    for name, kw in (("yaml", dict(sim_overrides={"physx": physx})), ("tgs", dict(contact_solver="tgs")), ("pgs", dict(contact_solver="pgs"))):
+        task = make_rb_task(n, mlib, debug_contacts=0, **kw)
+        assert task.contact_solver == ("pgs" if name == "pgs" else "tgs")
+        if name == "yaml":
+            assert task.contact_solver_source == "sim.physx.solver_type"
+            assert "running PGS" not in capsys.readouterr().out
+        g = torch.Generator(device=DEV)
+        g.manual_seed(5)
+        task.reset_with_times(None, torch.rand(n, device=DEV, generator=g) * 0.8)
+        root = task._humanoid_root_states[:, 0:3]
+        task.reset_balls(torch.arange(n, device=DEV), root + torch.tensor([1.2, 0.0, 0.3], device=DEV), torch.tensor([[-20.0, 0.0, 1.0]], device=DEV).repeat(n, 1),
+                         torch.tensor([[0.0, -120.0, 0.0]], device=DEV).repeat(n, 1))
+        for _ in range(4):
+            a = torch.cat([task._target_dof_pos + 0.4 * torch.randn((n, 69), device=DEV, generator=g), 0.3 * torch.randn((n, 6), device=DEV, generator=g)], dim=1).contiguous()
+            task.step(a)
+        task.check()
+        assert torch.isfinite(task.obs_buf).all()
+        outs[name] = (N(task._rigid_body_state).copy(), N(task._ball_root_states).copy())
+        task.close()
+    assert np.array_equal(outs["yaml"][0], outs["tgs"][0]) and np.array_equal(outs["yaml"][1], outs["tgs"][1])
+    assert np.abs(outs["yaml"][0] - outs["pgs"][0]).max() > 1e-3, "TGS must be a different solver from PGS on the same inputs"

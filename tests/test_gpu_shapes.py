@@ -95,6 +95,21 @@ def test_degenerate_clouds():
         bs.compile_clouds_device(np.random.default_rng(0).normal(size=(5000, 3)), [0, 5000], DEV)
 
 
+def test_a_job_larger_than_max_points_is_refused_not_run():
+    """advisor r5: the kernel sizes its LDS arrays from the caller's max_points; a job whose offsets disagree with it (more points, or a
+    negative count) sets status 7 instead of overrunning them - the other jobs of the launch are compiled as usual."""
+    from vid2player3d_amd import body_shapes as bs
+
+    rng = np.random.default_rng(3)
+    sizes = [40, 200, 40]
+    pts = rng.normal(size=(sum(sizes), 3))
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    with pytest.raises(ValueError, match="cloud 1 of 3.*max_points"):
+        bs.compile_clouds_device(pts, off, DEV, max_points=64)
+    out = bs.compile_clouds_device(pts, off, DEV)
+    assert (out["num_verts"] >= 4).all()
+
+
 def test_2048_shapes_compile_in_seconds():
     """The reference's scale: one body shape per AMASS clip.  2048 shapes = 49,152 hull jobs in one launch; the numpy loop takes ~0.4 s per
     shape (~15 min), the budget here is 30 s for clouds + device compile + BodyModel construction (VERDICT r4 #1a)."""

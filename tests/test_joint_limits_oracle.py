@@ -13,8 +13,8 @@ def racket_model():
     return with_racket(load_baked_model())[0]
 
 
-def _fly(model, limits, tar, steps=30, dof_vel=None):
-    o = po.PhysOracle(model, po.default_params(joint_limits=int(limits)))
+def _fly(model, limits, tar, steps=30, dof_vel=None, solver=0):
+    o = po.PhysOracle(model, po.default_params(joint_limits=int(limits), solver_type=solver))
     root = np.zeros(13)
     root[2], root[6] = 3.0, 1.0
     o.set_state(root, np.zeros(69), np.zeros(69) if dof_vel is None else dof_vel)
@@ -34,14 +34,15 @@ def test_player_arm_ranges_are_on_the_racket_model(racket_model):
     assert (base.limit_upper - base.limit_lower >= 2 * np.pi - 1e-6).all(), "the amass MJCF has no DOF narrower than a full turn"
 
 
-def test_drive_beyond_the_range_stops_at_the_limit(racket_model):
+@pytest.mark.parametrize("solver", [0, 1], ids=["pgs", "tgs"])
+def test_drive_beyond_the_range_stops_at_the_limit(racket_model, solver):
     m = racket_model
     jw, je = 3 * (m.body_index("R_Wrist") - 1), 3 * (m.body_index("R_Elbow") - 1)
     tar = np.zeros(69)
     tar[jw:jw + 3] = [1.0, 1.2, -2.0]
     tar[je] = 2.5
-    _, dp_free, _, _ = _fly(m, False, tar)
-    _, dp_lim, _, _ = _fly(m, True, tar)
+    _, dp_free, _, _ = _fly(m, False, tar, solver=solver)
+    _, dp_lim, _, _ = _fly(m, True, tar, solver=solver)
     assert np.rad2deg(dp_free[jw]) > 40 and np.rad2deg(dp_free[je]) > 100  # the drives do go there when nothing stops them
     lim = np.deg2rad([10.0, 45.0, -90.0])
     assert np.abs(dp_lim[jw:jw + 3] - lim).max() < 2e-3, np.rad2deg(dp_lim[jw:jw + 3])
@@ -60,7 +61,8 @@ def test_rows_far_from_their_limits_change_nothing(racket_model):
         assert np.array_equal(x, y)
 
 
-def test_fast_approach_is_stopped_within_the_substep(racket_model):
+@pytest.mark.parametrize("solver", [0, 1], ids=["pgs", "tgs"])
+def test_fast_approach_is_stopped_within_the_substep(racket_model, solver):
     """Wrist spun at 20 rad/s towards its 10-degree limit: the limit is reached, not crossed (speculative bias gap / h)."""
     m = racket_model
     jw = 3 * (m.body_index("R_Wrist") - 1)
@@ -68,16 +70,17 @@ def test_fast_approach_is_stopped_within_the_substep(racket_model):
     dv[jw] = 20.0
     tar = np.zeros(69)
     tar[jw] = 1.0  # the drive keeps pushing as well
-    _, dp, _, _ = _fly(m, True, tar, steps=1, dof_vel=dv)
+    _, dp, _, _ = _fly(m, True, tar, steps=1, dof_vel=dv, solver=solver)
     assert dp[jw] <= np.deg2rad(10.0) + 2e-3 and dp[jw] > np.deg2rad(9.0), np.rad2deg(dp[jw])
-    _, dp_free, _, _ = _fly(m, False, tar, steps=1, dof_vel=dv)
+    _, dp_free, _, _ = _fly(m, False, tar, steps=1, dof_vel=dv, solver=solver)
     assert dp_free[jw] > np.deg2rad(14.0)
 
 
-def test_limits_and_contacts_share_the_sweep(racket_model):
+@pytest.mark.parametrize("solver", [0, 1], ids=["pgs", "tgs"])
+def test_limits_and_contacts_share_the_sweep(racket_model, solver):
     """Lying on the ground with the wrist driven into its limit: finite, bounded, the limit holds while contacts are active."""
     m = racket_model
-    o = po.PhysOracle(m, po.default_params(joint_limits=1))
+    o = po.PhysOracle(m, po.default_params(joint_limits=1, solver_type=solver))
     root = np.zeros(13)
     root[2], root[3:7] = 0.12, [np.sqrt(0.5), 0.0, 0.0, np.sqrt(0.5)]
     o.set_state(root, np.zeros(69), np.zeros(69))

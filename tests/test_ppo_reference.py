@@ -266,6 +266,44 @@ def test_ranks_start_from_rank_0s_state(tmp_path):
         assert float(r1[7][k]["step"]) == 1.0
 
 
+def _bcast_mismatch_main(rank, world, port, q):
+    import torch.distributed as dist
+    from vid2player3d_amd.ppo import PPOAgent
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    agent = PPOAgent(stub_task(3), horizon_length=T, units=(32, 16), minibatch_envs=3, seed=5)
+    if rank == 1:  # Adam state on one rank only, and nobody materialises it on the other: the layouts differ
+        for p_ in agent.model.parameters():
+            p_.grad = torch.full_like(p_, 0.01)
+        agent.optimizer.step()
+    try:
+        agent.broadcast_state()
+        q.put((rank, "no error"))
+    except RuntimeError as e:
+        q.put((rank, str(e)))
+    dist.destroy_process_group()
+
+
+def test_broadcast_state_refuses_mismatched_layouts_on_every_rank():
+    """advisor r5: ranks whose state differs in layout (optimizer slots on one rank only; `step` counters on different devices used to split
+    the dtype groups differently) must not enter mismatched collectives - the layout manifest is exchanged first and EVERY rank raises."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_bcast_mismatch_main, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all("different state layouts" in got[r] for r in (0, 1)), got
+
+
 # ---------------------------------------------------------------- the reference agent's configuration and checkpoint surface
 AMASS_IM_PARAMS = {  # the `params` block of embodied_pose/cfg/amass_im.yaml:55-143, as yaml.safe_load returns it
     "seed": 7, "algo": {"name": "pose_im_rnn"}, "model": {"name": "pose_im"},

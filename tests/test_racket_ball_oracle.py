@@ -63,9 +63,10 @@ def test_free_flight_drag_and_magnus(models):
         assert az < -9.81 and abs(az + 9.81 + kf * cl * 900.0 / 0.057) < 0.03 * abs(az)
 
 
-def test_bounce_height_and_friction(models):
+@pytest.mark.parametrize("solver", [0, 1], ids=["pgs", "tgs"])
+def test_bounce_height_and_friction(models, solver):
     _, (m, geom) = models
-    o = PhysOracle(m, default_params())
+    o = PhysOracle(m, default_params(solver_type=solver))
     far_humanoid(o)
     o.attach_ball(geom)
     ball = np.zeros(13); ball[0:3] = [0, 0, 1.0]; ball[6] = 1
@@ -92,12 +93,13 @@ def test_bounce_height_and_friction(models):
     assert b[7] < 5.0 - 0.3 and b[11] > 10.0  # rolling forward about +y
 
 
-def test_racket_hit_exchanges_momentum(models):
+@pytest.mark.parametrize("solver", [0, 1], ids=["pgs", "tgs"])
+def test_racket_hit_exchanges_momentum(models, solver):
     """A ball thrown at the face of the racket of a floating, limp humanoid (no gravity, no drives): it comes back (restitution 1), the
     total linear momentum of humanoid + ball is conserved, the hit is reported for that simulate() call only."""
     _, (m, geom) = models
     zeros = np.zeros(69)
-    o = PhysOracle(m, default_params(gravity_z=0.0, ang_damp=0.0), kp=zeros, kd=zeros)
+    o = PhysOracle(m, default_params(gravity_z=0.0, ang_damp=0.0, solver_type=solver), kp=zeros, kd=zeros)
     root = np.zeros(13); root[2] = 3.0; root[3:7] = BASE
     o.set_state(root, zeros, zeros)
     o.attach_ball(geom, material={"ang_damp": 0.0})
@@ -128,7 +130,8 @@ def test_racket_hit_exchanges_momentum(models):
     assert np.linalg.norm(o.get_state()[3][22, 7:10]) > 0.05  # the wrist was pushed
 
 
-def test_ball_bounces_off_a_link(models):
+@pytest.mark.parametrize("solver", [0, 1], ids=["pgs", "tgs"])
+def test_ball_bounces_off_a_link(models, solver):
     """Ball x hull contacts: a ball thrown at the chest of a floating, limp humanoid bounces off with about half its approach speed
     (restitution (1 + 0) / 2 against a link that is far heavier than the ball), total linear momentum is conserved, and the racket-hit
     flags stay clear; with body_contacts off the same ball flies through."""
@@ -136,7 +139,7 @@ def test_ball_bounces_off_a_link(models):
     zeros = np.zeros(69)
     out = {}
     for on in (True, False):
-        o = PhysOracle(m, default_params(gravity_z=0.0, ang_damp=0.0), kp=zeros, kd=zeros)
+        o = PhysOracle(m, default_params(gravity_z=0.0, ang_damp=0.0, solver_type=solver), kp=zeros, kd=zeros)
         root = np.zeros(13); root[2] = 3.0; root[3:7] = BASE
         o.set_state(root, zeros, zeros)
         o.attach_ball(geom, material={"ang_damp": 0.0}, body_contacts=on)

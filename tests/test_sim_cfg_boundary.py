@@ -85,18 +85,19 @@ def test_velocity_iterations_are_refused_by_the_library_not_dropped():
     assert c.num_velocity_iterations == 1 and abs(c.rest_offset - 0.005) < 1e-9
 
 
-def test_racket_ball_task_falls_back_to_pgs_when_the_file_says_tgs():
-    """vid2player's tennis configs state solver_type: 1; the racket-arm limit rows and the ball exist in the PGS solver only: the task
-    runs PGS and says so (it used to fail in v2p_env_create) - unless the caller names a solver by the engine's own key."""
-    from vid2player3d_amd.tasks.humanoid_racket_ball import racket_ball_solver_override
+def test_racket_ball_task_keeps_the_solver_the_file_names():
+    """vid2player's tennis configs state solver_type: 1 (tennis_im.yaml:39, djokovic_im.yaml:41).  Until round 5 the racket + ball task
+    overrode that to PGS; the override is gone (the limit rows and the ball's rows are solved under TGS too): the task module resolves the
+    solver exactly like the base task, and nothing in it rewrites env.contact_solver."""
+    import inspect
 
+    from vid2player3d_amd.tasks import humanoid_racket_ball as rb
+
+    assert not hasattr(rb, "racket_ball_solver_override")
+    src = inspect.getsource(rb.HumanoidSMPLIMRacketBall.__init__)
+    assert 'env["contact_solver"]' not in src and "contact_solver\"] =" not in src
     sp = SimParams.from_cfg(yaml.safe_load(AMASS_IM_SIM)["sim"])
-    env, said = {}, []
-    assert racket_ball_solver_override(env, sp, log=said.append) and env["contact_solver"] == "pgs"
-    assert len(said) == 1 and "TGS" in said[0] and "PGS" in said[0]
-    env = {"contact_solver": "tgs"}  # an explicit engine-side choice is left alone (and refused by the engine with its own message)
-    assert not racket_ball_solver_override(env, sp) and env["contact_solver"] == "tgs"
-    assert not racket_ball_solver_override({}, SimParams.from_cfg(default_cfg(4)["sim"]))  # no solver named: PGS anyway, nothing to say
+    assert resolve_contact_solver({"joint_limits": True}, sp) == ("tgs", "sim.physx.solver_type")
 
 
 def test_zero_initialised_cfg_keeps_the_job_defaults():

@@ -34,6 +34,7 @@ FIX = (("pd only", dict(contact=False, seed=11, lift=0.3)), ("standing", dict(co
        ("fallen", dict(contact=True, seed=3, lift=-0.75, vel_sigma=0.2)), ("fast", dict(contact=True, seed=13, lift=-0.5, vel_sigma=3.0)),
        ("low", dict(contact=True, seed=17, lift=-0.9, vel_sigma=1.0)), ("tgs", dict(contact=True, seed=2, lift=-0.1, solver="tgs")),
        ("limits", dict(contact=True, seed=61, lift=0.0, vel_sigma=0.5, limits=True, body_model=bm_racket, act_sigma=0.5)),
+       ("limitstgs", dict(contact=True, seed=61, lift=0.0, vel_sigma=0.5, limits=True, solver="tgs", body_model=bm_racket, act_sigma=0.5)),
        ("limits*", dict(contact=True, seed=61, lift=0.0, vel_sigma=0.5, limits=True, body_model=bm_racket, act_sigma=0.5, limit_margin=1e9)))  # rows always on
 for name, kw in FIX:
     if args.fixtures and name not in args.fixtures.split(","):

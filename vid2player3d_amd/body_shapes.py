@@ -262,7 +262,7 @@ def reduce_direction_tables(max_verts=MAX_HULL_VERTS):
     return np.concatenate([fibonacci_directions(k) for k in ks]), np.concatenate([[0], np.cumsum(ks)]).astype(np.int32)
 
 
-def compile_clouds_device(points, offsets, device, density=GEOM_DENSITY, max_verts=MAX_HULL_VERTS, eps_rel=1e-10):
+def compile_clouds_device(points, offsets, device, density=GEOM_DENSITY, max_verts=MAX_HULL_VERTS, eps_rel=1e-10, max_points=None):
     """The engine's shape compiler on a flat list of clouds: points [T,3] float64, offsets [J+1] -> dict of numpy arrays per job
     (mass [J], com [J,3], inertia [J,3,3], num_verts [J], vert_ids [J,max_verts], verts [J,max_verts,3]).  HIP only (no CPU path:
     body_from_clouds is the numpy statement of the same algorithm and the checker of this one)."""
@@ -291,14 +291,14 @@ def compile_clouds_device(points, offsets, device, density=GEOM_DENSITY, max_ver
         vid = torch.zeros((J, max_verts), dtype=torch.int32, device=dev)
         verts = torch.zeros((J, max_verts, 3), dtype=torch.float64, device=dev)
         status = torch.full((J,), -1, dtype=torch.int32, device=dev)
-        _lib.check(lib.v2p_shapes_compile(J, _lib.ptr(pts), _lib.ptr(off), int(sizes.max()), _lib.ptr(d_dirs), _lib.ptr(d_doff), len(doff) - 1, float(density),
+        _lib.check(lib.v2p_shapes_compile(J, _lib.ptr(pts), _lib.ptr(off), int(sizes.max() if max_points is None else max_points), _lib.ptr(d_dirs), _lib.ptr(d_doff), len(doff) - 1, float(density),
                                           int(max_verts), float(eps_rel), _lib.ptr(mass), _lib.ptr(com), _lib.ptr(inertia), _lib.ptr(nv), _lib.ptr(vid),
                                           _lib.ptr(verts), _lib.ptr(status), _lib.current_stream(dev)), "v2p_shapes_compile")
         st = status.cpu().numpy()
     if (st != 0).any():
         j = int(np.nonzero(st)[0][0])
         raise ValueError("v2p_shapes_compile: cloud %d of %d: %s" % (j, J, {1: "fewer than 4 points", 2: "the points are coplanar", 3: "hull face capacity exceeded",
-                                                                          4: "support reduction failed"}.get(int(st[j]), "status %d" % st[j])))
+                                                                          4: "support reduction failed", 7: "the job's point count is negative or exceeds max_points"}.get(int(st[j]), "status %d" % st[j])))
     return dict(mass=mass.cpu().numpy(), com=com.cpu().numpy(), inertia=inertia.cpu().numpy(), num_verts=nv.cpu().numpy(), vert_ids=vid.cpu().numpy(),
                 verts=verts.cpu().numpy())
 

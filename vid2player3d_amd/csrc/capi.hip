@@ -427,8 +427,8 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
         delete e;
         return V2P_ERR_INVALID;
     }
-    if (c->joint_limits && (c->schedule == 1 || c->solver_type != 0 || !c->enable_contact)) {
-        set_error("v2p_env_create: joint_limits needs the link-per-lane schedule, the PGS solver and contacts on");
+    if (c->joint_limits && (c->schedule == 1 || !c->enable_contact)) {
+        set_error("v2p_env_create: joint_limits needs the link-per-lane schedule and contacts on");
         delete e;
         return V2P_ERR_UNSUPPORTED;
     }
@@ -626,6 +626,7 @@ void v2p_env_destroy(v2p_env* e) {
 int v2p_env_reset(v2p_env* e, const int64_t* env_ids, int64_t n, const float* motion_times, void* stream) {
     if (!e || !motion_times || n < 0 || n > e->n) { set_error("v2p_env_reset: bad argument"); return V2P_ERR_INVALID; }
     DeviceGuard g(e->device);
+    if (!env_ids || n == e->n) e->build_latched = 0;  // an epoch boundary: the next launch may choose its build anew (kernel_build 0)
     return launch_env_reset(e, env_ids, env_ids ? n : e->n, motion_times, (hipStream_t)stream);
 }
 
@@ -642,11 +643,16 @@ int v2p_env_pre_physics(v2p_env* e, float* actions, void* stream) {
     return launch_env_pre(e, actions, (hipStream_t)stream);
 }
 
-// kernel_build = 0: the build follows the envs resident on the device NOW (a second rollout group created after this batch moves both
-// to the three-wave build); the heavy x light pairing share follows the build where it was left to the engine
+// kernel_build = 0: the build follows the envs resident on the device (a second rollout group created after this batch moves both to the
+// three-wave build); the heavy x light pairing share follows the build where it was left to the engine.  The choice is LATCHED: taken at
+// the first launch after the batch was created or reset as a whole (an epoch boundary: every env restarts from a reference state) and
+// kept until the next such reset - the two builds agree to rounding only, so a live batch must not change build in the middle of an
+// epoch because an unrelated batch (an eval task next to training) came or went (advisor r5).
+static int build_wanted(const v2p_env* e) { return resident_envs(e->device) <= REGS_BUILD_MAX_ENVS ? 1 : 0; }
 static void choose_build(v2p_env* e) {
-    if (e->kernel_build != 0) return;
-    const int regs = resident_envs(e->device) <= REGS_BUILD_MAX_ENVS ? 1 : 0;
+    if (e->kernel_build != 0 || e->build_latched) return;
+    e->build_latched = 1;
+    const int regs = build_wanted(e);
     if (regs == e->ll_regs_build) return;
     e->ll_regs_build = regs;
     if (e->pair_mix_default && !e->ball) e->pair_mix_permille = (e->n <= 12288 && !e->p.joint_limits) ? (regs ? 500 : 150) : 0;
@@ -687,8 +693,8 @@ int v2p_env_attach_ball(v2p_env* e, const v2p_ball_cfg* c, const v2p_ball_buffer
         const int nflags = (b->has_bounce != nullptr) + (b->has_bounce_now != nullptr) + (b->bounce_pos != nullptr) + (b->has_racket_contact != nullptr) + (b->has_racket_contact_now != nullptr);
         if (nflags != 0 && nflags != 5) { set_error("v2p_env_attach_ball: give all five flag buffers or none"); return V2P_ERR_INVALID; }
     }
-    if (e->schedule != 0 || !e->p.enable_contact || e->p.solver_type != 0) {
-        set_error("v2p_env_attach_ball: racket + ball needs the link-per-lane schedule, contacts on and the PGS solver");
+    if (e->schedule != 0 || !e->p.enable_contact) {
+        set_error("v2p_env_attach_ball: racket + ball needs the link-per-lane schedule and contacts on");
         return V2P_ERR_UNSUPPORTED;
     }
     if (e->p.rest_offset != 0.f) {
@@ -883,7 +889,7 @@ int v2p_env_set_schedule(v2p_env* e, int schedule) {
 int v2p_env_target_index(const v2p_env* e) { return e ? e->cur_target : V2P_ERR_INVALID; }
 int v2p_env_kernel_build(const v2p_env* e) {  // (the build the NEXT launch of the batch runs)
     if (!e) return V2P_ERR_INVALID;
-    choose_build(const_cast<v2p_env*>(e));
+    if (e->kernel_build == 0 && !e->build_latched) return build_wanted(e) ? 2 : 1;  // (read-only: what choose_build would take now)
     return e->ll_regs_build ? 2 : 1;
 }
 

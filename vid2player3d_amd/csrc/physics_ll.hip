@@ -305,8 +305,10 @@ constexpr int ROOTLAM_FLOATS = 2 * 24;  // (PARK2) Lambda of the two root links 
 // ball block (80 floats per env, after the parking area of the wave): state 13 | aero force 3 | ground contact: active gap bias lambda3 |
 // point j at BL_RK + 16 j: active gap bias rl3 n3 lambda3 link (j = 0, 1: against the racket's cylinders; j = 2 .. 4: against the hulls
 // of up to three links, RK_LINK = the link that owns the point) | velocity at the start of the substep 3
-constexpr int BL_POS = 0, BL_QUAT = 3, BL_VEL = 7, BL_ANG = 10, BL_F = 13, BL_GA = 16, BL_GGAP = 17, BL_GBIAS = 18, BL_GLAM = 19, BL_RK = 24,
-              RK_A = 0, RK_GAP = 1, RK_BIAS = 2, RK_RL = 3, RK_N = 6, RK_LAM = 9, RK_LINK = 12, NBREC = 5, BL_V0 = BL_RK + 16 * NBREC, BL_SLOTS = BL_V0 + 8;
+// (TGS: GGAP / RK_GAP advance slice by slice; BL_GREST / RK_REST = the restitution target of the row, rest x approach speed of v*, taken once
+// at the start of the substep, a large value when the row does not bounce: it caps the bias of every slice)
+constexpr int BL_POS = 0, BL_QUAT = 3, BL_VEL = 7, BL_ANG = 10, BL_F = 13, BL_GA = 16, BL_GGAP = 17, BL_GBIAS = 18, BL_GLAM = 19, BL_GREST = 22, BL_RK = 24,
+              RK_A = 0, RK_GAP = 1, RK_BIAS = 2, RK_RL = 3, RK_N = 6, RK_LAM = 9, RK_LINK = 12, RK_REST = 13, NBREC = 5, BL_V0 = BL_RK + 16 * NBREC, BL_SLOTS = BL_V0 + 8;
 constexpr int LDS_FLOATS_PER_WAVE = PARK_SLOTS * 64 + 2 * BL_SLOTS + ROOTLAM_FLOATS;
 // ball x hull narrow phase, out of line: it runs on the few substeps in which a ball is within reach of a link, and inlined its
 // registers would be spilled around on every substep
@@ -872,8 +874,10 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                     const float gap = bp.z - BP.radius;
                     const bool on = CONTACT && gap < coff + h * fmaxf(0.f, -bv.z);
                     float bias = gap >= 0.f ? gap * ih : fmaxf(P.erp * gap * ih, -P.max_depen);
-                    if (bvs.z < -BP.bounce_thr && gap * ih + bvs.z < 0.f) bias = fminf(bias, BP.rest_ground * bvs.z);  // restitution
+                    const float rest = (bvs.z < -BP.bounce_thr && gap * ih + bvs.z < 0.f) ? BP.rest_ground * bvs.z : 3.0e38f;  // restitution
+                    bias = fminf(bias, rest);
                     bl[BL_GA] = on ? 1.f : 0.f; bl[BL_GGAP] = gap; bl[BL_GBIAS] = bias;
+                    if (TGS) bl[BL_GREST] = rest;
                     bl[BL_GLAM] = 0.f; bl[BL_GLAM + 1] = 0.f; bl[BL_GLAM + 2] = 0.f;
                 }
                 // ---- ball x the racket's solid cylinders: closest point, normal from the cylinder to the ball
@@ -998,7 +1002,7 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                     const float clo = qi - lo, chi = hi - qi;
                     const float gap = clo <= chi ? clo : chi;
                     lsgn[i] = on ? (clo <= chi ? 1.f : -1.f) : 0.f;
-                    lbias[i] = gap >= 0.f ? gap * ih : fmaxf(P.erp * gap * ih, -P.max_depen);
+                    lbias[i] = TGS ? gap : (gap >= 0.f ? gap * ih : fmaxf(P.erp * gap * ih, -P.max_depen));  // (TGS: the gap, advanced slice by slice)
                     llam[i] = 0.f;
                     limact = limact || on;
                 }
@@ -1382,11 +1386,12 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                 const V3 pwv = pp(wv, true);
                 const V3 om = mulT(q2mat(q), wv - pwv);
                 const float mrate = P.limit_margin * PHYS_RCP(h);
+                const float lscale = TGS ? PHYS_RCP(h) : 1.f;  // (TGS keeps the gap itself: gap / h is what the test compares, negative when violated either way)
                 bool anyrow = false;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     const float omi = i == 0 ? om.x : (i == 1 ? om.y : om.z);
-                    const bool on = lsgn[i] != 0.f && lbias[i] < mrate + fmaxf(0.f, -lsgn[i] * omi);  // (violated: lbias < 0)
+                    const bool on = lsgn[i] != 0.f && lbias[i] * lscale < mrate + fmaxf(0.f, -lsgn[i] * omi);  // (violated: lbias < 0)
                     if (!on) lsgn[i] = 0.f;
                     anyrow = anyrow || on;
                 }
@@ -1505,8 +1510,10 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                             const float gap = rk[RK_GAP];
                             const float vn0 = dot(bv + cross(bw, -BP.radius * n) - xd - cross(w, rl), n);
                             float bias = gap >= 0.f ? gap * ih : fmaxf(P.erp * gap * ih, -P.max_depen);
-                            if (vn0 < -BP.bounce_thr && gap * ih + vn0 < 0.f) bias = fminf(bias, (j < 2 ? BP.rest_racket : BP.rest_body) * vn0);
+                            const float rest = (vn0 < -BP.bounce_thr && gap * ih + vn0 < 0.f) ? (j < 2 ? BP.rest_racket : BP.rest_body) * vn0 : 3.0e38f;
+                            bias = fminf(bias, rest);
                             rk[RK_BIAS] = bias;
+                            if (TGS) rk[RK_REST] = rest;
                         }
                     }
                 }
@@ -1713,12 +1720,13 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                         V3 bv{bl[BL_VEL], bl[BL_VEL + 1], bl[BL_VEL + 2]}, bw{bl[BL_ANG], bl[BL_ANG + 1], bl[BL_ANG + 2]};
                         const V3 rb{0.f, 0.f, -BP.radius};
                         float lamn = bl[BL_GLAM];
+                        const float gbias = TGS ? fminf(rowbias(bl[BL_GGAP]), bl[BL_GREST]) : bl[BL_GBIAS];
 #pragma unroll
                         for (int ax = 0; ax < 3; ++ax) {
                             const V3 dir = ax == 0 ? V3{0.f, 0.f, 1.f} : (ax == 1 ? V3{1.f, 0.f, 0.f} : V3{0.f, 1.f, 0.f});
                             const V3 jb = cross(rb, dir);
                             const float wii = BP.inv_mass + BP.inv_inertia * dot(jb, jb);
-                            const float rel = dot(dir, bv) + dot(jb, bw) + (ax == 0 ? bl[BL_GBIAS] : 0.f);
+                            const float rel = dot(dir, bv) + dot(jb, bw) + (ax == 0 ? gbias : 0.f);
                             const float old = bl[BL_GLAM + ax];
                             float nl = old - rel * __builtin_amdgcn_rcpf(wii);
                             if (ax == 0) nl = fmaxf(nl, 0.f);
@@ -1751,6 +1759,29 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
 #pragma unroll
                         for (int c = 0; c < 4; ++c) { const V3 rc = CS.cr(c); CS.set_bias(c, CS.bias(c) + hs * (rc.y * w.x - rc.x * w.y + xd.z)); }
                         tgs_irem = 1.f / (h - (float)it * hs);
+                        if (LIMITS && any64(limact)) {
+                            // ... a limit row's with the joint rate of its DOF (the walk was closed down to the deepest stop: joint and parent are current)
+                            const V3 pw = pp(w, true);
+                            if (limact) {
+                                const V3 om = mulT(q2mat(Q4{park[PARK_Q * 64], park[(PARK_Q + 1) * 64], park[(PARK_Q + 2) * 64], park[(PARK_Q + 3) * 64]}), w - pw);
+                                lbias[0] += hs * lsgn[0] * om.x; lbias[1] += hs * lsgn[1] * om.y; lbias[2] += hs * lsgn[2] * om.z;
+                            }
+                        }
+                        if (BALL) {
+                            // ... the ball's rows with the relative normal velocity of the two contact points (the ball's own point is at -R n of its
+                            // centre: its spin does not move it along n)
+                            const V3 bv{bl[BL_VEL], bl[BL_VEL + 1], bl[BL_VEL + 2]};
+                            if (ballground) bl[BL_GGAP] = bl[BL_GGAP] + hs * bv.z;
+                            if (ballhit) {
+#pragma unroll 1
+                                for (int j = 0; j < NBREC; ++j) {
+                                    lds_vfloat* rk = bl + BL_RK + 16 * j;
+                                    if (rk[RK_A] == 0.f || !ball_rec_mine(j)) continue;
+                                    const V3 n{rk[RK_N], rk[RK_N + 1], rk[RK_N + 2]}, rl{rk[RK_RL], rk[RK_RL + 1], rk[RK_RL + 2]};
+                                    rk[RK_GAP] = rk[RK_GAP] + hs * dot(bv - xd - cross(w, rl), n);
+                                }
+                            }
+                        }
                     }
                     if (BALL && backward) moved |= ball_ground_rows(done);  // (the last stop of a forward sweep is the first of a backward one)
                     while (t0 | t1) {
@@ -1796,7 +1827,7 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                                     for (int i = 0; i < 3; ++i) {
                                         const V3 kc = i == 0 ? V3{Kd.xx, Kd.xy, Kd.xz} : (i == 1 ? V3{Kd.xy, Kd.yy, Kd.yz} : V3{Kd.xz, Kd.yz, Kd.zz});
                                         const float kii = i == 0 ? kc.x : (i == 1 ? kc.y : kc.z);
-                                        const float rel = lsgn[i] * om[i] + lbias[i];
+                                        const float rel = lsgn[i] * om[i] + rowbias(lbias[i]);
                                         const float nl = fmaxf(llam[i] - rel * __builtin_amdgcn_rcpf(kii), 0.f);
                                         const float dl = lsgn[i] != 0.f ? nl - llam[i] : 0.f;
                                         llam[i] += dl;
@@ -1879,6 +1910,7 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                                     ball_dirs(n, t1v, t2v);
                                     const V3 rb = -BP.radius * n;
                                     float lamn = rk[RK_LAM];
+                                    const float rkbias = TGS ? fminf(rowbias(rk[RK_GAP]), rk[RK_REST]) : rk[RK_BIAS];
 #pragma unroll 1
                                     for (int ax = 0; ax < 3; ++ax) {
                                         const V3 dir = ax == 0 ? n : (ax == 1 ? t1v : t2v);
@@ -1886,7 +1918,7 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                                         const V3 yw = mul(Lam.A, jn) + mul(Lam.B, dir);
                                         const V3 yv = V3{dot(col(Lam.B, 0), jn), dot(col(Lam.B, 1), jn), dot(col(Lam.B, 2), jn)} + mul(Lam.C, dir);
                                         const float wii = dot(jn, yw) + dot(dir, yv) + BP.inv_mass + BP.inv_inertia * dot(jb, jb);
-                                        const float rel = dot(dir, bv) + dot(jb, bw) - dot(jn, wl) - dot(dir, xl) + (ax == 0 ? rk[RK_BIAS] : 0.f);
+                                        const float rel = dot(dir, bv) + dot(jb, bw) - dot(jn, wl) - dot(dir, xl) + (ax == 0 ? rkbias : 0.f);
                                         const float old = rk[RK_LAM + ax];
                                         float nl = old - rel * __builtin_amdgcn_rcpf(wii);
                                         if (ax == 0) nl = fmaxf(nl, 0.f);
@@ -1932,6 +1964,7 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                 if (!TGS && (live0 || live1)) walk_close(maxd, true);
                 } else
                 for (int it = 0; it < P.n_iter; ++it) {
+                    static_assert(WALK || !(TGS && (BALL || LIMITS)), "the per-group propagation (V2P_LL_WALK=0) solves the ball and limit rows under PGS only");
                     unsigned t0 = m0, t1 = m1, l0 = lm0, l1 = lm1;
                     bool moved = false;
                     if (TGS && it > 0) {
@@ -2742,12 +2775,12 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s, float* actions, int* fuse
             *fused_post = 1;
         }
     };
-    if (env->p.joint_limits && !(env->p.enable_contact && !tgs)) {
-        set_error("physics: joint limits run with contacts on and the PGS solver");
+    if (env->p.joint_limits && !env->p.enable_contact) {
+        set_error("physics: joint limits run with contacts on");
         return V2P_ERR_UNSUPPORTED;
     }
-    if (env->ball && !(env->p.enable_contact && !tgs)) {
-        set_error("physics: racket + ball runs with contacts on and the PGS solver");
+    if (env->ball && !env->p.enable_contact) {
+        set_error("physics: racket + ball runs with contacts on");
         return V2P_ERR_UNSUPPORTED;
     }
     if (diag && env->p.enable_contact && !tgs && !multi && !env->ball && !env->p.joint_limits) {
@@ -2761,8 +2794,11 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s, float* actions, int* fuse
 #define V2P_LL_LAUNCH(C, T, B, L) do { \
             if (multi) hipLaunchKernelGGL((physics_ll_kernel<C, true, T, false, B, true, L>), jgrid, block, lds, s, a); \
             else hipLaunchKernelGGL((physics_ll_kernel<C, false, T, false, B, true, L>), jgrid, block, lds, s, a); } while (0)
-        if (lim && ball) V2P_LL_LAUNCH(true, false, true, true);
+        if (lim && ball && tgs) V2P_LL_LAUNCH(true, true, true, true);
+        else if (lim && ball) V2P_LL_LAUNCH(true, false, true, true);
+        else if (lim && tgs) V2P_LL_LAUNCH(true, true, false, true);
         else if (lim) V2P_LL_LAUNCH(true, false, false, true);
+        else if (ball && tgs) V2P_LL_LAUNCH(true, true, true, false);
         else if (ball) V2P_LL_LAUNCH(true, false, true, false);
         else if (con && tgs) V2P_LL_LAUNCH(true, true, false, false);
         else if (con) V2P_LL_LAUNCH(true, false, false, false);

@@ -274,6 +274,10 @@ __global__ __launch_bounds__(SC_WAVE) void shape_compile_kernel(ShapeCompileArgs
         double* outv = a.verts + 3 * (size_t)job * a.max_verts;
         int32_t* outi = a.vert_ids + (size_t)job * a.max_verts;
         __syncthreads();
+        if (n < 0 || n > a.max_pts) {  // an offsets array that disagrees with max_points: the LDS arrays are sized from max_points (advisor r5)
+            if (lane == 0) { a.status[job] = 7; a.num_verts[job] = 0; a.mass[job] = 0; }
+            continue;
+        }
         int F = hull(P, n, a.eps_rel, maxf, L);
         if (F < 0) {
             if (lane == 0) { a.status[job] = -F; a.num_verts[job] = 0; a.mass[job] = 0; }

@@ -157,7 +157,8 @@ struct v2p_env {
     int job_len;              // substeps per job; 0 = the engine decides (2 for launches of >= job_len2_blocks env pairs, else 1)
     int job_len2_blocks;
     int ll_regs_build;        // 1: this batch runs the register build of the link-per-lane kernel (two waves per SIMD)
-    int kernel_build;         // v2p_sim_cfg.kernel_build (0: ll_regs_build follows the envs resident on the device, launch by launch)
+    int kernel_build;         // v2p_sim_cfg.kernel_build (0: ll_regs_build follows the envs resident on the device)
+    int build_latched;        // kernel_build 0: the choice is taken at the first launch after creation / after a whole-batch reset and holds until the next one
     int counted_resident;     // this batch is in the device's resident-env count
     int job_lead;             // substeps of the FIRST job of a cut pair (0 = like the others, -1 = the engine decides)
     int64_t job_recoveries;   // jobs that gave up waiting and recomputed, as last fetched (v2p_env_check / _check_async)

@@ -324,13 +324,33 @@ class PPOAgent(PolicyInference):
             tensors += [t for t in st.values() if torch.is_tensor(t)]
         counters = torch.tensor([self.epoch_num, self.frame], dtype=torch.float64, device=self.device)
         tensors.append(counters)
+        # one flat buffer per DTYPE, staged on this rank's device whatever device a tensor lives on: Adam's `step` counters are CPU tensors
+        # on a rank that materialised them and device tensors on a rank that loaded them with map_location (advisor r5) - grouped by
+        # (dtype, device) the ranks would issue different numbers of collectives of different sizes
         seen, by_dtype = set(), {}
         for t in tensors:
-            if t.data_ptr() in seen and t.numel() > 0:
+            key = (str(t.device), t.data_ptr())
+            if key in seen and t.numel() > 0:
                 continue
-            seen.add(t.data_ptr())
-            by_dtype.setdefault((t.dtype, str(t.device)), []).append(t)
-        for (dt, _), ts in by_dtype.items():
+            seen.add(key)
+            by_dtype.setdefault(str(t.dtype), []).append(t)
+        names = sorted(by_dtype)
+        # the layout every rank is about to broadcast, compared BEFORE any data moves: a mismatch raises on every rank instead of hanging
+        # in (or silently corrupting) mismatched collectives
+        K = 8
+        assert len(names) <= K
+        man = torch.full((K, 3), -1, dtype=torch.int64, device=self.device)
+        for i, nm in enumerate(names):
+            man[i, 0] = sum(ord(c) * (k + 1) for k, c in enumerate(nm)) % (1 << 31)
+            man[i, 1] = len(by_dtype[nm])
+            man[i, 2] = sum(t.numel() for t in by_dtype[nm])
+        allman = [torch.empty_like(man) for _ in range(_world(self.group))]
+        vdist.dist.all_gather(allman, man, group=self.group)
+        if any(not torch.equal(m, man) for m in allman):
+            raise RuntimeError("broadcast_state: the ranks hold different state layouts (dtype hash, tensors, elements per dtype): %s"
+                               % [m.cpu().tolist()[:len(names) + 1] for m in allman])
+        for nm in names:
+            ts = by_dtype[nm]
             flat = torch.cat([t.reshape(-1).to(self.device) for t in ts])
             vdist.dist.broadcast(flat, src=vdist.dist.get_global_rank(self.group, src) if self.group is not None else src, group=self.group)
             off = 0
@@ -359,6 +379,21 @@ class PPOAgent(PolicyInference):
         self.model.train()
         self.model.running_obs.train()
         self.value_mean_std.train()
+
+    @staticmethod
+    def _fused_record_ok(task):
+        """v2p_rollout_record reads the task's buffers through raw pointers with the layouts of HumanoidSMPLIM hard-coded (int64 reset /
+        terminate flags, float32 [N] rewards, float32 [N,4] sub-rewards, contiguous float32 observations): any other CUDA task - bool or
+        int32 flags, another number of sub-rewards - takes the torch statement of the bookkeeping instead of being misread (advisor r5)."""
+        ex = getattr(task, "extras", None)
+        if not isinstance(ex, dict):
+            return False
+        n = task.num_envs
+        # (the task fills `extras` in its first step: before it, the buffers the entries will alias)
+        term, sub = ex.get("terminate", getattr(task, "_terminate_buf", None)), ex.get("sub_rewards", getattr(task, "_sub_rewards", None))
+        checks = ((task.obs_buf, torch.float32, (n, task.num_obs)), (task.rew_buf, torch.float32, (n,)), (task.reset_buf, torch.int64, (n,)),
+                  (term, torch.int64, (n,)), (sub, torch.float32, (n, 4)))
+        return all(torch.is_tensor(x) and x.is_cuda and x.dtype == dt and tuple(x.shape) == shp and x.is_contiguous() for x, dt, shp in checks)
 
     def get_action_values(self, obs, t, task=None, feat=None, noise=None, value=None, rows=None):
         """im_agent.py:271-294 (`obs['t']` = t).  feat / value: what `_eval_critic` of the step before has already computed for this
@@ -409,7 +444,7 @@ class PPOAgent(PolicyInference):
         overlap = self.overlap_critic and self.reuse_next_values and cuda
         # the after-step bookkeeping as one HIP launch (device tensors, the default rollout); the torch statement of it below stays for CPU
         # tensors (the gloo tests' stub tasks) and for the reference's two-critic-passes variant, and is what the kernel is tested against
-        fused = cuda and self.reuse_next_values and self.fused_record and all(hasattr(g.task, "extras") and g.task.obs_buf.is_contiguous() for g in self.groups)
+        fused = cuda and self.reuse_next_values and self.fused_record and all(self._fused_record_ok(g.task) for g in self.groups)
         if fused:
             for s in st:
                 s["sub"] = torch.zeros(4, dtype=torch.float64, device=self.device)

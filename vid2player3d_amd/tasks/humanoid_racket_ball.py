@@ -19,23 +19,9 @@ import torch
 
 from .. import _lib, racket
 from ..model import load_baked_model
-from .humanoid_smpl_im import HumanoidSMPLIM, SimParams, resolve_contact_solver
+from .humanoid_smpl_im import HumanoidSMPLIM
 
 BALL_R = racket.BALL["radius"]
-
-
-def racket_ball_solver_override(env, sim_params, log=None):
-    """`env["contact_solver"] = "pgs"` when the files only state sim.physx.solver_type = 1 (TGS); returns True when it overrode."""
-    if "contact_solver" in env:
-        return False
-    name, source = resolve_contact_solver(env, sim_params)
-    if name == "pgs":
-        return False
-    env["contact_solver"] = "pgs"
-    if log is not None:
-        log("vid2player3d_amd: %s selects TGS, but the racket-arm joint limits and the ball are built for the engine's PGS solver only: "
-            "running PGS (set env.contact_solver to silence this)" % source)
-    return True
 
 
 class HumanoidSMPLIMRacketBall(HumanoidSMPLIM):
@@ -64,11 +50,9 @@ class HumanoidSMPLIMRacketBall(HumanoidSMPLIM):
         env["body_model"] = model
         # the player MJCF's racket-arm ranges (R_Wrist +-10 / +-45 / +-90 deg, R_Elbow_x <= 90 deg) are enforced like Isaac Gym does
         env.setdefault("joint_limits", True)
-        # The racket-arm limit rows and the ball's rows exist in the engine's PGS solver only.  The reference's tennis configs state
-        # `solver_type: 1` (vid2player/cfg/*.yaml: PhysX TGS), which `resolve_contact_solver` would honour: run PGS and say so, unless
-        # the caller asked for a solver by the engine's own key (then v2p_env_create / v2p_env_attach_ball refuse TGS loudly).
-        sp_probe = sim_params or SimParams.from_cfg(cfg.get("sim"))
-        racket_ball_solver_override(env, sp_probe, log=lambda m: print(m, flush=True))
+        # (the solver is the one the files name: vid2player/cfg/im/tennis_im.yaml:39, embodied_pose/cfg/djokovic_im.yaml:41 state
+        # `solver_type: 1`, TGS - the racket-arm limit rows and the ball's rows are solved inside its slices like the hull rows;
+        # `env.contact_solver` overrides as in the base task)
         self.cfg_v2p = dict(cfg.get("v2p") or {})
         super().__init__(cfg, sim_params, physics_engine, device_type, device_id, headless)
         n, dev = self.num_envs, self.device
