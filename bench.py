@@ -44,6 +44,10 @@ ALGO_BYTES_PER_ENV_STEP = 9896          # SURVEY.md 8(d) per-step total (config 
 ALGO_BYTES_PER_ENV_STEP_AMORTISED = 16090  # + per-epoch reset/context / 32
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_VECTOR_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md
+# the measured VALU issue ceiling of a saturated SIMD (tools/ubench/valu_issue.hip); `cycles` are "nominal cycles at an assumed 2.4 GHz" from
+# HIP-event times of sub-0.3 ms kernels (profiles/r04_valu_issue.txt) unless a round-6 run with in-kernel clocks has replaced the note
+VALU_CEILING = {"cycles": 2.7, "note": "profiles/r04_valu_issue.txt: 2.67 .. 2.88 'nominal cycles at an assumed 2.4 GHz' per v_fma_f32 per SIMD from HIP-event times of "
+                                        "sub-0.3 ms kernels; the clock those kernels ran at was not measured (profiles/r06_valu_issue.txt measures it in-kernel)"}
 HORIZON = 32
 WHOLE_EPOCHS = 10                       # the separately timed whole-epoch block behind a short / ragged --steps
 
@@ -340,12 +344,28 @@ def cpu_baseline(sizes=((4, 32, 3.0), (1024, 8, 5.0), (8192, 3, 12.0)), sigma=0.
 
 
 def profiles_view():
-    """What the committed profiles say about the physics kernel: FLOPs and HBM bytes per launch (labelled from_profiles in the line)."""
+    """What the committed profiles say about the physics kernel: FLOPs and HBM bytes per launch (labelled from_profiles in the line).
+    The counters describe ONE kernel: each file carries the hash of the kernel sources it was collected with
+    (vid2player3d_amd.build.kernel_source_hash) and is DROPPED from the line - null + a warning on stderr - when the sources have moved on."""
+    from vid2player3d_amd import build
+
+    now = build.kernel_source_hash()
+
+    def current(path, j):
+        have = j.get("kernel_source_sha16")
+        if have == now:
+            return True
+        sys.stderr.write("bench.py: %s was collected with kernel sources %s, the library is built from %s: its counters are NOT quoted (roofline.valu / traffic = null); "
+                         "re-run tools/valu_probe.sh / tools/pmc_probe.sh on the GPU box\n" % (os.path.relpath(path, REPO), have or "(unstamped)", now))
+        return False
+
     valu = traffic = None
     vc = os.path.join(REPO, "profiles", "valu_counters.json")
     if os.path.exists(vc):
         try:
             c = json.load(open(vc))
+            if not current(vc, c):
+                raise KeyError("stale")
             g = lambda k: c[k]["avg"]
             lanes = g("SQ_THREAD_CYCLES_VALU") / g("SQ_ACTIVE_INST_VALU")
             wave_ops = 2.0 * g("SQ_INSTS_VALU_FMA_F32") + g("SQ_INSTS_VALU_MUL_F32") + g("SQ_INSTS_VALU_ADD_F32")
@@ -355,9 +375,15 @@ def profiles_view():
                     # what bounds the kernel while its wave slots are full: cycles between two VALU instructions of a SIMD that holds three
                     # waves (SQ_WAVE_CYCLES counts quad-cycles of wave residency) against the issue ceiling of a saturated SIMD measured by
                     # tools/ubench/valu_issue.hip (profiles/r04_valu_issue.txt: 2.67 .. 2.88 nominal cycles per v_fma_f32, 2 .. 8 waves per SIMD)
-                    "valu_issue": {"cycles_per_inst_per_simd_at_3_waves": 4.0 * g("SQ_WAVE_CYCLES") / 3.0 / g("SQ_INSTS_VALU"), "ceiling_cycles_per_inst": 2.7,
-                                   "frac": 2.7 / (4.0 * g("SQ_WAVE_CYCLES") / 3.0 / g("SQ_INSTS_VALU")),
+                    # Two ceilings, both reported: the guide's issue rate the 157.3 TFLOP/s peak assumes (MI355X_MICROARCH.md: a wave64
+                    # v_fma_f32 occupies a SIMD-32 for 2 cycles) and this box's measurement (see VALU_CEILING below)
+                    "valu_issue": {"cycles_per_inst_per_simd_at_3_waves": 4.0 * g("SQ_WAVE_CYCLES") / 3.0 / g("SQ_INSTS_VALU"),
+                                   "ceiling_cycles_per_inst_guide": 2.0, "frac_of_guide_ceiling": 2.0 / (4.0 * g("SQ_WAVE_CYCLES") / 3.0 / g("SQ_INSTS_VALU")),
+                                   "ceiling_cycles_per_inst_measured": VALU_CEILING["cycles"], "ceiling_measured_note": VALU_CEILING["note"],
+                                   "frac_of_measured_ceiling": VALU_CEILING["cycles"] / (4.0 * g("SQ_WAVE_CYCLES") / 3.0 / g("SQ_INSTS_VALU")),
+                                   "frac": 2.0 / (4.0 * g("SQ_WAVE_CYCLES") / 3.0 / g("SQ_INSTS_VALU")), "frac_of": "the guide's 2-cycle wave64 issue (the conservative one)",
                                    "float_math_share_of_valu": (g("SQ_INSTS_VALU_FMA_F32") + g("SQ_INSTS_VALU_MUL_F32") + g("SQ_INSTS_VALU_ADD_F32") + g("SQ_INSTS_VALU_TRANS_F32")) / g("SQ_INSTS_VALU")},
+                    "kernel_source_sha16": c.get("kernel_source_sha16"), "profile_git_head": c.get("git_head"),
                     "source": "from_profiles: " + c.get("source", "profiles/valu_counters.json")}
         except Exception:
             valu = None
@@ -365,7 +391,10 @@ def profiles_view():
     if os.path.exists(pmc):
         try:
             p = json.load(open(pmc))
-            traffic = {"bytes_per_launch": p.get("physics_kernel_hbm_bytes_calibrated", p.get("physics_kernel_hbm_bytes_per_launch")),
+            if not current(pmc, p):
+                raise KeyError("stale")
+            traffic = {"kernel_source_sha16": p.get("kernel_source_sha16"), "profile_git_head": p.get("git_head"),
+                       "bytes_per_launch": p.get("physics_kernel_hbm_bytes_calibrated", p.get("physics_kernel_hbm_bytes_per_launch")),
                        "bytes_per_launch_fetch_x2": p.get("physics_kernel_hbm_bytes_per_launch_fetch_x2"),
                        "note": p.get("calibration_note", "raw FETCH_SIZE + WRITE_SIZE; the guide's gfx950 correction doubles FETCH_SIZE for wide coalesced reads: traffic_fetch_x2 is that upper bound"),
                        "source": "from_profiles: " + p.get("source", "profiles/pmc_summary.json")}
@@ -408,7 +437,7 @@ def run_ppo(args, task, dist, world, rank):
         except Exception:
             rccl = "unknown"
     if rank == 0:
-        out = {"metric": "env-steps/sec at num_envs=8192, SMPL humanoid imitation", "value": world * frames / total, "unit": "env-steps/s", "n_gpus": world,
+        out = {"metric": "env-steps/sec at num_envs=%d, SMPL humanoid imitation" % args.num_envs, "value": world * frames / total, "unit": "env-steps/s", "n_gpus": world,
                "steps": args.ppo_epochs * HORIZON, "warmup": HORIZON, "ms_per_step": 1e3 * total / (args.ppo_epochs * HORIZON), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f16 autocast (update) / f32" if args.ppo_mixed_precision else "f32", "data": "synthetic",
                "config": {"workload": "FULL PPO LOOP (BASELINE config 5 shape, reported separately from the rollout metric): amass_im num_envs=%d per GPU, "
@@ -636,7 +665,8 @@ def main():
                 "traffic": None if traffic is None else traffic["bytes_per_launch"],
                 "traffic_fetch_x2": None if traffic is None else traffic.get("bytes_per_launch_fetch_x2"),
                 "traffic_note": None if traffic is None else traffic.get("note"),
-                "traffic_source": None if traffic is None else traffic["source"], "kernel_ms": k_ms, "kernel_launches_timed": k_cnt,
+                "traffic_source": None if traffic is None else traffic["source"],
+                "traffic_kernel_source_sha16": None if traffic is None else traffic["kernel_source_sha16"], "kernel_ms": k_ms, "kernel_launches_timed": k_cnt,
                 "kernel_ms_region": "whole_epoch block (%d epochs)" % WHOLE_EPOCHS if whole else "the timed steps (whole epochs)",
                 "kernel_ms_source": "HIP events recorded by the engine around %s (launch stream)%s" % (
                     "every physics launch" if k_stride == 1 else "one physics launch in %d" % k_stride,
@@ -660,7 +690,7 @@ def main():
             except Exception:
                 rccl = "unknown"
         out = {
-            "metric": "env-steps/sec at num_envs=8192, SMPL humanoid imitation", "value": value, "unit": "env-steps/s", "n_gpus": world,
+            "metric": "env-steps/sec at num_envs=%d, SMPL humanoid imitation" % n, "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "value_region": "the %d timed steps (whole epochs)" % args.steps if not whole else
                             "whole_epoch block: %d steps = %d whole epochs timed right after the %d requested steps, same barriers (a region that is not whole epochs "
@@ -680,7 +710,8 @@ def main():
                        "timed_epoch_positions": "all, %d times" % (args.steps // HORIZON) if args.steps % HORIZON == 0 else
                                                 ("0..%d" % (args.steps - 1) if args.steps < HORIZON else "all %d times + 0..%d" % (args.steps // HORIZON, args.steps % HORIZON - 1)),
                        "resets_in_timed_region": nresets,
-                       "scaling_curve": "no multi-GPU curve has been measured for this engine (the driver's 8-GPU runs were skipped in rounds 1-3)"},
+                       "scaling_curve": "no multi-GPU curve has been measured for this engine (the driver's 8-GPU runs were skipped in every round so far: "
+                                        "more than one RCCL rank has never run)"},
             "roofline": roof,
         }
         if whole:

@@ -48,6 +48,23 @@ def test_ppo_loop_line_with_two_ranks_and_stub_task():
     assert "world 2" in err and "no multi-GPU curve" in d["config"]["scaling_curve"]
 
 
+def test_self_launch_eight_ranks_with_stub_task():
+    """`bench.py --gpus 8` - the driver's widest launch - through the rank spawn, the barrier, the MAX over ranks and the one line (gloo,
+    stub task: the launch logic, never a measurement).  No 8-GPU node has been available to any round; this is what pins the N = 8 path."""
+    d, _ = _run(["--gpus", "8", "--stub-task", "--steps", "64", "--warmup", "32", "--num-envs", "64"])
+    assert d["n_gpus"] == 8 and d["config"]["world_size_seen"] == 8 and d["config"]["world_size_matches_gpus"] and d["config"]["backend"] == "gloo"
+    assert len(d["config"]["per_rank_env_steps_per_s"]) == 8 and len(d["config"]["per_rank_kernel_ms"]) == 8 and d["config"]["global_envs"] == 512
+    assert d["value"] <= sum(d["config"]["per_rank_env_steps_per_s"]) * (1 + 1e-9) and d["value"] >= 8 * min(d["config"]["per_rank_env_steps_per_s"]) * (1 - 1e-9)
+    assert d["metric"].startswith("env-steps/sec at num_envs=64") and d["scaling"] == "weak"
+
+
+def test_ppo_loop_line_with_eight_ranks_and_stub_task():
+    """BASELINE config 5's launch shape: `bench.py --gpus 8 --ppo` (stub task and stub agent over gloo)."""
+    d, err = _run(["--gpus", "8", "--ppo", "--ppo-epochs", "2", "--stub-task", "--num-envs", "64"])
+    assert d["n_gpus"] == 8 and d["config"]["world_size_seen"] == 8 and d["config"]["world_size_matches_gpus"] and d["config"]["global_envs"] == 512
+    assert d["config"]["fps_total"] <= d["config"]["fps_step"] and "world 8" in err
+
+
 def test_short_run_is_followed_by_a_whole_epoch_block():
     """The driver's command (--steps 20 --warmup 5): every run() starts an epoch, so the timed region is reset + positions 0..19 - the
     line must say so, and carry a separately timed block of whole epochs from which the roofline figures are taken."""

@@ -204,6 +204,99 @@ def test_two_ranks_equal_one_process_on_the_concatenated_batch():
     np.testing.assert_allclose(got[0][4], [float(v.running_mean), float(v.running_var), float(v.count)], rtol=1e-9)
 
 
+# ---------------------------------------------------------------- world 8: even and uneven env shards
+def tiled_batch(m):
+    """the golden 6-env rollout tiled to m envs (env e = golden env e % 6, shifted a little per tile so that no two envs are equal)"""
+    b = golden_batch()
+    idx = torch.arange(m) % N_ENV
+    tile = (torch.arange(m) // N_ENV).float()
+    out = {}
+    for k, v in b.items():
+        x = v[idx].clone()
+        if k in ("obses", "values", "returns", "actions", "mus", "context_feat"):
+            x = x + 0.01 * tile.reshape((m,) + (1,) * (x.dim() - 1))
+        out[k] = x
+    return out
+
+
+def _feat_of(b):
+    return torch.as_tensor(oracle_features(b["obses"].numpy(), b["context_feat"].numpy()))
+
+
+def _rank8_main(rank, world, port, q, bounds, m):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    b = tiled_batch(m)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    shard = {k: v[lo:hi] for k, v in b.items()}
+    agent = make_agent(stub_task(hi - lo))
+    agent.set_train()
+    ds = agent.prepare_dataset(shard, feat_raw=_feat_of(shard))
+    adv = ds["advantages"].clone()
+    per = max(bounds[r + 1] - bounds[r] for r in range(world))
+    for k in range(per):  # minibatch k = env k of every rank's shard (ranks with fewer envs wrap around: every rank joins every all-reduce)
+        j = k % (hi - lo)
+        agent.minibatch_envs = 1
+        agent.calc_gradients({kk: x[j:j + 1] for kk, x in ds.items()})
+    # the north star's all-gather of the advantages: every rank ends with the whole job's, in rank order
+    from vid2player3d_amd import dist as vdist
+    gathered = vdist.all_gather_advantages(adv.transpose(0, 1).contiguous())
+    q.put((rank, adv.numpy(), {k: v.numpy() for k, v in agent.model.state_dict().items()}, agent.model.running_obs.mean.numpy(),
+           [float(agent.value_mean_std.running_mean), float(agent.value_mean_std.running_var), float(agent.value_mean_std.count)], gathered.numpy()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("m,even", [(16, True), (12, False)])
+def test_eight_ranks_hold_identical_replicas_and_global_statistics(m, even):
+    """World 8 over gloo (BASELINE config 5's launch shape; the only multi-rank evidence short of an 8-GPU node): 16 envs as 8 x 2, and 12
+    envs as the uneven shards shard_envs hands out (2,2,2,2,1,1,1,1).  Every rank ends with bit-identical weights and normalisers; the
+    advantages are normalised with the statistics of the WHOLE job; the all-gather returns the whole job's advantages in rank order.  With
+    even shards the replicas also equal ONE process on the concatenated batch (averaging per-rank means = the mean over the union)."""
+    import torch.multiprocessing as mp
+
+    from vid2player3d_amd.dist import shard_envs
+
+    world = 8
+    bounds = [shard_envs(m, r, world)[0] for r in range(world)] + [m]
+    sizes = [bounds[r + 1] - bounds[r] for r in range(world)]
+    assert (len(set(sizes)) == 1) == even and min(sizes) >= 1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + os.getpid() % 2000 + (0 if even else 7)
+    procs = [ctx.Process(target=_rank8_main, args=(r, world, port, q, bounds, m)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=600) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for r in range(1, world):
+        for k in got[0][2]:
+            assert np.array_equal(got[0][2][k], got[r][2][k]), "rank %d holds different weights: %s" % (r, k)
+        assert np.array_equal(got[0][3], got[r][3]) and got[0][4] == got[r][4]
+        assert np.array_equal(got[0][5], got[r][5])
+    # one process on the concatenated batch
+    b = tiled_batch(m)
+    agent = make_agent(stub_task(m))
+    agent.set_train()
+    ds = agent.prepare_dataset(b, feat_raw=_feat_of(b))
+    adv_all = np.concatenate([g[1] for g in got], axis=0)
+    np.testing.assert_allclose(adv_all, ds["advantages"].numpy(), rtol=1e-5, atol=1e-6)          # global advantage statistics
+    np.testing.assert_allclose(got[0][5].transpose(1, 0), adv_all, rtol=0, atol=0)               # the all-gather: rank order, uneven shards trimmed
+    v = agent.value_mean_std
+    np.testing.assert_allclose(got[0][4], [float(v.running_mean), float(v.running_var), float(v.count)], rtol=1e-9)  # merged moments are exact for any shard sizes
+    if even:
+        for k in range(sizes[0]):
+            idx = torch.tensor([bounds[r] + k for r in range(world)])
+            agent.calc_gradients({kk: x[idx] for kk, x in ds.items()})
+        for k, w in agent.model.state_dict().items():
+            assert np.abs(got[0][2][k] - w.numpy()).max() <= 0.02 * float(G["grad/lr"]) * sizes[0] + 1e-7, k
+        np.testing.assert_allclose(got[0][3], agent.model.running_obs.mean.numpy(), rtol=1e-5, atol=1e-6)
+
+
 def _bcast_main(rank, world, port, q, ckpt):
     import torch.distributed as dist
     from vid2player3d_amd.ppo import PPOAgent

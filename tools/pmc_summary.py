@@ -34,6 +34,11 @@ def main(fetch_db, write_db, out_path):
                                "FETCH_SIZE = 0.500 x bytes read at both widths, WRITE_SIZE = 1.000 x bytes of full-line stores, 32 B per isolated 4-byte store) and on "
                                "env_context_kernel's known 594.5 MB of output (WRITE_SIZE 1.006 x); `traffic` is the calibrated figure, the raw sum stays in the summary",
            "all_kernels": {k: {"fetch_KiB": f.get(k, {}).get("avg_KiB"), "write_KiB": w.get(k, {}).get("avg_KiB")} for k in sorted(set(f) | set(w)) if "v2p" in k}}
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from vid2player3d_amd import build
+
+    res["kernel_source_sha16"] = build.kernel_source_hash()  # (bench.py quotes these bytes only while the kernel's sources still hash to this)
     json.dump(res, open(out_path, "w"), indent=1)
     print(json.dumps(res, indent=1))
 

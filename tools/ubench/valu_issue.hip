@@ -3,9 +3,12 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float f2 __attribute__((ext_vector_type(2)));
-constexpr int ITER = 4096;
+constexpr int ITER = 32768;  // (round 6: 8 x longer - ~1 ms kernels, past launch overhead and clock ramp)
 
-template <int MODE> __global__ void k(float* out, float seed) {
+// clk (nullable): per wave, [shader-clock cycles (s_memtime), constant 100 MHz ticks (s_memrealtime)] spent in the loop - the clock the
+// SIMD actually ran at = cycles / ticks x 100 MHz, and the issue interval in REAL cycles instead of "nominal cycles at an assumed 2.4 GHz"
+template <int MODE> __global__ void k(float* out, float seed, long long* clk) {
+    const long long c0 = clock64(), w0 = wall_clock64();
     float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     f2 p0{a0, a1}, p1{a2, a3}, p2{a4, a5}, p3{a6, a7}, p4{a1, a0}, p5{a3, a2}, p6{a5, a4}, p7{a7, a6};
     const float m = 1.0000001f, c = 1e-9f;
@@ -26,22 +29,31 @@ template <int MODE> __global__ void k(float* out, float seed) {
             for (int j = 0; j < 4; ++j) { a0 = a0 * m + c; a1 = a1 * m + c; }
         }
     }
+    if (clk && threadIdx.x == 0) { clk[2 * blockIdx.x] = clock64() - c0; clk[2 * blockIdx.x + 1] = wall_clock64() - w0; }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p2.x + p3.x + p4.x + p5.x + p6.x + p7.y;
 }
 
 template <int MODE> void run(const char* name, int waves_per_simd, float* d) {
     const int cus = 256, blocks = cus * 4 * waves_per_simd;  // one wave per block: spread over all SIMDs
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(64), 0, 0, d, 1.f);
+    static long long* clk = nullptr;
+    if (!clk) hipMalloc(&clk, sizeof(long long) * 2 * 256 * 4 * 8);
+    for (int warm = 0; warm < 3; ++warm) hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(64), 0, 0, d, 1.f, nullptr);  // (clock ramp)
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(64), 0, 0, d, 1.f);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(64), 0, 0, d, 1.f, clk);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double insts_per_wave = 8.0 * ITER;
     const double cyc = ms * 1e-3 * 2.4e9;  // at 2.4 GHz nominal
-    printf("%-34s waves/SIMD %d: %.3f ms  -> %.2f cycles per wave-instruction (per wave), %.2f cycles per instruction per SIMD\n", name, waves_per_simd, ms,
-           cyc / insts_per_wave, cyc / (insts_per_wave * waves_per_simd));
+    static long long h[2 * 256 * 4 * 8];
+    hipMemcpy(h, clk, sizeof(long long) * 2 * blocks, hipMemcpyDeviceToHost);
+    double sc = 0, sw = 0;
+    for (int i = 0; i < blocks; ++i) { sc += (double)h[2 * i]; sw += (double)h[2 * i + 1]; }
+    sc /= blocks; sw /= blocks;
+    printf("%-34s waves/SIMD %d: %.3f ms  -> %.2f nominal cycles (2.4 GHz, HIP events) per instruction per SIMD | in-kernel: s_memtime %.0f, s_memrealtime %.0f ticks per wave "
+           "-> s_memtime / s_memrealtime = %.3f (x 100 MHz = %.0f MHz if s_memtime counts shader clocks), %.2f s_memtime cycles per instruction per SIMD\n", name, waves_per_simd, ms,
+           cyc / (insts_per_wave * waves_per_simd), sc, sw, sc / sw, 100.0 * sc / sw, sc / (insts_per_wave * waves_per_simd));
 }
 
 int main() {

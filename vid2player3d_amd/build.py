@@ -33,11 +33,26 @@ def needs_build():
 
 def build_info():
     """What the bench line records about the build."""
-    return {"arch": ARCH, "physics_ll_math": "precise" if os.environ.get("V2P_LL_STRICT_MATH") else "relaxed (" + " ".join(LL_MATH_FLAGS) + "; precise device libraries, strict pre-physics prologue)",
+    return {"arch": ARCH, "kernel_source_sha16": kernel_source_hash(), "physics_ll_math": "precise" if os.environ.get("V2P_LL_STRICT_MATH") else "relaxed (" + " ".join(LL_MATH_FLAGS) + "; precise device libraries, strict pre-physics prologue)",
             "hipcc": _hipcc()}
 
 
 LL_MATH_FLAGS = ["-fassociative-math", "-freciprocal-math", "-fno-signed-zeros", "-fno-trapping-math", "-fno-honor-nans"]
+# what the physics kernel is compiled from: the counters kept under profiles/ (VALU instructions, HBM bytes per launch) describe ONE
+# kernel; they carry this hash, and bench.py drops them from its line when the sources have moved on
+KERNEL_SOURCES = ["physics_ll.hip", "phys_common.hpp", "phys_math.hpp", "hull_gjk.hpp", "post_ops.inc", "v2p_math.inc", "motion_sample.inc", "v2p_internal.hpp", "v2p_dev.hpp"]
+
+
+def kernel_source_hash():
+    """sha256 (16 hex digits) of the sources of physics_ll_kernel and of the flags it is built with."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for s in KERNEL_SOURCES:
+        with open(os.path.join(CSRC, s), "rb") as f:
+            h.update(s.encode() + b"\0" + f.read() + b"\0")
+    h.update(" ".join(LL_MATH_FLAGS + [os.environ.get("V2P_LL_STRICT_MATH", ""), os.environ.get("V2P_FLAGS_PHYSICS_LL", "")]).encode())
+    return h.hexdigest()[:16]
 
 
 def build(force=False, verbose=False, lib_out=None, tag=""):
