@@ -44,12 +44,11 @@ ALGO_BYTES_PER_ENV_STEP = 9896          # SURVEY.md 8(d) per-step total (config 
 ALGO_BYTES_PER_ENV_STEP_AMORTISED = 16090  # + per-epoch reset/context / 32
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_VECTOR_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md
-# the measured VALU issue ceiling of a saturated SIMD (tools/ubench/valu_issue.hip); `cycles` are "nominal cycles at an assumed 2.4 GHz" from
-# HIP-event times of sub-0.3 ms kernels (profiles/r04_valu_issue.txt) unless a round-6 run with in-kernel clocks has replaced the note
-VALU_CEILING = {"cycles": 2.7, "note": "profiles/r04_valu_issue.txt: 2.67 .. 2.88 'nominal cycles at an assumed 2.4 GHz' per v_fma_f32 per SIMD from HIP-event times of "
-                                        "sub-0.3 ms kernels; the clock those kernels ran at was not measured (profiles/r06_valu_issue.txt measures it in-kernel)"}
-HORIZON = 32
-WHOLE_EPOCHS = 10                       # the separately timed whole-epoch block behind a short / ragged --steps
+# the measured VALU issue ceiling of a saturated SIMD (tools/ubench/valu_issue.hip cu, tools/valu_issue_probe.sh), in cycles of the clock the
+# microbenchmark was MEASURED to run at
+VALU_CEILING = {"cycles": 2.34, "note": "profiles/r06_valu_issue.txt (tools/valu_issue_probe.sh): one workgroup per CU, 4 waves of dependent v_fma_f32 chains on every SIMD, "
+                                         "4 x 262144 instructions per SIMD in 1.100 ms = 1.049 ns each at a MEASURED 2228 MHz (GRBM_GUI_ACTIVE / 8 XCDs / kernel time) = 2.34 cycles "
+                                         "(2.38 at 2 waves); round 4's 2.67 - 2.88 were 'nominal cycles at an assumed 2.4 GHz' of sub-0.3 ms kernels, launch overhead included"}
 
 
 # ---------------------------------------------------------------------------------------------- launching the ranks
@@ -383,6 +382,7 @@ def profiles_view():
                                    "frac_of_measured_ceiling": VALU_CEILING["cycles"] / (4.0 * g("SQ_WAVE_CYCLES") / 3.0 / g("SQ_INSTS_VALU")),
                                    "frac": 2.0 / (4.0 * g("SQ_WAVE_CYCLES") / 3.0 / g("SQ_INSTS_VALU")), "frac_of": "the guide's 2-cycle wave64 issue (the conservative one)",
                                    "float_math_share_of_valu": (g("SQ_INSTS_VALU_FMA_F32") + g("SQ_INSTS_VALU_MUL_F32") + g("SQ_INSTS_VALU_ADD_F32") + g("SQ_INSTS_VALU_TRANS_F32")) / g("SQ_INSTS_VALU")},
+                    "kernel_clock_mhz": (c.get("clock_mhz") or {}).get("avg"),
                     "kernel_source_sha16": c.get("kernel_source_sha16"), "profile_git_head": c.get("git_head"),
                     "source": "from_profiles: " + c.get("source", "profiles/valu_counters.json")}
         except Exception:
