@@ -37,3 +37,20 @@ def golden_task_ops():
 @pytest.fixture(scope="session")
 def golden_env_trace():
     return load_golden("env_trace.npz")
+
+
+# ---- the large reference-pinned fixtures (oracle/gen_golden_large.py: OUTPUTS of the reference at BASELINE config 2's size; the inputs are
+# regenerated from their seeds by oracle/golden_inputs.py)
+@pytest.fixture(scope="session")
+def golden_task_ops_1024():
+    return load_golden("task_ops_1024.npz")
+
+
+@pytest.fixture(scope="session")
+def golden_motion_state_4096():
+    return load_golden("motion_state_4096.npz")
+
+
+@pytest.fixture(scope="session")
+def golden_env_trace_1024():
+    return load_golden("env_trace_1024.npz")

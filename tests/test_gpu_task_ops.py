@@ -443,3 +443,79 @@ def test_test_mode_starts_every_clip_at_its_first_frame():
     task.reset()
     assert float(task._reset_ref_motion_times.abs().max()) == 0.0 and float(task._cur_ref_motion_times.abs().max()) == 0.0
     task.close()
+
+
+# ---------------------------------------------------------------- the reference's outputs at BASELINE config 2's size (VERDICT r5 #4b):
+# 4096 motion-state queries, 1024 envs of task ops, a 1024-env x 32-step epoch - recorded by oracle/gen_golden_large.py from the reference's
+# own Python; the inputs are regenerated from their seeds (oracle/golden_inputs.py), the HIP kernels meet the REFERENCE's numbers directly
+def test_motion_state_4096_queries_match_the_reference(mlib, golden_tables, golden_motion_state_4096):
+    from oracle import golden_inputs as GI
+
+    g = golden_motion_state_4096
+    ids, times = GI.motion_state_queries(golden_tables)
+    assert np.array_equal(ids[:8], g["ids_check"]) and np.array_equal(times[:8], g["times_check"])
+    res = mlib.get_motion_state(T(ids, torch.long), T(times), return_rigid_body=True, adjust_height=True, ground_tolerance=0.0)
+    for name, r in zip(O.MOTION_STATE_NAMES, res):
+        close(N(r)[:len(g[name])], g[name], 5e-6, name + " (4096 queries)")
+
+
+def test_task_ops_on_1024_envs_match_the_reference(golden_task_ops_1024):
+    from oracle import golden_inputs as GI
+    from vid2player3d_amd import _lib
+
+    g, x = golden_task_ops_1024, GI.task_ops_inputs()
+    lib = _lib.load()
+    n = GI.N_LARGE
+    rew, sub = _reward(lib, x, n)
+    close(sub[:, :3], g["sub_rewards"][:, :3], 5e-6, "sub[dof,vel,pos] (1024 envs)")
+    close(sub[:, 3], g["sub_rewards"][:, 3], 2e-4, "sub[rot] (1024 envs)")
+    close(rew, g["reward"], 5e-5, "reward (1024 envs)")
+    h = x["reset_heights"].astype(np.float32).copy()
+    h[[7, 3]] = -np.inf
+    rst, term = torch.empty(n, dtype=torch.long, device=DEV), torch.empty(n, dtype=torch.long, device=DEV)
+    prog, rb, ct, cl = T(x["reset_progress"], torch.long), T(x["reset_rb_pos"]), T(x["reset_cur_time"]), T(x["reset_clip_len"])
+    _lib.check(lib.v2p_reset_flags(n, _lib.ptr(prog), _lib.ptr(rb), (C.c_float * 24)(*h.tolist()), _lib.ptr(ct), _lib.ptr(cl), 300.0, 1, _lib.ptr(rst), _lib.ptr(term), None),
+               "v2p_reset_flags")
+    assert np.array_equal(N(rst), g["reset_out"]) and np.array_equal(N(term), g["terminate_out"])
+    r = GI.OBS734_ROWS
+    obs = torch.empty((r, 734), device=DEV)
+    args = [T(x[k][:r]) for k in ("body_pos", "body_rot", "tgt_pos", "tgt_rot", "dof_pos", "dof_vel", "tgt_dof_pos", "body_vel", "body_ang_vel", "obs734_motion_bodies")]
+    _lib.check(lib.v2p_obs_imitation(r, *[_lib.ptr(a) for a in args], None, None, 0.0, _lib.ptr(obs), None), "v2p_obs_imitation")
+    close(N(obs), g["obs734"], 5e-6, "obs734 (256 rows)")
+
+
+def test_env_trace_of_1024_envs_matches_the_reference(mlib, golden_tables, golden_env_trace_1024):
+    """One epoch of the reference's own HumanoidSMPLIM on 1024 envs (physics teacher-forced): reward, sub-rewards, sticky flags, progress and
+    clip time of EVERY env at EVERY step, the in-place action masking, full observation and target rows of the 32 sampled envs - through
+    reset / pre_physics_step / post_physics_step of the engine's task."""
+    from oracle import golden_inputs as GI
+
+    g = golden_env_trace_1024
+    n, steps, S = int(g["n"]), int(g["steps"]), g["sample_envs"]
+    ids = GI.env_trace_motion_ids(golden_tables, n)
+    task = make_task(n, mlib, motion_ids=ids)
+    task.reset_with_times(None, T(g["reset_motion_times"]))
+    close(N(task._humanoid_root_states), g["reset_root_states"], 5e-6, "reset root states")
+    close(N(task.obs_buf)[S], g["reset_obs_sample"], 5e-6, "reset obs")
+    close(N(task.context_feat)[S[:8]], g["context_feat_sample"], 5e-6, "context_feat")
+    assert np.array_equal(N(task.context_mask).astype(np.uint8), g["context_mask"])
+    for i in range(steps):
+        x = GI.env_trace_step_inputs(golden_tables, ids, g["reset_motion_times"], i)
+        a = T(x["actions"])
+        task.pre_physics_step(a)
+        assert np.array_equal((N(a) == 0).all(axis=1).astype(np.uint8), g["actions_masked_rows"][i]), i
+        task._dof_pos[:] = T(x["dof_pos"])
+        task._dof_vel[:] = T(x["dof_vel"])
+        task._rigid_body_state.view(n, 24, 13)[:] = T(x["rb_state"])
+        task._humanoid_root_states[:] = T(x["rb_state"][:, 0, :])
+        task._reset_env_tensors(None, with_rb_state=True)
+        task.post_physics_step()
+        close(N(task.rew_buf), g["rew"][i], 1e-4, "rew %d" % i)
+        close(N(task.extras["sub_rewards"]), g["sub_rewards"][i], 5e-4, "sub_rewards %d" % i)
+        assert np.array_equal(N(task.reset_buf), g["reset"][i]) and np.array_equal(N(task.extras["terminate"]), g["terminate"][i]), i
+        assert np.array_equal(N(task.progress_buf), g["progress"][i]), i
+        close(N(task._cur_ref_motion_times), g["cur_time"][i], 1e-6, "cur_time %d" % i)
+        close(N(task.obs_buf)[S], g["obs_sample"][i], 5e-6, "obs %d" % i)
+        tgt = np.concatenate([N(getattr(task, "_target_" + k))[S].reshape(len(S), -1) for k in O.MOTION_STATE_NAMES], axis=1)
+        close(tgt, g["target_sample"][i], 5e-6, "target %d" % i)
+    task.close()

@@ -101,3 +101,73 @@ def test_env_trace(golden_tables, golden_env_trace):
             close(task.cur_time, g[p + "cur_time"], 1e-6, p + "cur_time")
             for k, name in enumerate(T.MOTION_STATE_NAMES):
                 close(task.target[k], g[p + "target_" + name], 5e-6, p + "target_" + name)
+
+
+# ---------------------------------------------------------------- the same functions at BASELINE config 2's size (VERDICT r5 #4b): the
+# reference's outputs on 1024 envs / 4096 queries / a 1024-env x 32-step epoch; inputs regenerated from their seeds
+def test_large_motion_state(golden_tables, golden_motion_state_4096):
+    from oracle import golden_inputs as GI
+
+    g = golden_motion_state_4096
+    ids, times = GI.motion_state_queries(golden_tables)
+    assert len(ids) == int(g["q"]) == 4096 and np.array_equal(ids[:8], g["ids_check"]) and np.array_equal(times[:8], g["times_check"])
+    res = T.get_motion_state(golden_tables, ids, times, adjust_height=True, ground_tolerance=0.0)
+    for name, r in zip(T.MOTION_STATE_NAMES, res):
+        close(r[:len(g[name])], g[name], 5e-6, name)
+    assert (times < 0).sum() > 100 and (times > golden_tables["motion_lengths"][ids]).sum() > 100  # both ends are exercised
+
+
+def test_large_task_ops(golden_task_ops_1024):
+    from oracle import golden_inputs as GI
+
+    g, x = golden_task_ops_1024, GI.task_ops_inputs()
+    assert int(g["n"]) == GI.N_LARGE == len(x["dof_pos"])
+    close(T.dof_to_obs(x["dof_pos"]), g["dof_obs"], what="dof_obs")
+    rew, sub = T.compute_humanoid_reward(x["body_pos"], x["body_rot"], x["tgt_pos"], x["tgt_rot"], x["dof_pos"], x["dof_vel"], x["tgt_dof_pos"], x["tgt_dof_vel"],
+                                         x["body_pos_weights"])
+    close(sub[:, :3], g["sub_rewards"][:, :3], 5e-6, "sub_rewards[dof,vel,pos]")
+    close(sub[:, 3], g["sub_rewards"][:, 3], 2e-4, "sub_rewards[rot]")
+    close(rew, g["reward"], 5e-5, "reward")
+    rst, term = T.compute_humanoid_reset(x["reset_progress"], x["reset_rb_pos"], x["reset_heights"], x["reset_cur_time"], x["reset_clip_len"])
+    assert np.array_equal(rst, g["reset_out"]) and np.array_equal(term, g["terminate_out"]) and term.sum() > 50 and (rst - term).sum() > 50
+    a, pd_tar, pd_torque, force, torque = T.pre_physics(x["pre_actions"], x["pre_reset"], x["dof_pos"], x["body_rot"][:, 0], x["pre_kp"])
+    close(pd_tar, g["pre_pd_tar"], 0.0, "pd_tar")
+    close(pd_torque, g["pre_pd_torque"], 1e-6, "pd_torque")
+    close(force, g["pre_res_force"], 2e-6, "res_force")
+    close(torque, g["pre_res_torque"], 2e-6, "res_torque")
+    assert x["pre_reset"].sum() > 10 and (a[x["pre_reset"] == 1] == 0).all()
+    r = GI.OBS734_ROWS
+    o = T.obs_imitation_734(x["body_pos"][:r], x["body_rot"][:r], x["tgt_pos"][:r], x["tgt_rot"][:r], x["dof_pos"][:r], x["dof_vel"][:r], x["tgt_dof_pos"][:r],
+                            x["body_vel"][:r], x["body_ang_vel"][:r], x["obs734_motion_bodies"][:r])
+    close(o, g["obs734"], 5e-6, "obs734")
+
+
+def test_large_env_trace(golden_tables, golden_env_trace_1024):
+    """TaskOracle over one epoch of 1024 envs against what the reference's own HumanoidSMPLIM recorded: reward, sub-rewards, sticky flags,
+    progress and clip time of every env at every step; full observation and target rows of the sampled envs."""
+    from oracle import golden_inputs as GI
+    from vid2player3d_amd.model import load_baked_model
+
+    g = golden_env_trace_1024
+    n, steps, S = int(g["n"]), int(g["steps"]), g["sample_envs"]
+    ids = GI.env_trace_motion_ids(golden_tables, n)
+    task = T.TaskOracle(golden_tables, ids, load_baked_model().kp.astype(np.float32))
+    task.reset_all(g["reset_motion_times"])
+    close(task.root_states, g["reset_root_states"], 5e-6, "reset root states")
+    close(task.obs_buf[S], g["reset_obs_sample"], 5e-6, "reset obs")
+    close(task.context_feat[S[:8]], g["context_feat_sample"], 5e-6, "context_feat")
+    assert np.array_equal(task.context_mask.astype(np.uint8), g["context_mask"])
+    for i in range(steps):
+        x = GI.env_trace_step_inputs(golden_tables, ids, g["reset_motion_times"], i)
+        out = task.pre_physics_step(x["actions"])
+        assert np.array_equal((out[0] == 0).all(axis=1).astype(np.uint8), g["actions_masked_rows"][i]), i
+        task.set_sim_state(x["dof_pos"], x["dof_vel"], x["rb_state"])
+        task.post_physics_step()
+        close(task.rew_buf, g["rew"][i], 1e-4, "rew %d" % i)
+        close(task.sub_rewards, g["sub_rewards"][i], 5e-4, "sub_rewards %d" % i)
+        assert np.array_equal(task.reset_buf, g["reset"][i]) and np.array_equal(task.terminate_buf, g["terminate"][i]), i
+        assert np.array_equal(task.progress_buf, g["progress"][i]), i
+        close(task.cur_time, g["cur_time"][i], 1e-6, "cur_time %d" % i)
+        close(task.obs_buf[S], g["obs_sample"][i], 5e-6, "obs %d" % i)
+        close(np.concatenate([t[S].reshape(len(S), -1) for t in task.target], axis=1), g["target_sample"][i], 5e-6, "target %d" % i)
+    assert g["terminate"][-1].sum() >= 20 and (g["reset"][-1] - g["terminate"][-1]).sum() >= 0 and g["reset"][20].sum() > g["reset"][19].sum()
