@@ -480,6 +480,7 @@ def main():
     ap.add_argument("--actions-per-step", action="store_true", help="stand-in policy evaluated before every step (one elementwise kernel between the physics launches) instead of once per epoch from the context window")
     ap.add_argument("--action-noise", type=float, default=0.17, help="sigma of the stand-in policy (0.17 = SURVEY 8d; small values = tracking-quality actions, fewer falls)")
     ap.add_argument("--solver", choices=["pgs", "tgs"], default="pgs")
+    ap.add_argument("--friction-frame", choices=["world", "velocity"], default="world", help="v2p_sim_cfg.friction_frame (ABI 14): tangent frame of the hull x ground friction rows; 'velocity' is a labelled variant")
     ap.add_argument("--freeze-terminated", action="store_true", help="opt-in engine feature: terminated envs are not simulated until the epoch reset (not reference behaviour)")
     ap.add_argument("--djokovic", action="store_true", help="BASELINE config 4 (djokovic_im.yaml: terminationHeadHeight -0.5, faster clips)")
     ap.add_argument("--job-mono", type=int, default=None, help="v2p_sim_cfg.job_mono_permille (tuning sweeps)")
@@ -544,7 +545,7 @@ def main():
         tasks = [build_task(n // G, local_rank, seed=7 + rank + 100 * g, contact=not args.no_contact, per_clip_shapes=args.per_clip_shapes, num_shapes=args.num_shapes, djokovic=args.djokovic or args.racket_ball,
                           freeze=args.freeze_terminated, solver=args.solver, racket_ball=args.racket_ball, substep_jobs=bool(args.substep_jobs),
                           joint_limits=args.joint_limits,
-                          env_extra={k: v for k, v in (("job_mono_permille", args.job_mono), ("pair_mix_permille", args.pair_mix), ("kernel_build", args.kernel_build), ("ball_body_contacts", None if args.ball_body_contacts else False)) if v is not None})  # per-rank seed like run.py:37
+                          env_extra={k: v for k, v in (("job_mono_permille", args.job_mono), ("pair_mix_permille", args.pair_mix), ("kernel_build", args.kernel_build), ("ball_body_contacts", None if args.ball_body_contacts else False), ("friction_frame", None if args.friction_frame == "world" else args.friction_frame)) if v is not None})  # per-rank seed like run.py:37
                  for g in range(G)]
         task = tasks[0]
     if args.ppo:
@@ -698,7 +699,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "amass_im num_envs=%d per GPU, %s, imitation reward, per-epoch reset+context every %d steps, %s synthetic clips, action noise %.3g%s"
                                    % (n, "PD control only (no contact solve)" if args.no_contact else "full contact %s (4 substeps x 4 iterations)" % args.solver.upper(), HORIZON,
-                                      args.num_shapes if args.per_clip_shapes else 64, args.action_noise, (", one NON-UNIFORM body shape per clip (%d shapes from vertex clouds, %d clips)" % (args.num_shapes, args.num_shapes) if args.per_clip_shapes else "") + (", djokovic_im variant" if args.djokovic or args.racket_ball else "") + (", RACKET + BALL in every env (reported separately)" if args.racket_ball else "") + (", joint limits on" if (args.joint_limits if args.joint_limits is not None else args.racket_ball) else "") +
+                                      args.num_shapes if args.per_clip_shapes else 64, args.action_noise, (", one NON-UNIFORM body shape per clip (%d shapes from vertex clouds, %d clips)" % (args.num_shapes, args.num_shapes) if args.per_clip_shapes else "") + (", djokovic_im variant" if args.djokovic or args.racket_ball else "") + (", RACKET + BALL in every env (reported separately)" if args.racket_ball else "") + (", joint limits on" if (args.joint_limits if args.joint_limits is not None else args.racket_ball) else "") + (", VELOCITY-ALIGNED FRICTION FRAME (variant)" if args.friction_frame == "velocity" else "") +
                                       (", %d ROLLOUT GROUPS of %d envs on %d streams (reported separately from the headline)" % (G, ng, G) if G > 1 else "") +
                                       (", stand-in policy evaluated once per epoch (targets = context frames)" if per_epoch else ", stand-in policy evaluated before every step") + (", TERMINATED ENVS FROZEN (not reference behaviour)" if args.freeze_terminated else "") + (", STUB TASK (launch-logic test, not a measurement)" if stub else "")),
                        "num_envs_per_gpu": n, "global_envs": world * n, "parallelism": "env-sharded x%d, no data-path collective" % world,

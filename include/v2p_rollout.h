@@ -34,7 +34,7 @@ extern "C" {
 #define V2P_NUM_OBS 461
 #define V2P_MOTION_STATE_DIM 331  /* root_pos3 root_rot4 dof_pos69 root_vel3 root_ang_vel3 dof_vel69 key_pos12 rb_pos72 rb_rot96 */
 #define V2P_CONTEXT_DIM 378       /* body_pos72 body_rot96 dof_pos69 body_pos_gt72 dof_pos_gt69 (humanoid_smpl_im.py:202) */
-#define V2P_ABI_VERSION 13
+#define V2P_ABI_VERSION 14
 
 typedef enum {
     V2P_OK = 0,
@@ -295,6 +295,15 @@ typedef struct {
     int32_t job_len;            /* substeps per job; 0 = the engine decides (1, or 2 for launches of >= CUs x 32 env pairs) */
     int32_t job_lead;           /* substeps of the FIRST job of a cut pair; 0 = the engine decides, < 0 = like the other jobs */
     int32_t job_no_interleave;  /* 1: the jobs of a pair are not interleaved with those of other pairs in dispatch order (A/B) */
+    /* ---- ABI 14 */
+    int32_t friction_frame;     /* tangent directions of the hull x ground rows.  0 (default) = world: t1 = x, t2 = y, each clamped to mu x the
+                                 * normal impulse on its own - the friction limit is a box aligned with the world axes (a body pushed along the
+                                 * diagonal holds up to sqrt(2) mu).  1 = velocity: t1 along the tangential velocity the contact point has under
+                                 * the unconstrained velocity of the substep (where it would slide without contact impulses), t2 = n x t1; world
+                                 * frame below 1e-6 m/s - the limit along the direction of sliding is mu whatever that direction is.  The
+                                 * reference hands mu = 1 to PhysX (humanoid_smpl.py:175-182, amass_im.yaml:32-35), whose friction directions
+                                 * follow the relative velocity at the contact; which of the two agrees with an Isaac Gym trace is for
+                                 * tools/replay_trace.py --friction-frame to show.  Link-per-lane schedule (both solvers, ball, joint limits). */
 } v2p_sim_cfg;
 
 /* Caller-owned DEVICE buffers the engine reads/writes; these are the tensors the reference

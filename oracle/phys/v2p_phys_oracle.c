@@ -75,6 +75,12 @@ typedef struct {
     int joint_limits;      /* 1: DOFs whose range is narrower than a full turn get a limit row (see the substep) */
     double limit_margin;   /* 0.05 rad: the row exists only while C < limit_margin + h max(0, approach rate of v*) */
     double rest_offset;    /* 0.0 (sim.physx.rest_offset): the gap of a hull-vertex row is z - rest_offset */
+    int friction_frame;    /* 0 = world (t1 = x, t2 = y: the friction limit of a hull x ground point is a box aligned with the world axes);
+                            * 1 = velocity: t1 along the tangential velocity the contact point has under v* (the unconstrained velocity of the
+                            * substep: where the point would slide without contact impulses), t2 = n x t1; below 1e-6 m/s the world frame.
+                            * PhysX aligns its friction directions with the relative velocity at the contact; which of the two is closer to
+                            * Isaac Gym is for a trace to say (tools/replay_trace.py --friction-frame).  Hull x ground rows only: the ball's
+                            * rows keep the basis of their normal. */
 } v2p_oparams;
 
 /* ---- racket + ball (vid2player/env/tasks/humanoid_smpl_im_mvae.py:367-442, 711-783; data/assets/tennis_ball.urdf,
@@ -826,7 +832,7 @@ static int substep_impl(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s
             if (r->body >= 0 && r->kind != 3) body_jacobian(m, &k, r->body, J);
             for (int a = 0; a < 3; ++a) {
                 int row = 3 * c + a;
-                double *jr = &Jr[row * NDT], *tr = &Tr[row * NDT];
+                double *jr = &Jr[row * NDT];
                 if (r->kind == 3) { /* rows 1, 2 of a limit stay empty (skipped by the sweep) */
                     if (a > 0) { wii[row] = 1.0; continue; }
                     jr[6 + 3 * (r->body - 1) + r->vert] = r->n[0];
@@ -855,6 +861,27 @@ static int substep_impl(const v2p_omodel *m, const v2p_oparams *p, v2p_ostate *s
                         }
                     }
                 }
+            }
+            if (r->kind == 0 && p->friction_frame == 1) {
+                /* friction frame of a hull x ground point from the tangential velocity it has under v* (the rows are linear in their direction) */
+                double *j1 = &Jr[(3 * c + 1) * NDT], *j2 = &Jr[(3 * c + 2) * NDT], vx = 0, vy = 0;
+                for (int col = 0; col < ND; ++col) { vx += j1[col] * v[col]; vy += j2[col] * v[col]; }
+                const double sp = sqrt(vx * vx + vy * vy);
+                if (sp > 1e-6) {
+                    const double cx = vx / sp, cy = vy / sp;
+                    for (int col = 0; col < ND; ++col) {
+                        const double a1 = j1[col], a2 = j2[col];
+                        j1[col] = cx * a1 + cy * a2;
+                        j2[col] = -cy * a1 + cx * a2;
+                    }
+                    rows[c].t1[0] = cx; rows[c].t1[1] = cy; rows[c].t1[2] = 0;
+                    rows[c].t2[0] = -cy; rows[c].t2[1] = cx; rows[c].t2[2] = 0;
+                }
+            }
+            for (int a = 0; a < 3; ++a) {
+                int row = 3 * c + a;
+                double *jr = &Jr[row * NDT], *tr = &Tr[row * NDT];
+                if (r->kind == 3 && a > 0) continue;
                 memcpy(tr, jr, sizeof(double) * NDT);
                 chol_solve(M, ND, tr);
                 if (ball) for (int l = 0; l < 3; ++l) { tr[ND + l] /= bp->mass; tr[ND + 3 + l] /= bp->inertia; }

@@ -28,7 +28,7 @@ class OModel(C.Structure):
 class OParams(C.Structure):
     _fields_ = [("h", C.c_double), ("gravity_z", C.c_double), ("mu", C.c_double), ("contact_offset", C.c_double), ("max_depen_vel", C.c_double),
                 ("ang_damp", C.c_double), ("max_ang_vel", C.c_double), ("erp", C.c_double), ("n_iter", C.c_int), ("enable_contact", C.c_int), ("solver_type", C.c_int),
-                ("joint_limits", C.c_int), ("limit_margin", C.c_double), ("rest_offset", C.c_double)]
+                ("joint_limits", C.c_int), ("limit_margin", C.c_double), ("rest_offset", C.c_double), ("friction_frame", C.c_int)]
 
 
 class OCyl(C.Structure):
@@ -84,7 +84,7 @@ def lib_fast():
 def default_params(h=1.0 / 120.0, enable_contact=True, **kw):
     """amass_im.yaml:37-52 + humanoid_smpl_im.py:273-276."""
     p = OParams(h=h, gravity_z=-9.81, mu=1.0, contact_offset=0.02, max_depen_vel=10.0, ang_damp=0.01, max_ang_vel=100.0, erp=0.2, n_iter=4,
-                enable_contact=int(enable_contact), solver_type=0, joint_limits=0, limit_margin=0.05, rest_offset=0.0)
+                enable_contact=int(enable_contact), solver_type=0, joint_limits=0, limit_margin=0.05, rest_offset=0.0, friction_frame=0)
     for k, v in kw.items():
         setattr(p, k, v)
     return p

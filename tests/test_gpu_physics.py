@@ -78,6 +78,7 @@ def _run_pair(mlib, n, contact, seed, lift=0.0, vel_sigma=0.5, steps=1, hold="fi
     par.joint_limits = int(limits)
     if "limit_margin" in env:
         par.limit_margin = float(env["limit_margin"])
+    par.friction_frame = {"world": 0, "velocity": 1}[env.get("friction_frame", "world")]
     par.rest_offset = float(((env.get("sim_overrides") or {}).get("physx") or {}).get("rest_offset", 0.0))
     if shapes is None:
         oracle = BatchOracle(task.body_model, len(ids_o), par)
@@ -207,6 +208,27 @@ def test_tgs_option_matches_oracle(mlib):
     assert np.abs(got["rb"][..., 7:] - got_p["rb"][..., 7:]).max() > 1e-3
 
 
+@pytest.mark.parametrize("solver", ["pgs", "tgs"])
+def test_velocity_aligned_friction_frame_matches_oracle(mlib, solver):
+    """v2p_sim_cfg.friction_frame = velocity (ABI 14): the tangent rows of every hull x ground point along / across the tangential velocity
+    the point has under v*; kernel (its own instantiation) against the oracle on every env, standing and fallen, either solver, with the
+    racket arm's limit rows in the sweep as well; and the frame does change the result (sliding contacts)."""
+    from vid2player3d_amd.model import load_baked_model
+    from vid2player3d_amd.racket import with_racket
+
+    for seed, lift, sig, extra, what in ((2, 0.0, 0.5, {}, "standing"), (3, -0.75, 0.2, {}, "fallen"), (13, -0.5, 3.0, {}, "fast"),
+                                         (62, -0.75, 0.2, dict(limits=True, body_model=with_racket(load_baked_model())[0], act_sigma=0.5), "fallen + limits")):
+        what = "vfric %s %s" % (what, solver)
+        pairs = _run_pair(mlib, 48, contact=True, seed=seed, lift=lift, vel_sigma=sig, steps=2, solver=solver, what=what, friction_frame="velocity", **extra)
+        for got, ref in pairs:
+            _compare(got, ref, what)
+        (got_w, _), = _run_pair(mlib, 48, contact=True, seed=seed, lift=lift, vel_sigma=sig, solver=solver, what=what + " (world twin)", **extra)
+        d = np.abs(pairs[0][0]["rb"][..., 7:] - got_w["rb"][..., 7:]).max(axis=(1, 2))
+        print("[vfric] %s: body velocities differ from the world-frame run in %d of 48 envs (max %.3f m/s)" % (what, int((d > 1e-3).sum()), d.max()))
+        if lift < 0:
+            assert (d > 1e-3).mean() > 0.25
+
+
 @pytest.mark.parametrize("build", [1, 2])
 def test_both_builds_of_the_kernel_match_oracle(mlib, build):
     """The library holds two builds of the link-per-lane kernel (v2p_sim_cfg.kernel_build: 1 = contact records parked in LDS, three waves
@@ -221,7 +243,8 @@ def test_both_builds_of_the_kernel_match_oracle(mlib, build):
     task.close()
     for kw in (dict(contact=True, seed=2, lift=0.0), dict(contact=True, seed=2, lift=-0.1, solver="tgs"), dict(contact=False, seed=1),
                dict(contact=True, seed=62, lift=-0.75, vel_sigma=0.2, limits=True, body_model=with_racket(load_baked_model())[0], act_sigma=0.5),
-               dict(contact=True, seed=62, lift=-0.75, vel_sigma=0.2, limits=True, solver="tgs", body_model=with_racket(load_baked_model())[0], act_sigma=0.5)):
+               dict(contact=True, seed=62, lift=-0.75, vel_sigma=0.2, limits=True, solver="tgs", body_model=with_racket(load_baked_model())[0], act_sigma=0.5),
+               dict(contact=True, seed=3, lift=-0.75, vel_sigma=0.2, friction_frame="velocity")):
         what = "build %d %s" % (build, " ".join("%s=%s" % (k, v) for k, v in kw.items() if k in ("contact", "solver", "limits", "lift")))
         (got, ref), = _run_pair(mlib, 48, what=what, kernel_build=build, **kw)
         _compare(got, ref, what, contact=kw["contact"])
@@ -541,7 +564,7 @@ def test_substep_jobs_are_invisible(mlib, n):
 
 @pytest.mark.parametrize("build", [1, 2])
 @pytest.mark.parametrize("what,env", [("tgs", dict(contact_solver="tgs")), ("pd only", dict(enable_contact=False)), ("limits", dict(joint_limits=True)),
-                                      ("limits tgs", dict(joint_limits=True, contact_solver="tgs"))])
+                                      ("limits tgs", dict(joint_limits=True, contact_solver="tgs")), ("vfric", dict(friction_frame="velocity"))])
 def test_substep_jobs_are_invisible_in_every_instantiation(mlib, what, env, build):
     """TGS, the contact-free kernel and the joint-limit kernel cut into substep jobs (forced: at this size the engine would keep whole
     control steps per workgroup) == one workgroup per env pair, bit for bit, over several steps incl. the fused post-physics; in either
@@ -881,8 +904,11 @@ def test_rest_contact_supports_the_weight_at_full_size(mlib):
     task.close()
 
 
-def test_engine_obeys_the_closed_form_friction_law(mlib):
-    """Closed-form facts of the contact model, on the HIP ENGINE itself (tests/test_phys_oracle.py checks the same on the float64 oracle):
+@pytest.mark.parametrize("frame", ["world", "velocity"])
+def test_engine_obeys_the_closed_form_friction_law(mlib, frame):
+    """(frame = velocity, v2p_sim_cfg.friction_frame 1: t1 along the tangential velocity of the point under v* - the limit is mu in every
+    direction: the diagonal push lets go at 1.3 with (alpha - mu) g, where the world-aligned box still holds.)
+    Closed-form facts of the contact model, on the HIP ENGINE itself (tests/test_phys_oracle.py checks the same on the float64 oracle):
     a rigid box on the plane (the root link of a 24-link model whose other links are 0.1 g points on stiff drives, far from the ground),
     pushed horizontally at its centre of mass with alpha x its weight through the residual-force actions (a slope of tan(theta) = alpha),
     mu = 1: along a tangent axis it sticks at alpha = 0.9 and slides with (alpha - mu) g at 1.1; along the DIAGONAL it still sticks at 1.3
@@ -903,9 +929,10 @@ def test_engine_obeys_the_closed_form_friction_law(mlib):
     blob = dict(bm.blob, local_pos=lp)
     from vid2player3d_amd.model import BodyModel
     bm = BodyModel(blob, default_humanoid_mass=float(bm.mass.sum()))
-    cases = [(0.9, (1, 0)), (1.1, (1, 0)), (1.3, (1, 1)), (1.5, (1, 1)), (0.9, (0, 1)), (1.1, (0, -1))]
+    cases = [(0.9, (1, 0)), (1.1, (1, 0)), (1.3, (1, 1)), (1.5, (1, 1)), (0.9, (0, 1)), (1.1, (0, -1)), (0.9, (1, 1)), (1.3, (0.3, -1.0))]
     n = len(cases)
-    task = make_task(n, mlib, body_model=bm, residual_force_hold="all", terminationHeadHeight=-0.5, enableEarlyTermination=False, debug_contacts=1)
+    task = make_task(n, mlib, body_model=bm, residual_force_hold="all", terminationHeadHeight=-0.5, enableEarlyTermination=False, debug_contacts=1, friction_frame=frame)
+    assert task.friction_frame == frame
     task.reset_with_times(None, torch.full((n,), 0.1, device=DEV))
     root = np.zeros((n, 13), np.float32)
     root[:, 2], root[:, 3:7] = 0.1, BASEQ
@@ -935,10 +962,15 @@ def test_engine_obeys_the_closed_form_friction_law(mlib):
     mu = 1.0
     for e, (alpha, d) in enumerate(cases):
         along = v[:, e] @ dirs[e]
-        limit = mu * (np.sqrt(2.0) if abs(d[0]) == abs(d[1]) else 1.0)
-        if alpha < limit:
+        dn = np.abs(dirs[e])
+        # world frame: a box aligned with x / y - each component of the push is held up to mu on its own, what exceeds it accelerates that axis;
+        # velocity frame: the limit is mu along the push
+        acc = np.sign(dirs[e]) * np.maximum(alpha * dn - mu, 0.0) * 9.81 if frame == "world" else dirs[e] * max(alpha - mu, 0.0) * 9.81
+        want = float(acc @ dirs[e]) * t
+        if want == 0.0:
             assert np.abs(v[-10:, e]).max() < 1e-2 and abs(along[-1] - along[-11]) / (10 / 30.0) < 0.005 * 9.81, (e, alpha, np.abs(v[-10:, e]).max())
         else:
-            want = (alpha - limit) * 9.81 * t
             assert abs(along[-1] - want) < 0.06 * want and np.all(np.diff(along) > 0), (e, alpha, along[-1], want)
+            if frame == "velocity":  # ... and the box slides ALONG the push, not along a world axis
+                assert np.linalg.norm(v[-1, e] - along[-1] * dirs[e]) < 0.03 * want, (e, v[-1, e], along[-1] * dirs[e])
     task.close()

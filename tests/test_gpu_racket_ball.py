@@ -139,6 +139,14 @@ def test_ball_step_with_six_substeps_per_simulate_call(mlib, mode, solver):
     _ball_step_vs_oracle(mlib, mode, 0.0, True, "djokovic", substeps=6, solver=solver)
 
 
+@pytest.mark.parametrize("solver", ["pgs", "tgs"])
+@pytest.mark.parametrize("mode", ["hit", "body"])
+def test_ball_step_with_the_velocity_aligned_friction_frame(mlib, mode, solver):
+    """v2p_sim_cfg.friction_frame = velocity in the racket + ball instantiations (limit rows on): the feet's friction rows turn with their
+    sliding direction, the ball's rows keep the basis of their normal; kernel vs oracle on every env."""
+    _ball_step_vs_oracle(mlib, mode, 0.0, True, "djokovic", solver=solver, friction_frame="velocity")
+
+
 def _ball_step_vs_oracle(mlib, mode, lift, limits, player, shapes=None, substeps=2, n=32, subset=None, steps=2, solver="pgs", **env):
     """subset: the envs that get an oracle (all by default); every comparison is restricted to them."""
     env = dict(env, contact_solver=solver)
@@ -164,7 +172,8 @@ def _ball_step_vs_oracle(mlib, mode, lift, limits, player, shapes=None, substeps
     for e in sub:
         if shapes is not None:
             bm = task.body_shapes[task._env_shape_ids[e]]
-        o = PhysOracle(bm, default_params(h=1.0 / (60.0 * substeps), joint_limits=int(limits), solver_type={"pgs": 0, "tgs": 1}[solver]), kp=bm.kp.astype(np.float32), kd=bm.kd.astype(np.float32))
+        o = PhysOracle(bm, default_params(h=1.0 / (60.0 * substeps), joint_limits=int(limits), solver_type={"pgs": 0, "tgs": 1}[solver],
+                                           friction_frame={"world": 0, "velocity": 1}[env.get("friction_frame", "world")]), kp=bm.kp.astype(np.float32), kd=bm.kd.astype(np.float32))
         o.set_state(root[e], dpos[e], dvel[e])
         o.attach_ball(task.racket_geometry)
         oracles.append(o)

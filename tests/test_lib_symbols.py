@@ -39,7 +39,7 @@ def test_binding_covers_the_header():
 def test_abi_version_and_error_string(lib):
     lib.v2p_abi_version.restype = ctypes.c_int
     lib.v2p_last_error.restype = ctypes.c_char_p
-    assert lib.v2p_abi_version() == 13
+    assert lib.v2p_abi_version() == 14
     assert isinstance(lib.v2p_last_error(), bytes)
 
 

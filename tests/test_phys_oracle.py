@@ -234,11 +234,11 @@ def box_model(model, half=(0.25, 0.25, 0.1), mass=10.0):
     return BodyModel(blob, default_humanoid_mass=float(m.sum()))  # (gain scale 1)
 
 
-def _push_box(model, alpha, direction, steps=30, mu=1.0):
+def _push_box(model, alpha, direction, steps=30, mu=1.0, friction_frame=0):
     """The box at rest on the plane, pushed horizontally at its centre of mass with alpha x its weight along `direction` for `steps`
     control steps: a slope of tan(theta) = alpha in the frame of the plane.  Returns the box's horizontal velocity after every step."""
     bm = box_model(model)
-    o = PhysOracle(bm, default_params(mu=mu, ang_damp=0.0))
+    o = PhysOracle(bm, default_params(mu=mu, ang_damp=0.0, friction_frame=friction_frame))
     root = np.zeros(13)
     root[2] = 0.1
     root[6] = 1.0  # identity: the box's z is the world's
@@ -286,6 +286,24 @@ def test_friction_limit_is_a_pyramid_aligned_with_the_world_axes(model):
     want = (1.5 - np.sqrt(2.0)) * 9.81 * t
     assert abs(v[-1] @ d - want) < 0.06 * want, (v[-1] @ d, want)
     assert abs(v[-1][0] - v[-1][1]) < 1e-3 * v[-1][0]  # symmetric in x and y (Gauss-Seidel visits t1 before t2: 1e-4 relative)
+
+
+def test_velocity_aligned_friction_frame_is_isotropic(model):
+    """v2p_oparams.friction_frame = 1 (v2p_sim_cfg.friction_frame "velocity"): t1 of a hull x ground point lies along the tangential velocity
+    the point has under v*, so the friction limit along the direction of sliding is mu whatever that direction is: pushed along the DIAGONAL
+    the box now lets go above mu - it slides at alpha = 1.3 with (alpha - mu) g, where the world-aligned box (friction_frame 0) still holds -
+    and sticks at 0.9; along x nothing changes.  (The switch exists so that the first Isaac Gym trace can choose, tools/replay_trace.py.)"""
+    g = 9.81
+    for direction in ([1, 1, 0], [1, 0, 0], [0.3, -1.0, 0]):
+        v, d = _push_box(model, 0.9, direction, friction_frame=1)
+        assert np.abs(v[-10:]).max() < 1e-2, (direction, np.abs(v[-10:]).max())              # below mu: sticks, in every direction
+        v, d = _push_box(model, 1.3, direction, friction_frame=1)
+        t = len(v) / 30.0
+        want = 0.3 * g * t
+        assert abs(v[-1] @ d - want) < 0.06 * want, (direction, v[-1] @ d, want)              # above mu: (alpha - mu) g along the push
+        assert np.linalg.norm(v[-1][:2] - (v[-1] @ d) * d[:2]) < 0.02 * want                  # ... and only along it
+    v0, d = _push_box(model, 1.3, [1, 1, 0], friction_frame=0)
+    assert np.abs(v0[-10:]).max() < 1e-2                                                      # the world-aligned box holds the same push
 
 
 def test_ball_bounces_above_the_threshold_velocity_only():

@@ -8,7 +8,7 @@ through this engine on an MI355X:
       run, and the result compared with the recorded state of step i+1 (this is the number that pins - or quantifies the distance of -
       the engine's own physics model against PhysX; with the synthetic golden trace it only shows that the tool runs).
 
-    python tools/replay_trace.py trace.npz --motion mlib.npz [--body-model blob.npz]
+    python tools/replay_trace.py trace.npz --motion mlib.npz [--body-model blob.npz] [--friction-frame world|velocity] [--solver pgs|tgs]
 """
 import argparse
 import sys
@@ -29,6 +29,9 @@ def main():
     ap.add_argument("trace")
     ap.add_argument("--motion", required=True, help="flat motion tables (.npz) of the recorded run")
     ap.add_argument("--body-model", help="compiled body model blob (.npz); default: the baked amass_v1 asset")
+    ap.add_argument("--friction-frame", choices=["world", "velocity"], default="world",
+                    help="tangent frame of the hull x ground friction rows (v2p_sim_cfg.friction_frame): run both and keep the one the trace agrees with")
+    ap.add_argument("--solver", choices=["pgs", "tgs"], default=None, help="contact solver (default: the engine's, PGS); the reference's yaml names TGS")
     args = ap.parse_args()
     dev = "cuda:0"
     T = lambda x, dt=torch.float32: torch.as_tensor(np.ascontiguousarray(x)).to(device=dev, dtype=dt).contiguous()  # noqa: E731
@@ -38,6 +41,9 @@ def main():
         lib = MotionLib({k: z[k] for k in z.files}, dev)
     n = len(g["motion_ids"])
     cfg = default_cfg(n, motion_lib=lib, record_pd_torque=True, motion_ids=g["motion_ids"], body_shape_mismatch="warn")  # a trace names its own body; the baked one is used here
+    cfg["env"]["friction_frame"] = args.friction_frame
+    if args.solver:
+        cfg["env"]["contact_solver"] = args.solver
     if args.body_model:
         with np.load(args.body_model) as z:
             cfg["env"]["body_model"] = BodyModel({k: z[k] for k in z.files})

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "libv2p_rollout.so")
 
 NUM_BODIES, NUM_DOF, NUM_ACTIONS, NUM_OBS = 24, 69, 75, 461
 MOTION_STATE_DIM, CONTEXT_DIM = 331, 378
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 c_f = C.POINTER(C.c_float)
 c_i32 = C.POINTER(C.c_int32)
@@ -44,7 +44,8 @@ class SimCfg(C.Structure):
                 ("solver_type", C.c_int32), ("substep_jobs", C.c_int32), ("job_mono_permille", C.c_int32), ("pair_mix_permille", C.c_int32), ("debug_contacts", C.c_int32),
                 ("joint_limits", C.c_int32), ("limit_margin", C.c_float),
                 ("rest_offset", C.c_float), ("bounce_threshold_velocity", C.c_float), ("num_velocity_iterations", C.c_int32), ("kernel_build", C.c_int32),
-                ("job_timeout_spins", C.c_int32), ("job_len", C.c_int32), ("job_lead", C.c_int32), ("job_no_interleave", C.c_int32)]
+                ("job_timeout_spins", C.c_int32), ("job_len", C.c_int32), ("job_lead", C.c_int32), ("job_no_interleave", C.c_int32),
+                ("friction_frame", C.c_int32)]
 
 
 class EnvBuffers(C.Structure):

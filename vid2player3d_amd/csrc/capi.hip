@@ -427,6 +427,8 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
         delete e;
         return V2P_ERR_INVALID;
     }
+    if (c->friction_frame != 0 && c->friction_frame != 1) { set_error("v2p_env_create: friction_frame must be 0 (world) or 1 (velocity)"); delete e; return V2P_ERR_INVALID; }
+    if (c->friction_frame == 1 && c->schedule == 1) { set_error("v2p_env_create: the env-per-lane cross-check kernel solves in the world friction frame only"); delete e; return V2P_ERR_UNSUPPORTED; }
     if (c->joint_limits && (c->schedule == 1 || !c->enable_contact)) {
         set_error("v2p_env_create: joint_limits needs the link-per-lane schedule and contacts on");
         delete e;
@@ -450,6 +452,7 @@ static int env_create_impl(const v2p_model* const* shapes, int32_t num_shapes, c
     p.joint_limits = c->joint_limits ? 1 : 0;
     p.limit_margin = c->limit_margin <= 0.f ? 0.05f : c->limit_margin;  // (a zero-initialised cfg gets the default)
     p.rest_offset = c->rest_offset;
+    p.friction_frame = c->friction_frame;
     p.bounce_threshold = c->bounce_threshold_velocity;
     p.context_length = c->context_length; p.context_padding = c->context_padding;
     p.dt = (float)c->control_freq_inv * c->sim_dt;
@@ -876,6 +879,7 @@ int v2p_env_set_schedule(v2p_env* e, int schedule) {
     if (!e || (schedule != 0 && schedule != 1)) { set_error("v2p_env_set_schedule: bad argument"); return V2P_ERR_INVALID; }
     if (schedule == 1 && e->num_shapes > 1) { set_error("v2p_env_set_schedule: the env-per-lane kernel handles single-shape batches only"); return V2P_ERR_UNSUPPORTED; }
     if (schedule == 1 && e->p.solver_type == 1) { set_error("v2p_env_set_schedule: the env-per-lane cross-check kernel solves PGS only"); return V2P_ERR_UNSUPPORTED; }
+    if (schedule == 1 && e->p.friction_frame == 1) { set_error("v2p_env_set_schedule: the env-per-lane cross-check kernel solves in the world friction frame only"); return V2P_ERR_UNSUPPORTED; }
     if (schedule == 1 && e->p.joint_limits) { set_error("v2p_env_set_schedule: the env-per-lane cross-check kernel has no joint limits"); return V2P_ERR_UNSUPPORTED; }
     if (schedule == 1) {
         DeviceGuard g(e->device);

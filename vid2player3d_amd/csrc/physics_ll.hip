@@ -347,6 +347,16 @@ struct ContactStore<true> {
     __device__ __forceinline__ void set_lam(int c, V3 v) { p[(PARK_CL + 3 * c) * 64] = v.x; p[(PARK_CL + 3 * c + 1) * 64] = v.y; p[(PARK_CL + 3 * c + 2) * 64] = v.z; }
 };
 
+// friction frame of a hull x ground point from the link's v* (w0, xd0) and the point's offset rr: t1 along the tangential velocity of the
+// point, t2 = z x t1; below 1e-6 m/s the world frame (oracle: v2p_oparams.friction_frame = 1)
+__device__ __forceinline__ void vfric_frame(const V3& w0, const V3& xd0, const V3& rr, V3& t1, V3& t2) {
+    const float vx = xd0.x + w0.y * rr.z - w0.z * rr.y, vy = xd0.y + w0.z * rr.x - w0.x * rr.z;
+    const float s2 = vx * vx + vy * vy;
+    const bool on = s2 > 1e-12f;
+    const float inv = on ? rsqrtf(s2) : 0.f;
+    t1 = on ? V3{vx * inv, vy * inv, 0.f} : V3{1.f, 0.f, 0.f};
+    t2 = V3{-t1.y, t1.x, 0.f};
+}
 // TGS: temporal Gauss-Seidel with frozen Jacobians (v2p_sim_cfg.solver_type 1; the model is stated in oracle/phys/v2p_phys_oracle.c):
 // cbias[] then holds the GAP of each point, advanced after every sweep, and the row bias is evaluated where it is used.
 // DIAG: the per-phase cycle counters (V2P_PHASE_TIMING) and per-wave timeline stamps (V2P_WAVE_TIMES) are compiled into a separate
@@ -366,7 +376,13 @@ struct ContactStore<true> {
 // the contact block of link b.  A limit impulse is a joint-space impulse: it enters the propagation as the link's `un`, and its
 // reaction (-impulse, a pure torque) joins what the link hands up to its parent.  The inverse mass of the rows is the joint-space
 // inverse inertia K = Di + ((T - 1)^T G (T - 1))_ww = Lambda_b,ww - H1 - H1^T + Lambda_parent,ww in the notation of the recursion below.
-template <bool CONTACT, bool MULTI, bool TGS, bool DIAG, bool BALL, bool JOBS, bool LIMITS>
+// VFRIC: v2p_sim_cfg.friction_frame = velocity (ABI 14; the model is stated in oracle/phys/v2p_phys_oracle.c).  The tangent rows of a hull x
+// ground point lie along / across the tangential velocity the point has under v* (the link's velocity at the start of the sweep, which
+// stays parked in the PARK_W0 / PARK_XD0 slots of the lane's LDS column for the whole sweep) instead of along world x / y: the frame is
+// re-derived from those six floats at every visit of the link (one rsqrt per point) - eight more floats per lane of LDS to keep it would
+// cost the third wave per SIMD.  An instantiation of its own: with general tangent directions the rows lose the zeros the world frame
+// gives them (~+40 % instructions in the friction rows), which the default kernel must not pay.
+template <bool CONTACT, bool MULTI, bool TGS, bool DIAG, bool BALL, bool JOBS, bool LIMITS, bool VFRIC = false>
 __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (LIMITS ? V2P_LL_WPS_LIMITS : V2P_LL_WPS))) void physics_ll_kernel(PhysArgs a) {
     constexpr bool WALK = V2P_LL_WALK != 0;  // the sweep as one walk over the tree (see the sweep)
     const int64_t N = a.n;
@@ -1545,6 +1561,7 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                 float tgs_irem = 1.f / h;                // TGS: 1 / (time left in the substep) for separated points
                 const float tgs_pen = P.erp / hs;
                 auto rowbias = [&](float v) -> float { return TGS ? (v >= 0.f ? v * tgs_irem : fmaxf(tgs_pen * v, -P.max_depen)) : v; };
+                static_assert(!VFRIC || (WALK && CONTACT), "the velocity-aligned friction frame exists in the walk form of the sweep");
                 if constexpr (WALK) {
                 // ---- the sweep as ONE WALK over the tree.  Solving the touched links one by one in ascending order visits them in depth-first
                 // order, cyclically, iteration after iteration (back and forth with the experimental ALT switch below); between two of them only
@@ -1863,11 +1880,15 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                             float bias4[4];
 #pragma unroll
                             for (int c = 0; c < 4; ++c) { rr4[c] = CS.cr(c); lam4[c] = CS.lam(c); bias4[c] = CS.bias(c); }
+                            V3 ws0{0.f, 0.f, 0.f}, xs0{0.f, 0.f, 0.f};  // VFRIC: v* of the link
+                            if constexpr (VFRIC) { ws0 = park_get3(PARK_W0); xs0 = park_get3(PARK_XD0); }
 #pragma unroll
                             for (int c = 0; c < 4; ++c) {
                                 const bool active = c < cnt;
                                 if (!any64(active)) break;  // uniform over the (at most two) touched links solved here
                                 const V3 rr = rr4[c];
+                                V3 t1{1.f, 0.f, 0.f}, t2{0.f, 1.f, 0.f};
+                                if constexpr (VFRIC) vfric_frame(ws0, xs0, rr, t1, t2);
                                 const V3 lam0 = lam4[c];
                                 float ln = lam0.x, l1 = lam0.y, l2 = lam0.z;
                                 // a point without normal impulse (hence without friction impulses: they are clamped to mu x normal)
@@ -1878,7 +1899,7 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                                 if (!any64(act)) continue;
 #pragma unroll
                                 for (int ax = 0; ax < 3; ++ax) {
-                                    const V3 dir = ax == 0 ? V3{0.f, 0.f, 1.f} : (ax == 1 ? V3{1.f, 0.f, 0.f} : V3{0.f, 1.f, 0.f});
+                                    const V3 dir = ax == 0 ? V3{0.f, 0.f, 1.f} : (VFRIC ? (ax == 1 ? t1 : t2) : (ax == 1 ? V3{1.f, 0.f, 0.f} : V3{0.f, 1.f, 0.f}));
                                     const V3 jn = cross(rr, dir);
                                     const V3 yw = mul(Lam.A, jn) + mul(Lam.B, dir);
                                     const V3 yv = V3{dot(col(Lam.B, 0), jn), dot(col(Lam.B, 1), jn), dot(col(Lam.B, 2), jn)} + mul(Lam.C, dir);
@@ -2236,6 +2257,18 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
         }
 
         LLPH(6);
+        V3 cimp_v{0.f, 0.f, 0.f};  // VFRIC: net contact impulse of this link's ground points, world axes (v* is about to leave its slots)
+        if constexpr (VFRIC && CONTACT) {
+            const V3 ws0 = park_get3(PARK_W0), xs0 = park_get3(PARK_XD0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < cnt) {
+                    V3 t1, t2;
+                    vfric_frame(ws0, xs0, CS.cr(c), t1, t2);
+                    const V3 lc = CS.lam(c);
+                    cimp_v = cimp_v + V3{lc.y * t1.x + lc.z * t2.x, lc.y * t1.y + lc.z * t2.y, lc.x};
+                }
+        }
         q = Q4{park[PARK_Q * 64], park[(PARK_Q + 1) * 64], park[(PARK_Q + 2) * 64], park[(PARK_Q + 3) * 64]};
         x = park_get3(PARK_X);
         // ================================================================ velocities -> generalized, damping, clamp, integrate
@@ -2346,9 +2379,12 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
             V3 cforce{0.f, 0.f, 0.f};
             if (CONTACT) {
                 const float ih = 1.f / h;
+                if constexpr (VFRIC) cforce = ih * cimp_v;
+                else {
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (c < cnt) { const V3 lc = CS.lam(c); cforce.z += lc.x * ih; cforce.x += lc.y * ih; cforce.y += lc.z * ih; }
+                    for (int c = 0; c < 4; ++c)
+                        if (c < cnt) { const V3 lc = CS.lam(c); cforce.z += lc.x * ih; cforce.x += lc.y * ih; cforce.y += lc.z * ih; }
+                }
                 if (BALL) cforce = cforce - park_get3(PARK_W0);
             }
             if (last) {
@@ -2783,7 +2819,7 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s, float* actions, int* fuse
         set_error("physics: racket + ball runs with contacts on");
         return V2P_ERR_UNSUPPORTED;
     }
-    if (diag && env->p.enable_contact && !tgs && !multi && !env->ball && !env->p.joint_limits) {
+    if (diag && env->p.enable_contact && !tgs && !multi && !env->ball && !env->p.joint_limits && env->p.friction_frame == 0) {
         hipLaunchKernelGGL((physics_ll_kernel<true, false, false, true, false, false, false>), grid, block, lds, s, a);
     } else {
         int rc0;
@@ -2791,8 +2827,12 @@ int launch_env_physics_ll(v2p_env* env, hipStream_t s, float* actions, int* fuse
         if (rc0 != V2P_OK) return rc0;
         with_post();
         const bool lim = env->p.joint_limits != 0, ball = env->ball != nullptr, con = env->p.enable_contact != 0;
+        const bool vfric = env->p.friction_frame == 1 && con;
 #define V2P_LL_LAUNCH(C, T, B, L) do { \
-            if (multi) hipLaunchKernelGGL((physics_ll_kernel<C, true, T, false, B, true, L>), jgrid, block, lds, s, a); \
+            if (vfric && C) { \
+                if (multi) hipLaunchKernelGGL((physics_ll_kernel<C, true, T, false, B, true, L, C>), jgrid, block, lds, s, a); \
+                else hipLaunchKernelGGL((physics_ll_kernel<C, false, T, false, B, true, L, C>), jgrid, block, lds, s, a); \
+            } else if (multi) hipLaunchKernelGGL((physics_ll_kernel<C, true, T, false, B, true, L>), jgrid, block, lds, s, a); \
             else hipLaunchKernelGGL((physics_ll_kernel<C, false, T, false, B, true, L>), jgrid, block, lds, s, a); } while (0)
         if (lim && ball && tgs) V2P_LL_LAUNCH(true, true, true, true);
         else if (lim && ball) V2P_LL_LAUNCH(true, false, true, true);

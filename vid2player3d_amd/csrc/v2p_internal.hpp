@@ -100,6 +100,7 @@ struct EnvParams {
     float limit_margin;     // ... that exist only while C < limit_margin + h max(0, approach rate of v*)
     float rest_offset;      // gap of a hull-vertex row = z - rest_offset (sim.physx.rest_offset)
     float bounce_threshold; // sim.physx.bounce_threshold_velocity (the humanoid's rows have restitution 0: kept for the record)
+    int friction_frame;     // 0 world (t1 = x, t2 = y), 1 velocity (t1 along the tangential velocity of the point under v*): hull x ground rows
     int context_length, context_padding;
     float dt;              // control step
     float term_heights[NB];

@@ -465,6 +465,12 @@ class HumanoidSMPLIM:
         c.job_len = int(env.get("job_len", 0))
         c.job_lead = int(env.get("job_lead", 0))
         c.job_no_interleave = int(env.get("job_no_interleave", 0))
+        # tangent frame of the hull x ground friction rows (v2p_sim_cfg.friction_frame, ABI 14): "world" (x / y, the default) | "velocity"
+        ff = env.get("friction_frame", "world")
+        if ff not in ("world", "velocity"):
+            raise ValueError("env.friction_frame = %r: 'world' or 'velocity'" % (ff,))
+        c.friction_frame = {"world": 0, "velocity": 1}[ff]
+        self.friction_frame = ff
         # joint ranges of the MJCF enforced as limit rows (Isaac Gym always enforces them; only the racket arm of the player MJCFs has
         # DOFs narrower than a full turn, the amass MJCF has none)
         c.joint_limits = int(env.get("joint_limits", False))
