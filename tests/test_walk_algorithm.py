@@ -3,7 +3,7 @@ Gauss-Seidel with a dense inverse mass matrix: float64 model on the SMPL tree (o
 import numpy as np
 import pytest
 
-from oracle.walk_model import Tree, random_rows, sweep_dense, sweep_walk
+from oracle.walk_model import Tree, blocks_cost, delassus_blocks, random_rows, sweep_blocks, sweep_dense, sweep_walk
 
 SMPL_PARENTS = [-1, 0, 1, 2, 3, 0, 5, 6, 7, 0, 9, 10, 11, 12, 11, 14, 15, 16, 17, 11, 19, 20, 21, 22]  # SURVEY 8 a14 (MJCF body order)
 CASES = {
@@ -81,3 +81,40 @@ def test_random_touched_sets():
             vw, lw = sweep_walk(t, v0, rows, n_iter=4, alternate=alternate)
             assert max(abs(ld[k2] - lw[k2]) for k2 in ld) < 1e-9, (touched, alternate)
             assert max(np.abs(vd[j] - vw[j]).max() for j in range(t.n)) < 1e-9, (touched, alternate)
+
+
+# ---------------------------------------------------------------- round 6: the Delassus-block form - counted, not built
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_delassus_block_form_equals_the_dense_sweep(name):
+    """Step 1 of the verdict's plan: Gauss-Seidel with precomputed Lambda_ba blocks between the touched links (no tree walk inside the
+    iterations, one pass over the tree at the end) reproduces the row-wise sweep to 1e-9 - the form is exact; whether it PAYS is the count
+    below."""
+    rng = np.random.default_rng(7 + len(name))
+    t = Tree(SMPL_PARENTS, rng)
+    v0 = [rng.normal(size=6) for _ in range(t.n)]
+    rows = random_rows(t, CASES[name], rng)
+    vd, ld = sweep_dense(t, v0, rows, n_iter=4)
+    vb, lb = sweep_blocks(t, v0, rows, n_iter=4)
+    assert max(abs(ld[k] - lb[k]) for k in ld) < 1e-9
+    assert max(np.abs(vd[j] - vb[j]).max() for j in range(t.n)) < 1e-9
+    blk = delassus_blocks(t, sorted(CASES[name]))
+    for (b, a), m in blk.items():
+        assert np.allclose(m, t.lam_dense(b, a), atol=1e-10), (b, a)
+
+
+def test_the_count_says_the_blocks_do_not_pay_at_four_sweeps():
+    """The count (docs/NOTES.md D).  Building Lambda_ba takes SIX unit-impulse propagations between every pair of touched links - three
+    with the symmetry Lambda_ab = Lambda_ba^T - where the 4-sweep walk makes FOUR real ones along the tour of the links, and the blocks
+    still have to be applied (one 6x6 matvec per pair per sweep, about a level step each).  For the standing humanoid (two feet: ankles +
+    toes) and for the 2 / 4 / 7-link cases the verdict names, the block form costs MORE level-step equivalents than the walk - the >= 15 %
+    saving that would have justified building it is not there, at any of the three sizes."""
+    t = Tree(SMPL_PARENTS, np.random.default_rng(1))
+    out = {}
+    for name, touched in (("2 links (the two ankles)", [3, 7]), ("4 links (two feet: ankles + toes)", [3, 4, 7, 8]), ("7 links (fallen, scattered)", [2, 4, 6, 13, 18, 21, 23])):
+        c = blocks_cost(t, touched, n_iter=4)
+        out[name] = c
+        print("[delassus count] %-36s walk %3d level steps | blocks: build %3d (%3d with symmetry) + use %3d matvecs = %3d  -> x %.2f of the walk"
+              % (name, c["walk_level_steps"], c["blocks_build_level_vectors"], c["blocks_build_with_symmetry"], c["blocks_use_matvecs"],
+                 c["blocks_total_with_symmetry"], c["blocks_total_with_symmetry"] / c["walk_level_steps"]))
+        assert c["blocks_total_with_symmetry"] > 0.85 * c["walk_level_steps"], name  # no 15 % saving anywhere
+    assert out["4 links (two feet: ankles + toes)"]["blocks_total_with_symmetry"] >= out["4 links (two feet: ankles + toes)"]["walk_level_steps"]
