@@ -49,6 +49,8 @@ FP32_VECTOR_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md
 VALU_CEILING = {"cycles": 2.34, "note": "profiles/r06_valu_issue.txt (tools/valu_issue_probe.sh): one workgroup per CU, 4 waves of dependent v_fma_f32 chains on every SIMD, "
                                          "4 x 262144 instructions per SIMD in 1.100 ms = 1.049 ns each at a MEASURED 2228 MHz (GRBM_GUI_ACTIVE / 8 XCDs / kernel time) = 2.34 cycles "
                                          "(2.38 at 2 waves); round 4's 2.67 - 2.88 were 'nominal cycles at an assumed 2.4 GHz' of sub-0.3 ms kernels, launch overhead included"}
+HORIZON = 32
+WHOLE_EPOCHS = 10                       # the separately timed whole-epoch block behind a short / ragged --steps
 
 
 # ---------------------------------------------------------------------------------------------- launching the ranks

@@ -1,5 +1,5 @@
 #!/bin/bash
-# where a physics_ll_kernel instantiation spills: scratch stores / loads by source line.  usage: tools/spill_sites.sh <7 template flags, e.g. 1000111> [extra flags]
+# where a physics_ll_kernel instantiation spills: scratch stores / loads by source line.  usage: tools/spill_sites.sh <8 template flags CONTACT MULTI TGS DIAG BALL JOBS LIMITS VFRIC, e.g. 10001110> [extra flags]
 T=$1; shift
 cd "$(dirname "$0")/../vid2player3d_amd/csrc"
 M=$(echo $T | sed 's/./Lb&E/g')
