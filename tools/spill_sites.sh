@@ -3,7 +3,7 @@
 T=$1; shift
 cd "$(dirname "$0")/../vid2player3d_amd/csrc"
 M=$(echo $T | sed 's/./Lb&E/g')
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast-honor-pragmas -fno-vectorize -fno-slp-vectorize -fassociative-math -freciprocal-math -fno-signed-zeros -fno-trapping-math -fno-honor-nans "$@" -gline-tables-only --cuda-device-only -S physics_ll.hip -o /tmp/spill_$$.s 2>/dev/null
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast-honor-pragmas -fno-vectorize -fno-slp-vectorize -fassociative-math -freciprocal-math -fno-signed-zeros -fno-trapping-math -fno-honor-nans -mllvm -sink-insts-to-avoid-spills=1 "$@" -gline-tables-only --cuda-device-only -S physics_ll.hip -o /tmp/spill_$$.s 2>/dev/null
 python3 - /tmp/spill_$$.s "_ZN3v2p17physics_ll_kernelI${M}EEvNS_8PhysArgsE" <<'PY'
 import re,sys,collections
 L=open(sys.argv[1]).read().split('\n'); name=sys.argv[2]

@@ -37,6 +37,7 @@ def build_info():
             "hipcc": _hipcc()}
 
 
+LL_CODEGEN_FLAGS = ["-mllvm", "-sink-insts-to-avoid-spills=1"]
 LL_MATH_FLAGS = ["-fassociative-math", "-freciprocal-math", "-fno-signed-zeros", "-fno-trapping-math", "-fno-honor-nans"]
 # what the physics kernel is compiled from: the counters kept under profiles/ (VALU instructions, HBM bytes per launch) describe ONE
 # kernel; they carry this hash, and bench.py drops them from its line when the sources have moved on
@@ -51,7 +52,7 @@ def kernel_source_hash():
     for s in KERNEL_SOURCES:
         with open(os.path.join(CSRC, s), "rb") as f:
             h.update(s.encode() + b"\0" + f.read() + b"\0")
-    h.update(" ".join(LL_MATH_FLAGS + [os.environ.get("V2P_LL_STRICT_MATH", ""), os.environ.get("V2P_FLAGS_PHYSICS_LL", "")]).encode())
+    h.update(" ".join(LL_MATH_FLAGS + LL_CODEGEN_FLAGS + [os.environ.get("V2P_LL_STRICT_MATH", ""), os.environ.get("V2P_FLAGS_PHYSICS_LL", "")]).encode())
     return h.hexdigest()[:16]
 
 
@@ -85,6 +86,11 @@ def build(force=False, verbose=False, lib_out=None, tag=""):
             # of the file for why the flags are spelled out instead of -ffast-math); V2P_LL_STRICT_MATH=1 builds it precise (A/B, bisecting)
             fl = [f if f != "-ffp-contract=fast" else "-ffp-contract=fast-honor-pragmas" for f in fl]
             fl = fl + (["-DV2P_LL_STRICT_MATH"] if os.environ.get("V2P_LL_STRICT_MATH") else LL_MATH_FLAGS)
+            # MachineLICM hoists every loop-invariant address / uniform expression in front of the substep loop and the register allocator then
+            # spills them across it; this switch lets it sink them back instead (round 6: racket + ball + limits 328 -> 184 B of scratch per
+            # lane, 12.89 -> 13.64 M env-steps/s; limits alone 84 -> 0 B; the headline instantiation 20 -> 0 B, unchanged speed:
+            # profiles/r06d_variants_spill.log)
+            fl = fl + LL_CODEGEN_FLAGS
         extra = os.environ.get("V2P_FLAGS_" + s.split(".")[0].upper() + ("_REGS" if regs else ""))  # experiments: per-object flag override, e.g. V2P_FLAGS_PHYSICS_LL="-O1" (V2P_FLAGS_PHYSICS_LL_REGS: the register build)
         if extra:
             fl = [f for f in fl if f != "-O3"] + extra.split()

@@ -298,6 +298,11 @@ constexpr bool PARK3 = V2P_LL_PARK3 != 0;
 #ifndef V2P_LL_DPP_DOWN
 #define V2P_LL_DPP_DOWN 0
 #endif
+#ifndef V2P_LL_EXP
+#define V2P_LL_EXP 0   // TIMING experiments of round 6 (tools/mkvariant.sh; bits 1, 2, 4 break the physics on purpose - they measure what a part costs):
+                       // 1 no post-bounce after limit rows, 2 limit rows never change anything, 4 limit stops taken out of the walk (Lambda depth kept),
+                       // 8 Lambda recursion only as deep as the CONTACT stops, 16 no joint ever has an active limit row (the code stays)
+#endif
 constexpr int PARK_TAR = 0, PARK_W0 = 3, PARK_XD0 = 6, PARK_Q = 9, PARK_X = 13, PARK_CR = 16, PARK_CB = 28, PARK_CL = 32,
               PARK_SCR = PARK3 ? 44 : 16,  // (one row of 64 dwords per wave: lane of the k-th near link)
               PARK_SLOTS = PARK_SCR + 1;  // LDS parking slots (dwords per lane)
@@ -385,6 +390,7 @@ __device__ __forceinline__ void vfric_frame(const V3& w0, const V3& xd0, const V
 template <bool CONTACT, bool MULTI, bool TGS, bool DIAG, bool BALL, bool JOBS, bool LIMITS, bool VFRIC = false>
 __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (LIMITS ? V2P_LL_WPS_LIMITS : V2P_LL_WPS))) void physics_ll_kernel(PhysArgs a) {
     constexpr bool WALK = V2P_LL_WALK != 0;  // the sweep as one walk over the tree (see the sweep)
+    constexpr bool OPAQUE_H = BALL || LIMITS;  // (the headline instantiation keeps its 0 - 12 B of scratch either way: measured no difference, profiles/r06d_variants_spill.log)
     const int64_t N = a.n;
     const int lane = threadIdx.x & 63;
     const int half = lane >> 5;
@@ -504,7 +510,7 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
     ConstShape* S = MULTI ? (ConstShape*)(a.shapes + sid) : &M.shape;
     float* __restrict__ st = a.state;
     const EnvParams& P = a.p;
-    const float h = P.h;
+    const float h_launch = P.h;
     const int maxd = M.max_depth;
     const int multi = M.multi_child_levels;
     const int nonchain = M.nonchain_levels;
@@ -802,6 +808,11 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
 #endif
 
     for (int sub = sub0; sub < sub1; ++sub) {
+        // (the substep length behind an opaque scalar move: the dozen uniform expressions of it - 1 / h, h / n_iter, erp / hs, 1 / (1 + h damping),
+        // margin / h ... - are then evaluated where they are used, a few scalar-operand instructions each, instead of being hoisted in front
+        // of the substep loop and kept - spilled: in the racket + ball kernels - across all of it)
+        float h = h_launch;
+        if constexpr (OPAQUE_H) asm volatile("" : "+s"(h));
         const bool wrench_on = sub < P.hold_sub;
         const bool last = sub == nsub - 1;
         // a substep that is being recomputed by a job that gave up waiting for its predecessor: it publishes nothing (the predecessor does)
@@ -1413,7 +1424,7 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                 }
                 limact = anyrow;
             }
-            const unsigned long long lmb = LIMITS ? __ballot(valid && limact) : 0ull;
+            const unsigned long long lmb = (LIMITS && !(V2P_LL_EXP & 16)) ? __ballot(valid && limact) : 0ull;
             const unsigned lm0 = (unsigned)lmb, lm1 = (unsigned)(lmb >> 32);
             if (DIAG && a.wave_times) { const int tt = __popc(half ? m1 : m0); tsum += tt; tmaxs = tt > tmaxs ? tt : tmaxs; }
             if (last) {
@@ -1423,15 +1434,15 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                 for (unsigned t = mine; t; t &= t - 1) { const int dd = M.depth[__ffs(t) - 1]; kdep = dd > kdep ? dd : kdep; }
             }
             if (DIAG && a.prof && ((a.prof_heavy ? blockIdx.x < 8u : (blockIdx.x & 63) == 0)) && lane == 0) { atomicAdd((unsigned long long*)&a.prof[9], (unsigned long long)(__popc(m0) + __popc(m1))); atomicAdd((unsigned long long*)&a.prof[10], 1ull); }
-            const bool sweep_on = ((m0 | m1 | lm0 | lm1) || (BALL && any64(ballground))) && P.n_iter > 0;
+            const bool sweep_on = ((m0 | m1 | ((V2P_LL_EXP & 32) ? 0u : (lm0 | lm1))) || (BALL && any64(ballground))) && P.n_iter > 0;
             if (PARK2 && !sweep_on) unpark_vel(w, xd);
             if (sweep_on) {
                 // deepest touched link of either env: links below it are never read during the sweep, so Lambda and the
                 // per-update propagation stop there; their velocities catch up once at the end (the propagation is linear)
                 // (each env stops at ITS deepest touched link, so its arithmetic does not depend on which env shares the wave)
                 int dn0 = 0, dn1 = 0;
-                for (unsigned t = m0 | lm0; t; t &= t - 1) { const int dd = M.depth[__ffs(t) - 1]; dn0 = dd > dn0 ? dd : dn0; }
-                for (unsigned t = m1 | lm1; t; t &= t - 1) { const int dd = M.depth[__ffs(t) - 1]; dn1 = dd > dn1 ? dd : dn1; }
+                for (unsigned t = (V2P_LL_EXP & 8) ? m0 : (m0 | lm0); t; t &= t - 1) { const int dd = M.depth[__ffs(t) - 1]; dn0 = dd > dn0 ? dd : dn0; }
+                for (unsigned t = (V2P_LL_EXP & 8) ? m1 : (m1 | lm1); t; t &= t - 1) { const int dd = M.depth[__ffs(t) - 1]; dn1 = dd > dn1 ? dd : dn1; }
                 const int dneed = dn0 > dn1 ? dn0 : dn1, dmin = dn0 < dn1 ? dn0 : dn1;
                 const bool insweep = dep <= (half ? dn1 : dn0);  // this link moves with every update; the others catch up afterwards
                 LLPH(4);
@@ -1584,7 +1595,7 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                 // the move INTO each touched link, from the touched link before it (cyclically): depth of their lowest common ancestor |
                 // depth of the link before << 4 | own depth << 8 | side-entry levels << 12 (12 bits).  (A link has depth + 1 ancestors-or-self: depths from ballots.)
                 // LIMITS: the walk also stops at the joints that carry limit rows (their block comes right before the contact block of the link)
-                const unsigned v0 = LIMITS ? m0 | lm0 : m0, v1 = LIMITS ? m1 | lm1 : m1;
+                const unsigned v0 = (LIMITS && !(V2P_LL_EXP & 4)) ? m0 | lm0 : m0, v1 = (LIMITS && !(V2P_LL_EXP & 4)) ? m1 | lm1 : m1;
                 V3 jt_new{0.f, 0.f, 0.f};  // LIMITS: limit impulse of this joint not yet handed up (its reaction, -jt, goes to the parent)
                 // ALT (experiment, off by default: V2P_LL_ALT_SWEEP): odd PGS sweeps visit the stops in DESCENDING order - minfo_rev = the move into a
                 // stop from the stop AFTER it (same fields; the highest stop has none: a backward sweep starts on it, where the forward sweep ended)
@@ -1858,14 +1869,14 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                                     jt_new = jt_new + jt;
                                     lchg = tq[0] != 0.f || tq[1] != 0.f || tq[2] != 0.f;
                                 }
-                                const unsigned long long lc = __ballot(lchg);
+                                const unsigned long long lc = __ballot((V2P_LL_EXP & 2) ? false : lchg);
                                 const int sl = __builtin_amdgcn_readfirstlane(((unsigned)lc != 0u ? 1 : 0) | ((unsigned)(lc >> 32) != 0u ? 2 : 0));
                                 if (sl) {
                                     // the joint answers, and so does everything above it: one joint up (the parent turns), one joint down again
                                     live0 = live0 || (sl & 1);
                                     live1 = live1 || (sl & 2);
                                     moved |= sl;
-                                    walk_to(b0 < 0 ? 0 : b0, b1 < 0 ? 0 : b1, j0i, j1i, (sl & 1) != 0, (sl & 2) != 0);
+                                    if (!(V2P_LL_EXP & 1)) walk_to(b0 < 0 ? 0 : b0, b1 < 0 ? 0 : b1, j0i, j1i, (sl & 1) != 0, (sl & 2) != 0);
                                 }
                             }
                         }
