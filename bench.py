@@ -486,6 +486,7 @@ def main():
     ap.add_argument("--freeze-terminated", action="store_true", help="opt-in engine feature: terminated envs are not simulated until the epoch reset (not reference behaviour)")
     ap.add_argument("--djokovic", action="store_true", help="BASELINE config 4 (djokovic_im.yaml: terminationHeadHeight -0.5, faster clips)")
     ap.add_argument("--job-mono", type=int, default=None, help="v2p_sim_cfg.job_mono_permille (tuning sweeps)")
+    ap.add_argument("--job-lead", type=int, default=None, help="v2p_sim_cfg.job_lead: substeps of the first job of a cut pair (tuning sweeps)")
     ap.add_argument("--kernel-build", type=int, default=None, choices=(0, 1, 2), help="v2p_sim_cfg.kernel_build: 0 engine's choice by env count, 1 LDS-parked / 3 waves per SIMD, 2 registers / 2 waves (A/B)")
     ap.add_argument("--pair-mix", type=int, default=None, help="v2p_sim_cfg.pair_mix_permille (tuning sweeps)")
     ap.add_argument("--substep-jobs", type=int, default=1, help="1: physics launch cut into (substep, env pair) jobs (v2p_sim_cfg.substep_jobs); same results, finer load balancing")
@@ -547,7 +548,7 @@ def main():
         tasks = [build_task(n // G, local_rank, seed=7 + rank + 100 * g, contact=not args.no_contact, per_clip_shapes=args.per_clip_shapes, num_shapes=args.num_shapes, djokovic=args.djokovic or args.racket_ball,
                           freeze=args.freeze_terminated, solver=args.solver, racket_ball=args.racket_ball, substep_jobs=bool(args.substep_jobs),
                           joint_limits=args.joint_limits,
-                          env_extra={k: v for k, v in (("job_mono_permille", args.job_mono), ("pair_mix_permille", args.pair_mix), ("kernel_build", args.kernel_build), ("ball_body_contacts", None if args.ball_body_contacts else False), ("friction_frame", None if args.friction_frame == "world" else args.friction_frame)) if v is not None})  # per-rank seed like run.py:37
+                          env_extra={k: v for k, v in (("job_mono_permille", args.job_mono), ("pair_mix_permille", args.pair_mix), ("job_lead", args.job_lead), ("kernel_build", args.kernel_build), ("ball_body_contacts", None if args.ball_body_contacts else False), ("friction_frame", None if args.friction_frame == "world" else args.friction_frame)) if v is not None})  # per-rank seed like run.py:37
                  for g in range(G)]
         task = tasks[0]
     if args.ppo:

@@ -58,22 +58,28 @@ def main(prefix, write):
             d = last_json(p)
             rows.append(("`--per-clip-shapes --num-shapes %d` (one body shape per clip, env i -> shape i %% %d)" % (S, S), *fmt(d), "`r05_shapes_bench_%d.log`" % S))
     ppo_log = os.path.join(ROOT, "profiles", "r05g_bench_ppo.log")  # (the rollout fusion landed after the r05f round: its own log)
+    if os.path.exists(P("bench_ppo.log")) and not prefix.startswith("r05"):
+        ppo_log = P("bench_ppo.log")
     d = last_json(ppo_log if os.path.exists(ppo_log) else P("bench_ppo.log"))
     ppo = ""
     if d:
         c = d["config"]
         ppo = ("\n\nFull PPO loop (`bench.py --ppo`, 8192 envs, `%s`): **fps step %.2f M** (rollout: T_play %.4f s per epoch), fps total %.3f M "
-               "(T_update %.3f s per epoch: fp32 MLPs through rocBLAS, outside this path)." % ("r05g_bench_ppo.log" if os.path.exists(ppo_log) else prefix + "_bench_ppo.log", c["fps_step"] / 1e6, c["T_play_s_per_epoch"], c["fps_total"] / 1e6, c["T_update_s_per_epoch"]))
+               "(T_update %.3f s per epoch: fp32 MLPs through rocBLAS, outside this path)." % (os.path.basename(ppo_log) if os.path.exists(ppo_log) else prefix + "_bench_ppo.log", c["fps_step"] / 1e6, c["T_play_s_per_epoch"], c["fps_total"] / 1e6, c["T_update_s_per_epoch"]))
     r = head["roofline"]
+    VI = (r.get("valu") or {}).get("valu_issue", {})
     cb = head.get("cpu_baseline")
     out = ["| configuration (one MI355X) | env-steps/s | ms per step | physics kernel ms | log |", "|---|---|---|---|---|"]
     out += ["| %s | %s | %s | %s | %s |" % row for row in rows]
     txt = "\n".join(out)
     txt += ("\n\nRoofline of the default command (`roofline` of the line): physics kernel %.4f ms per launch; algorithmic %.2f MB per launch -> %.0f GB/s = **%.4f of the 8 TB/s HBM peak**; "
-            "measured HBM traffic %.1f MB per launch (%.2f x algorithmic); fp32 vector: %.2f TFLOP/s = %.4f of 157.3; VALU issue: %.2f of the measured ceiling while three waves are resident, "
-            "%.1f of 64 lanes active per VALU instruction."
+            "measured HBM traffic %.1f MB per launch (%.2f x algorithmic); fp32 vector: %.2f TFLOP/s = %.4f of 157.3; VALU issue while three waves are resident: one instruction per "
+            "%.2f cycles per SIMD = %.2f of the guide's 2-cycle wave64 issue, %.2f of the %.2f cycles measured on this GPU at a measured clock (`profiles/r06_valu_issue.txt`); "
+            "%.1f of 64 lanes active per VALU instruction%s."
             % (r["kernel_ms"], r["algorithmic_bytes_per_launch"] / 1e6, r["achieved"], r["frac"], (r.get("traffic") or 0) / 1e6, (r.get("traffic") or 0) / r["algorithmic_bytes_per_launch"],
-               r.get("valu_tflops", 0), r.get("valu_frac", 0), r.get("valu", {}).get("valu_issue", {}).get("frac", 0), r.get("valu", {}).get("lanes_active_per_valu_op", 0)))
+               r.get("valu_tflops", 0), r.get("valu_frac", 0), VI.get("cycles_per_inst_per_simd_at_3_waves", 0), VI.get("frac_of_guide_ceiling", 0), VI.get("frac_of_measured_ceiling", 0),
+               VI.get("ceiling_cycles_per_inst_measured", 0), r.get("valu", {}).get("lanes_active_per_valu_op", 0),
+               ("; the kernel ran at %.0f MHz" % r["valu"]["kernel_clock_mhz"]) if r.get("valu", {}).get("kernel_clock_mhz") else ""))
     if cb:
         b = cb["by_num_envs"]
         txt += ("\n\n`cpu_baseline` (kind \"port\": the float64 C oracle + numpy task ops on the GPU box's host, %s): **%.1f k env-steps/s at 8192 envs**, %.1f k at 1024, %.1f k at 4; "
@@ -92,5 +98,5 @@ def main(prefix, write):
 
 
 if __name__ == "__main__":
-    pre = sys.argv[sys.argv.index("--prefix") + 1] if "--prefix" in sys.argv else "r05f"
+    pre = sys.argv[sys.argv.index("--prefix") + 1] if "--prefix" in sys.argv else "r06f"
     main(pre, "--write" in sys.argv)
