@@ -1778,13 +1778,6 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                 // sweep in the other direction reaches the same links over other moves, i.e. with other rounding, and an env that kept
                 // iterating for its wave partner's sake would depend on it.)
                 int done = 0;
-                // LIMITS: the one-joint move that lets the parent answer a limit impulse ("bounce") is DEFERRED where nothing needs it at once
-                // (round 6).  It is needed at once when the same stop carries contact rows (they read the link's velocity) or when the env has
-                // no other stop.  Otherwise the env's NEXT move does the work: a move to a link outside the joint's subtree goes up through the
-                // parent anyway (the pending impulse and its reaction travel with what the link hands up); a move DOWN into the subtree (elbow ->
-                // wrist) is widened by one level - up to the parent, which turns, and down again through the joint - instead of being preceded
-                // by a bounce of its own.  pb: bit h = env h has a deferred bounce; pbi_h = the widened move without its destination depth.
-                int pb = 0, pbi0 = 0, pbi1 = 0;
                 for (int it = 0; it < P.n_iter; ++it) {
                     unsigned t0 = (done & 1) ? 0u : v0, t1 = (done & 2) ? 0u : v1;
                     int moved = 0;  // bit h: env h changed something in this sweep (wave-uniform)
@@ -1829,13 +1822,7 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                         int came_down = 0;  // LIMITS: bit h = env h has just come DOWN to its link (the lowest common ancestor of the move lies above it)
                         if (smv) {
                             const int msel = backward ? minfo_rev : minfo;
-                            int i0 = __builtin_amdgcn_readlane(msel, b0 < 0 ? 0 : b0), i1 = __builtin_amdgcn_readlane(msel, 32 + (b1 < 0 ? 0 : b1));
-                            if constexpr (LIMITS) {
-                                // (the destination lies in the subtree of the link the walk stands on <=> that link is the move's lowest common ancestor)
-                                if ((pb & smv & 1) && (i0 & 15) == ((i0 >> 4) & 15)) i0 = pbi0 | (i0 & 0xf00);
-                                if ((pb & smv & 2) && (i1 & 15) == ((i1 >> 4) & 15)) i1 = pbi1 | (i1 & 0xf00);
-                                pb &= ~smv;
-                            }
+                            const int i0 = __builtin_amdgcn_readlane(msel, b0 < 0 ? 0 : b0), i1 = __builtin_amdgcn_readlane(msel, 32 + (b1 < 0 ? 0 : b1));
                             walk_to(b0 < 0 ? 0 : b0, b1 < 0 ? 0 : b1, i0, i1, (smv & 1) != 0, (smv & 2) != 0);
                             if (LIMITS) came_down = smv & (((i0 & 15) < ((i0 >> 8) & 15) ? 1 : 0) | ((i1 & 15) < ((i1 >> 8) & 15) ? 2 : 0));
                         }
@@ -1889,13 +1876,10 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                                     live0 = live0 || (sl & 1);
                                     live1 = live1 || (sl & 2);
                                     moved |= sl;
-                                    // at once: the stop carries contact rows as well, or it is the env's only stop
-                                    const int now = sl & ((((b0 >= 0 && ((m0 >> b0) & 1u)) || (v0 & (v0 - 1u)) == 0u) ? 1 : 0) | (((b1 >= 0 && ((m1 >> b1) & 1u)) || (v1 & (v1 - 1u)) == 0u) ? 2 : 0));
-                                    const int later = sl & ~now;
-                                    if (later & 1) pbi0 = j0i & ~0xf00;
-                                    if (later & 2) pbi1 = j1i & ~0xf00;
-                                    pb |= later;
-                                    if (now && !(V2P_LL_EXP & 1)) walk_to(b0 < 0 ? 0 : b0, b1 < 0 ? 0 : b1, j0i, j1i, (now & 1) != 0, (now & 2) != 0);
+                                    // (deferring this move to the env's next one - it goes up through the parent anyway, or can be widened by a level when it
+                                    // goes down into the joint's subtree - was built and measured in round 6: +0.4 %, inside the noise, because most limit
+                                    // stops of the racket arm carry contact rows too and need the link current at once; not kept)
+                                    if (!(V2P_LL_EXP & 1)) walk_to(b0 < 0 ? 0 : b0, b1 < 0 ? 0 : b1, j0i, j1i, (sl & 1) != 0, (sl & 2) != 0);
                                 }
                             }
                         }
@@ -2006,7 +1990,6 @@ __global__ __launch_bounds__(64 * LL_WPB, DIAG ? 2 : (BALL ? V2P_LL_WPS_BALL : (
                         walk_close(dneed, false);  // (the links below catch up once, after the last iteration)
                         un_tot = un_new = uf_new = Dw = Dv = V3{0.f, 0.f, 0.f};
                         live0 = live1 = false;
-                        pb = 0;  // (the closing move went up through every parent)
                     }
                     if (!TGS) {  // (PGS: fixed biases - a sweep without any change would be repeated by the remaining ones)
                         done |= ~moved & 3;
