@@ -38,6 +38,8 @@ timeout 900 python tools/parity_sweep.py 2048 > $O/parity_sweep.log 2>&1
 timeout 1500 python tools/parity_sweep.py 16384 2>&1 | grep -v "^\[rows\]" > $O/parity_sweep_16k.log
 timeout 600 python tools/soak.py 4000 2>&1 | tail -3 > $O/soak.log
 timeout 600 python tools/soak.py 4000 racket 2>&1 | tail -3 > $O/soak_racket_ball.log
+timeout 900 python tools/soak.py 8000 racket 8192 tgs 2>&1 | tail -3 > $O/soak_racket_ball_tgs.log
+timeout 600 python tools/soak.py 4000 racket 8192 tgs velocity 2>&1 | tail -3 > $O/soak_racket_ball_tgs_vfric.log
 # round 5: two processes on one GPU, the rollout's kernel budget, per-clip shapes at scale (own script), MFMA microbenchmark, host CPU scaling
 timeout 900 python tools/soak2.py 2000 > $O/soak_two_processes.log 2>&1
 timeout 300 python tools/play_profile.py 4 > $O/play_wall.log 2>&1

@@ -1,4 +1,4 @@
-"""Long-run sanity of the engine on the GPU box: python tools/soak.py [steps] [racket|humanoid] [num_envs]  (racket: the racket + ball task, a
+"""Long-run sanity of the engine on the GPU box: python tools/soak.py [steps] [racket|humanoid] [num_envs] [pgs|tgs] [world|velocity]  (racket: the racket + ball task, a
 ball served at every player each epoch: ball x hull / racket / ground contacts, joint limits, substep jobs; num_envs <= 5120 runs the
 library's register build, 6000 envs cut into substep jobs there)."""
 import sys, torch
@@ -6,7 +6,9 @@ sys.path.insert(0, ".")
 import bench
 RACKET = len(sys.argv) > 2 and sys.argv[2] == "racket"
 NENV = int(sys.argv[3]) if len(sys.argv) > 3 else 8192
-task = bench.build_task(NENV, 0, 7, djokovic=RACKET, racket_ball=RACKET, substep_jobs=True)
+SOLVER = sys.argv[4] if len(sys.argv) > 4 else "pgs"
+FRAME = sys.argv[5] if len(sys.argv) > 5 else "world"
+task = bench.build_task(NENV, 0, 7, djokovic=RACKET, racket_ball=RACKET, substep_jobs=True, solver=SOLVER, env_extra={"friction_frame": FRAME})
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 n = task.num_envs
 bad = 0
@@ -37,4 +39,4 @@ for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 2000):
         bad += (not ok) + (not okp)
 task.check()
 print("substep jobs recomputed after waiting in vain:", task.job_recoveries())
-print("SOAK", "OK" if bad == 0 else "FAILED", "| envs", n, "| build:", task.kernel_build())
+print("SOAK", "OK" if bad == 0 else "FAILED", "| envs", n, "| build:", task.kernel_build(), "| solver", task.contact_solver, "| friction frame", task.friction_frame)

@@ -319,7 +319,15 @@ constexpr int LDS_FLOATS_PER_WAVE = PARK_SLOTS * 64 + 2 * BL_SLOTS + ROOTLAM_FLO
 // registers would be spilled around on every substep
 // (the closest point comes back BY VALUE, xyz = point, w = distance: an out-parameter by reference is a stack slot of the caller that the
 // callee writes through a pointer)
-__device__ __noinline__ f4 ball_hull_distance(ConstShape* S, int v0, int nv, V3 c) {
+#ifndef V2P_LL_GJK_INLINE
+#define V2P_LL_GJK_INLINE 0
+#endif
+#if V2P_LL_GJK_INLINE
+__device__ __forceinline__
+#else
+__device__ __noinline__
+#endif
+f4 ball_hull_distance(ConstShape* S, int v0, int nv, V3 c) {
     V3 p;
     const float d = hull_closest([&](int k) { return V3{S->hull_verts[v0 + k][0], S->hull_verts[v0 + k][1], S->hull_verts[v0 + k][2]}; }, nv, c, p);
     return f4{p.x, p.y, p.z, d};
